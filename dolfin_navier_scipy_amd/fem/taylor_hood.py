@@ -1,0 +1,237 @@
+"""P2/P1 Taylor-Hood assembly on triangles (NumPy, host side).
+
+Input scaffolding (SURVEY.md §7 stage 1): produces the SciPy CSR matrices and
+vectors that `dolfin_to_sparrays` hands to the hot path, from the same weak
+forms:
+
+ * `M`  = inner(u, v) dx                         (reference dts:243)
+ * `A`  = nu*inner(2*eps(u), grad(v)) dx, eps = symmetric gradient (dts:236-245)
+ * `J`  = q*div(u) dx, `JT` = div(v)*p dx        (dts:254-255)
+ * `MP` = inner(p, q) dx                         (dts:244)
+ * `N(u)u` = inner(grad(u)*u, v) dx              (dts:463)
+ * `N1(u0)` = inner(grad(u)*u0, v) dx, `N2(u0)` = inner(grad(u0)*u, v) dx
+                                                 (dts:358-359)
+
+Degrees of freedom: P2 nodes are the mesh vertices followed by the edge
+midpoints; velocity dof `2*node + component`; pressure dof = vertex index.
+The numbering differs from dolfin's -- parity is with the reference
+*algorithm* on identical matrices, not with dolfin's assembly.
+"""
+import numpy as np
+import scipy.sparse as sps
+
+__all__ = ['TaylorHood']
+
+# 7-point, degree-5 Gauss rule on the triangle (barycentric coordinates)
+_s15 = np.sqrt(15.0)
+_t1, _t2 = (6.0 - _s15)/21.0, (6.0 + _s15)/21.0
+_w1, _w2 = (155.0 - _s15)/1200.0, (155.0 + _s15)/1200.0
+_QP = np.array([[1/3., 1/3., 1/3.],
+                [1-2*_t1, _t1, _t1], [_t1, 1-2*_t1, _t1], [_t1, _t1, 1-2*_t1],
+                [1-2*_t2, _t2, _t2], [_t2, 1-2*_t2, _t2], [_t2, _t2, 1-2*_t2]])
+_QW = np.array([9/40., _w1, _w1, _w1, _w2, _w2, _w2])  # sums to 1
+
+# local P2 node k = 3,4,5 sits on the edge opposite to vertex k-3
+_EDGE_OF = [(1, 2), (0, 2), (0, 1)]
+
+
+def _p2_basis(lam):
+    """P2 shape functions at barycentric points `lam (nq, 3)` -> `(nq, 6)`"""
+    phi = np.empty((lam.shape[0], 6))
+    for k in range(3):
+        phi[:, k] = lam[:, k]*(2*lam[:, k] - 1)
+    for k, (i, j) in enumerate(_EDGE_OF):
+        phi[:, 3+k] = 4*lam[:, i]*lam[:, j]
+    return phi
+
+
+def _p2_dbasis_dlam(lam):
+    """d(phi_a)/d(lam_i) at `lam (nq,3)` -> `(nq, 6, 3)`"""
+    d = np.zeros((lam.shape[0], 6, 3))
+    for k in range(3):
+        d[:, k, k] = 4*lam[:, k] - 1
+    for k, (i, j) in enumerate(_EDGE_OF):
+        d[:, 3+k, i] = 4*lam[:, j]
+        d[:, 3+k, j] = 4*lam[:, i]
+    return d
+
+
+class TaylorHood(object):
+    """Taylor-Hood spaces on a `Mesh2D` and the forms of the NSE"""
+
+    def __init__(self, mesh):
+        self.mesh = mesh
+        edges, celledges, nadj = mesh.edges()
+        self.edges, self.celledges, self.edge_nadj = edges, celledges, nadj
+        nv = mesh.nverts
+        self.nnodes = nv + edges.shape[0]
+        self.vdim = 2*self.nnodes
+        self.pdim = nv
+        self.cellnodes = np.hstack([mesh.cells, nv + celledges])  # (nc, 6)
+        self.nodecoords = np.vstack(
+            [mesh.verts, 0.5*(mesh.verts[edges[:, 0]]+mesh.verts[edges[:, 1]])])
+        # geometry: gradients of the barycentric coordinates, (nc, 3, 2)
+        p = mesh.verts[mesh.cells]
+        self.area = mesh.cell_areas()
+        glam = np.empty((mesh.ncells, 3, 2))
+        for k in range(3):
+            i, j = (k+1) % 3, (k+2) % 3
+            glam[:, k, 0] = (p[:, i, 1] - p[:, j, 1])/(2*self.area)
+            glam[:, k, 1] = (p[:, j, 0] - p[:, i, 0])/(2*self.area)
+        self.glam = glam
+        self._phi = _p2_basis(_QP)                  # (nq, 6)
+        self._dphi_dlam = _p2_dbasis_dlam(_QP)      # (nq, 6, 3)
+        # physical P2 gradients at quadrature points, (nc, nq, 6, 2)
+        self._gphi = np.einsum('qai,cid->cqad', self._dphi_dlam, glam)
+        self._psi = _QP                              # P1 basis = lambdas
+
+    # -- helpers ---------------------------------------------------------
+    def _vdofs(self):
+        """cell velocity dofs `(nc, 6, 2)`"""
+        return 2*self.cellnodes[:, :, None] + np.arange(2)[None, None, :]
+
+    def _assemble(self, rows, cols, vals, shape):
+        mat = sps.coo_matrix((vals.ravel(), (rows.ravel(), cols.ravel())),
+                             shape=shape).tocsr()
+        mat.sum_duplicates()
+        mat.eliminate_zeros()   # as `mat_dolfin2sparse`, reference dts:80
+        mat.sort_indices()
+        return mat
+
+    # -- linear forms and matrices ---------------------------------------
+    def stokes_mats(self, nu=1.0):
+        """`dict(M, A, J, JT, MP)` on the full spaces (no BCs resolved)"""
+        nc = self.mesh.ncells
+        w = _QW[None, :]*self.area[:, None]                       # (nc, nq)
+        phi, gphi, psi = self._phi, self._gphi, self._psi
+        vd = self._vdofs()                                        # (nc,6,2)
+        # scalar P2 mass and stiffness blocks
+        mloc = np.einsum('cq,qa,qb->cab', w, phi, phi)
+        kloc = np.einsum('cq,cqad,cqbd->cab', w, gphi, gphi)
+        # d_c phi_a * d_d phi_b
+        gloc = np.einsum('cq,cqae,cqbd->cabed', w, gphi, gphi)
+        rows, cols, mv, av = [], [], [], []
+        for d in range(2):           # test component
+            for c in range(2):       # trial component
+                r = np.broadcast_to(vd[:, :, None, d], (nc, 6, 6))
+                cc = np.broadcast_to(vd[:, None, :, c], (nc, 6, 6))
+                # A[(a,d),(b,c)] = nu*(delta_cd grad a.grad b + d_c a d_d b)
+                aval = nu*gloc[:, :, :, c, d]
+                if c == d:
+                    aval = aval + nu*kloc
+                    mv.append(mloc)
+                else:
+                    mv.append(np.zeros_like(mloc))
+                rows.append(r), cols.append(cc), av.append(aval)
+        rows, cols = np.array(rows), np.array(cols)
+        M = self._assemble(rows, cols, np.array(mv), (self.vdim, self.vdim))
+        A = self._assemble(rows, cols, np.array(av), (self.vdim, self.vdim))
+        # divergence: J[q_a, (b,c)] = int psi_a d_c phi_b
+        jloc = np.einsum('cq,qa,cqbd->cabd', w, psi, gphi)      # (nc,3,6,2)
+        jr = np.broadcast_to(self.mesh.cells[:, :, None, None], (nc, 3, 6, 2))
+        jc = np.broadcast_to(vd[:, None, :, :], (nc, 3, 6, 2))
+        J = self._assemble(jr, jc, jloc, (self.pdim, self.vdim))
+        mploc = np.einsum('cq,qa,qb->cab', w, psi, psi)
+        pr = np.broadcast_to(self.mesh.cells[:, :, None], (nc, 3, 3))
+        pc = np.broadcast_to(self.mesh.cells[:, None, :], (nc, 3, 3))
+        MP = self._assemble(pr, pc, mploc, (self.pdim, self.pdim))
+        return dict(M=M, A=A, J=J, JT=sps.csr_matrix(J.T), MP=MP)
+
+    def _vel_at_qp(self, uvec):
+        """velocity `(nc,nq,2)` and its gradient `(nc,nq,2,2)` [i, j]=d_j u_i"""
+        uloc = np.asarray(uvec).reshape(-1)[self._vdofs()]         # (nc,6,2)
+        uq = np.einsum('qa,cai->cqi', self._phi, uloc)
+        guq = np.einsum('cqaj,cai->cqij', self._gphi, uloc)
+        return uq, guq
+
+    def convection_vec(self, uvec, utwo=None):
+        """`N(u1)u2 = inner(grad(u1)*u2, v) dx` as `(vdim, 1)` (dts:427-472)"""
+        uq, guq = self._vel_at_qp(uvec)
+        if utwo is not None:
+            uq, _ = self._vel_at_qp(utwo)
+        w = _QW[None, :]*self.area[:, None]
+        conv = np.einsum('cqij,cqj->cqi', guq, uq)               # (nc,nq,2)
+        floc = np.einsum('cq,qa,cqi->cai', w, self._phi, conv)   # (nc,6,2)
+        fvec = np.zeros(self.vdim)
+        np.add.at(fvec, self._vdofs().ravel(), floc.ravel())
+        return fvec.reshape((-1, 1))
+
+    def convection_mats(self, u0vec):
+        """`N1(u0), N2(u0), N(u0)u0` on the full space (dts:325-376)"""
+        nc = self.mesh.ncells
+        uq, guq = self._vel_at_qp(u0vec)
+        w = _QW[None, :]*self.area[:, None]
+        vd = self._vdofs()
+        # N1 = delta_cd int (u0 . grad phi_b) phi_a
+        ugphi = np.einsum('cqj,cqbj->cqb', uq, self._gphi)
+        n1loc = np.einsum('cq,qa,cqb->cab', w, self._phi, ugphi)
+        # N2[(a,d),(b,c)] = int d_c u0_d phi_b phi_a
+        n2loc = np.einsum('cq,qa,qb,cqdk->cabdk', w, self._phi, self._phi, guq)
+        rows, cols, v1, v2 = [], [], [], []
+        for d in range(2):
+            for c in range(2):
+                rows.append(np.broadcast_to(vd[:, :, None, d], (nc, 6, 6)))
+                cols.append(np.broadcast_to(vd[:, None, :, c], (nc, 6, 6)))
+                v1.append(n1loc if c == d else np.zeros_like(n1loc))
+                v2.append(n2loc[:, :, :, d, c])
+        rows, cols = np.array(rows), np.array(cols)
+        N1 = self._assemble(rows, cols, np.array(v1), (self.vdim, self.vdim))
+        N2 = self._assemble(rows, cols, np.array(v2), (self.vdim, self.vdim))
+        return N1, N2, self.convection_vec(u0vec)
+
+    # -- boundary conditions ---------------------------------------------
+    def boundary_nodes(self):
+        """P2 nodes on the boundary and their coordinates"""
+        bedges = np.where(self.edge_nadj == 1)[0]
+        nodes = np.unique(np.concatenate(
+            [self.edges[bedges].ravel(), self.mesh.nverts + bedges]))
+        return nodes, self.nodecoords[nodes]
+
+    def cylinderwake_bcs(self, xmin=0.0, xmax=2.2, ymin=0.0, ymax=0.41,
+                         xcenter=0.2, ycenter=0.2, radius=0.05,
+                         bmarg=1.e-3, obstacle_halfwidth=None):
+        """Dirichlet data of the 2D cylinder wake (problem_setups.py:371-599)
+
+        inflow parabola `4*y*(ymax-y)/ymax**2` at `x=xmin`, no-slip at the
+        channel walls and at the obstacle, do-nothing at `x=xmax`
+
+        Returns
+        -------
+        dbcinds : (K,) int32 velocity dofs with Dirichlet data
+        dbcvals : (K,) float64
+        invinds : (NV,) int32 inner velocity dofs (as reference dts:533)
+        """
+        nodes, xy = self.boundary_nodes()
+        x, y = xy[:, 0], xy[:, 1]
+        inflow = x < xmin + bmarg
+        walls = (y < ymin + bmarg) | (y > ymax - bmarg)
+        outflow = (x > xmax - bmarg) & ~walls
+        obstacle = ~inflow & ~walls & ~outflow
+        if obstacle_halfwidth is None:
+            r = np.sqrt((x-xcenter)**2 + (y-ycenter)**2)
+            if not np.all(r[obstacle] < radius + bmarg):
+                raise ValueError('unclassified boundary nodes')
+        vals = {}
+        for nd, yy in zip(nodes[inflow], y[inflow]):
+            vals[2*nd] = 4*yy*(ymax-yy)/(ymax*ymax)
+            vals[2*nd+1] = 0.0
+        for nd in np.concatenate([nodes[walls], nodes[obstacle]]):
+            vals[2*nd] = 0.0
+            vals[2*nd+1] = 0.0
+        dbcinds = np.array(sorted(vals.keys()), dtype=np.int32)
+        dbcvals = np.array([vals[k] for k in dbcinds])
+        invinds = np.setdiff1d(np.arange(self.vdim), dbcinds).astype(np.int32)
+        return dbcinds, dbcvals, invinds
+
+    def drivencavity_bcs(self, lidvel=1.0, bmarg=1e-10):
+        """enclosed flow: lid `u=(lidvel,0)` at `y=ymax`, no-slip elsewhere"""
+        nodes, xy = self.boundary_nodes()
+        ytop = self.mesh.verts[:, 1].max()
+        vals = {}
+        for nd, yy in zip(nodes, xy[:, 1]):
+            vals[2*nd] = lidvel if yy > ytop - bmarg else 0.0
+            vals[2*nd+1] = 0.0
+        dbcinds = np.array(sorted(vals.keys()), dtype=np.int32)
+        dbcvals = np.array([vals[k] for k in dbcinds])
+        invinds = np.setdiff1d(np.arange(self.vdim), dbcinds).astype(np.int32)
+        return dbcinds, dbcvals, invinds
