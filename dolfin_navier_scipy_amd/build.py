@@ -1,0 +1,46 @@
+"""Build the in-tree gfx950 shared library with hipcc (cross-compiles without
+a GPU).  `python -m dolfin_navier_scipy_amd.build`"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+SOURCES = ['dns_amd.hip']
+HEADERS = ['common.hpp', 'kernels.hpp', 'bicgstab_kernels.hpp', 'solver.hpp',
+           'imex.hpp', 'imex_capi.inc',
+           os.path.join('..', '..', 'include', 'dns_amd.h')]
+LIB = os.path.join(CSRC, 'libdnsamd.so')
+
+
+def _hipcc():
+    for cand in (shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    libtime = os.path.getmtime(LIB)
+    for name in SOURCES + HEADERS:
+        if os.path.getmtime(os.path.join(CSRC, name)) > libtime:
+            return True
+    return False
+
+
+def build_library(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
+           '-shared', '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB
+
+
+if __name__ == '__main__':
+    build_library(force='--force' in sys.argv)

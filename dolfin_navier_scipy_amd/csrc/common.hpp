@@ -1,0 +1,125 @@
+// Shared host-side plumbing for the gfx950 saddle-point library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dns_amd.h"
+
+namespace dns {
+
+constexpr int kBlock = 256;      // 4 wavefronts of 64 lanes
+constexpr int kWave = 64;
+constexpr int kMaxRestart = 64;  // GMRES cycle length bound (DnsCtl arrays)
+
+inline thread_local std::string g_last_error;
+
+inline int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define DNS_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess)                                               \
+            return dns::fail(DNS_ERR_HIP, "%s failed: %s (%s:%d)", #call,    \
+                             hipGetErrorString(e__), __FILE__, __LINE__);    \
+    } while (0)
+
+#define DNS_TRY(call)                                                        \
+    do {                                                                     \
+        int s__ = (call);                                                    \
+        if (s__ != DNS_OK) return s__;                                       \
+    } while (0)
+
+// device buffer with explicit lifetime (no exceptions across the C-ABI)
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count) {
+        release();
+        if (count == 0) count = 1;
+        DNS_HIP(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+        n = count;
+        return DNS_OK;
+    }
+    int upload(const T *host, size_t count, hipStream_t s) {
+        if (count > n) return fail(DNS_ERR_BAD_ARGUMENT, "upload overflow");
+        if (count == 0) return DNS_OK;
+        DNS_HIP(hipMemcpyAsync(p, host, count * sizeof(T),
+                               hipMemcpyHostToDevice, s));
+        return DNS_OK;
+    }
+    int download(T *host, size_t count, hipStream_t s) const {
+        if (count > n) return fail(DNS_ERR_BAD_ARGUMENT, "download overflow");
+        if (count == 0) return DNS_OK;
+        DNS_HIP(hipMemcpyAsync(host, p, count * sizeof(T),
+                               hipMemcpyDeviceToHost, s));
+        return DNS_OK;
+    }
+    int zero(hipStream_t s) {
+        DNS_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+        return DNS_OK;
+    }
+};
+
+// CSR matrix resident in HBM
+struct CsrDev {
+    int nrows = 0, ncols = 0;
+    int64_t nnz = 0;
+    int lpr = 16;                 // lanes per row of the vector kernel
+    DevBuf<int> rowptr, colidx;
+    DevBuf<double> vals;
+    // row-block table of the LDS-streaming kernel (built on the host)
+    DevBuf<int> rowblocks;
+    int nrowblocks = 0;
+
+    int upload(const dns_csr *a, hipStream_t s);
+};
+
+inline int pick_lpr(double avg_nnz_per_row) {
+    int lpr = 2;
+    while (lpr < 64 && lpr * 2 <= avg_nnz_per_row) lpr *= 2;
+    return lpr;
+}
+
+inline int check_csr(const dns_csr *a, const char *name) {
+    if (!a || !a->rowptr || (a->nnz > 0 && (!a->colidx || !a->vals)))
+        return fail(DNS_ERR_BAD_ARGUMENT, "%s: null CSR arrays", name);
+    if (a->nrows < 0 || a->ncols < 0 || a->nnz < 0)
+        return fail(DNS_ERR_BAD_ARGUMENT, "%s: negative sizes", name);
+    if (a->rowptr[0] != 0 || a->rowptr[a->nrows] != a->nnz)
+        return fail(DNS_ERR_BAD_ARGUMENT, "%s: rowptr does not span nnz",
+                    name);
+    for (int i = 0; i < a->nrows; ++i)
+        if (a->rowptr[i + 1] < a->rowptr[i])
+            return fail(DNS_ERR_BAD_ARGUMENT, "%s: rowptr not monotone", name);
+    for (int64_t k = 0; k < a->nnz; ++k)
+        if (a->colidx[k] < 0 || a->colidx[k] >= a->ncols)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "%s: column index %d out of range at %lld", name,
+                        a->colidx[k], (long long)k);
+    return DNS_OK;
+}
+
+}  // namespace dns

@@ -1,0 +1,948 @@
+// C-ABI implementation of include/dns_amd.h -- single translation unit for
+// hipcc --offload-arch=gfx950.
+#include "imex.hpp"
+#include "solver.hpp"
+
+using namespace dns;
+
+namespace dns {
+
+__global__ void __launch_bounds__(kBlock)
+k_set_unit(int n, int idx, double val, double *__restrict__ x) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock)
+        x[i] = (i == idx) ? val : 0.0;
+}
+
+// sdinv[i] = 1 / sum_k J[i,k]^2 * dinv[k]   (diagonal of J D^-1 JT)
+__global__ void __launch_bounds__(kBlock)
+k_schur_diag(int np, const int *__restrict__ rowptr,
+             const int *__restrict__ colidx, const double *__restrict__ vals,
+             const double *__restrict__ dinv, double *__restrict__ sdinv) {
+    for (int row = blockIdx.x * kBlock + threadIdx.x; row < np;
+         row += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int k = rowptr[row]; k < rowptr[row + 1]; ++k)
+            s = fma(vals[k] * vals[k], dinv[colidx[k]], s);
+        sdinv[row] = (s > 0.0) ? 1.0 / s : 1.0;
+    }
+}
+
+static void host_transpose(const dns_csr *a, std::vector<int> &rp,
+                           std::vector<int> &ci, std::vector<double> &va) {
+    rp.assign((size_t)a->ncols + 1, 0);
+    ci.resize((size_t)a->nnz);
+    va.resize((size_t)a->nnz);
+    for (int64_t k = 0; k < a->nnz; ++k) rp[a->colidx[k] + 1]++;
+    for (int c = 0; c < a->ncols; ++c) rp[c + 1] += rp[c];
+    std::vector<int> pos(rp.begin(), rp.end() - 1);
+    for (int r = 0; r < a->nrows; ++r)
+        for (int k = a->rowptr[r]; k < a->rowptr[r + 1]; ++k) {
+            const int c = a->colidx[k];
+            ci[pos[c]] = r;
+            va[pos[c]] = a->vals[k];
+            pos[c]++;
+        }
+}
+
+}  // namespace dns
+
+dns_saddle::~dns_saddle() {
+    if (hdr_host) (void)hipHostFree(hdr_host);
+    if (scal_host) (void)hipHostFree(scal_host);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
+                     const dns_csr *jt) {
+    DNS_TRY(check_csr(f, "F"));
+    DNS_TRY(check_csr(j, "J"));
+    if (f->nrows != f->ncols)
+        return fail(DNS_ERR_BAD_ARGUMENT, "F must be square");
+    if (j->ncols != f->nrows)
+        return fail(DNS_ERR_BAD_ARGUMENT, "J has %d columns, F has %d rows",
+                    j->ncols, f->nrows);
+    device = dev;
+    nv = f->nrows;
+    np = j->nrows;
+    n = nv + np;
+    ld = ((size_t)n + 63) / 64 * 64;
+    DNS_HIP(hipSetDevice(device));
+    DNS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    DNS_HIP(hipEventCreate(&ev0));
+    DNS_HIP(hipEventCreate(&ev1));
+    DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
+                          sizeof(CtlHeader)));
+    DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&scal_host),
+                          16 * sizeof(double)));
+    // J^T: given or formed here
+    std::vector<int> trp, tci;
+    std::vector<double> tva;
+    dns_csr jth;
+    if (jt) {
+        DNS_TRY(check_csr(jt, "JT"));
+        if (jt->nrows != nv || jt->ncols != np || jt->nnz != j->nnz)
+            return fail(DNS_ERR_BAD_ARGUMENT, "JT is not shaped like J^T");
+        jth = *jt;
+    } else {
+        host_transpose(j, trp, tci, tva);
+        jth.nrows = nv;
+        jth.ncols = np;
+        jth.nnz = j->nnz;
+        jth.rowptr = trp.data();
+        jth.colidx = tci.data();
+        jth.vals = tva.data();
+    }
+    DNS_TRY(F.upload(f, stream));
+    DNS_TRY(J.upload(j, stream));
+    DNS_TRY(JT.upload(&jth, stream));
+    // assembled K = [[F, JT], [J, 0]]
+    {
+        std::vector<int> krp((size_t)n + 1), kci;
+        std::vector<double> kva;
+        const int64_t knnz = f->nnz + 2 * j->nnz;
+        if (knnz > 0x7fffffffLL)
+            return fail(DNS_ERR_BAD_ARGUMENT, "K exceeds int32 indexing");
+        kci.resize((size_t)knnz);
+        kva.resize((size_t)knnz);
+        int64_t pos = 0;
+        krp[0] = 0;
+        for (int r = 0; r < nv; ++r) {
+            for (int k = f->rowptr[r]; k < f->rowptr[r + 1]; ++k) {
+                kci[pos] = f->colidx[k];
+                kva[pos++] = f->vals[k];
+            }
+            for (int k = jth.rowptr[r]; k < jth.rowptr[r + 1]; ++k) {
+                kci[pos] = nv + jth.colidx[k];
+                kva[pos++] = jth.vals[k];
+            }
+            krp[r + 1] = (int)pos;
+        }
+        for (int r = 0; r < np; ++r) {
+            for (int k = j->rowptr[r]; k < j->rowptr[r + 1]; ++k) {
+                kci[pos] = j->colidx[k];
+                kva[pos++] = j->vals[k];
+            }
+            krp[nv + r + 1] = (int)pos;
+        }
+        dns_csr kh;
+        kh.nrows = kh.ncols = n;
+        kh.nnz = knnz;
+        kh.rowptr = krp.data();
+        kh.colidx = kci.data();
+        kh.vals = kva.data();
+        DNS_TRY(K.upload(&kh, stream));
+    }
+    DNS_TRY(dinv.alloc((size_t)nv));
+    hipLaunchKernelGGL(k_diag_inv, grid_for_elems(nv), kBlock, 0, stream, nv,
+                       F.rowptr.p, F.colidx.p, F.vals.p, dinv.p);
+    DNS_HIP(hipGetLastError());
+    nred = (int)std::min<int64_t>(1024, std::max<int64_t>(64, (n + 255) / 256));
+    DNS_TRY(ctl.alloc(1));
+    DNS_TRY(ctl.zero(stream));
+    DNS_TRY(bctl.alloc(1));
+    DNS_TRY(bctl.zero(stream));
+    DNS_TRY(scal.alloc(16));
+    DNS_TRY(cheb_r.alloc((size_t)nv));
+    DNS_TRY(cheb_d0.alloc((size_t)nv));
+    DNS_TRY(cheb_d1.alloc((size_t)nv));
+    DNS_TRY(w.alloc(ld));
+    DNS_TRY(z.alloc(ld));
+    DNS_TRY(u.alloc(ld));
+    DNS_TRY(r.alloc(ld));
+    DNS_TRY(xdev.alloc(ld));
+    DNS_TRY(bdev.alloc(ld));
+    DNS_TRY(partA.alloc((size_t)(kMaxRestart + 1) * nred));
+    DNS_TRY(partN.alloc((size_t)nred));
+    DNS_TRY(partR.alloc((size_t)nred));
+    DNS_TRY(partB.alloc((size_t)nred));
+    DNS_TRY(partC.alloc((size_t)nred));
+    DNS_TRY(u.zero(stream));
+    DNS_HIP(hipStreamSynchronize(stream));
+    dns_default_precond_opts(&popts);
+    return DNS_OK;
+}
+
+int dns_saddle::update_values(const double *fvals) {
+    DNS_HIP(hipSetDevice(device));
+    DNS_TRY(F.vals.upload(fvals, (size_t)F.nnz, stream));
+    hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
+                       stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p, K.vals.p);
+    hipLaunchKernelGGL(k_diag_inv, grid_for_elems(nv), kBlock, 0, stream, nv,
+                       F.rowptr.p, F.colidx.p, F.vals.p, dinv.p);
+    DNS_HIP(hipGetLastError());
+    DNS_HIP(hipStreamSynchronize(stream));   // fvals is borrowed
+    return DNS_OK;
+}
+
+int dns_saddle::dot_host(int64_t len, const double *x, const double *y,
+                         double *out) {
+    hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream, len, x, y,
+                       partC.p);
+    hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partC.p, nred,
+                       scal.p);
+    DNS_HIP(hipGetLastError());
+    DNS_HIP(hipMemcpyAsync(scal_host, scal.p, sizeof(double),
+                           hipMemcpyDeviceToHost, stream));
+    DNS_HIP(hipStreamSynchronize(stream));
+    *out = scal_host[0];
+    return DNS_OK;
+}
+
+int dns_saddle::estimate_bounds() {
+    // power iterations on D^-1 F; same sequence as tests/krylov_model.py
+    double *x = cheb_d0.p, *y = cheb_d1.p;
+    const int g = grid_for_elems(nv);
+    double nrm2 = 0, lam = 0;
+    hipLaunchKernelGGL(k_fill_wave, g, kBlock, 0, stream, nv, x, 0.37, 7.0, 0);
+    for (int it = 0; it < 30; ++it) {
+        DNS_TRY(launch_spmv(F, x, y, 1.0, 0.0, nullptr, DNS_SPMV_VECTOR,
+                            stream));
+        hipLaunchKernelGGL(k_scale_by, g, kBlock, 0, stream, nv, dinv.p, y);
+        double xx, yy;
+        DNS_TRY(dot_host(nv, x, x, &xx));
+        DNS_TRY(dot_host(nv, y, y, &yy));
+        if (!(yy > 0.0) || !(xx > 0.0))
+            return fail(DNS_BREAKDOWN, "power iteration broke down");
+        lam = std::sqrt(yy / xx);
+        hipLaunchKernelGGL(k_axpby, g, kBlock, 0, stream, (int64_t)nv,
+                           1.0 / std::sqrt(yy), y, 0.0, x);
+    }
+    const double lmax = lam;
+    const double shift = 1.05 * lmax;
+    hipLaunchKernelGGL(k_fill_wave, g, kBlock, 0, stream, nv, x, 0.61, 7.0, 1);
+    double mu = 0;
+    for (int it = 0; it < 50; ++it) {
+        DNS_TRY(launch_spmv(F, x, y, 1.0, 0.0, nullptr, DNS_SPMV_VECTOR,
+                            stream));
+        hipLaunchKernelGGL(k_scale_by, g, kBlock, 0, stream, nv, dinv.p, y);
+        // y = shift*x - y
+        hipLaunchKernelGGL(k_axpby, g, kBlock, 0, stream, (int64_t)nv, shift,
+                           x, -1.0, y);
+        double xx, yy;
+        DNS_TRY(dot_host(nv, x, x, &xx));
+        DNS_TRY(dot_host(nv, y, y, &yy));
+        if (!(yy > 0.0) || !(xx > 0.0)) break;
+        mu = std::sqrt(yy / xx);
+        hipLaunchKernelGGL(k_axpby, g, kBlock, 0, stream, (int64_t)nv,
+                           1.0 / std::sqrt(yy), y, 0.0, x);
+    }
+    (void)nrm2;
+    double lmin = shift - mu;
+    if (!(lmin > 0.0)) lmin = lmax / 100.0;
+    lam_lo = popts.eig_lo_safety * lmin;
+    lam_hi = popts.eig_hi_safety * lmax;
+    return DNS_OK;
+}
+
+static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
+                      const int *jsel, const double *zp, double *zv) {
+    const int deg = h->popts.cheb_degree;
+    const int gj = grid_for_rows(h->nv, h->JT.lpr);
+    double *d0 = (deg == 1) ? zv : h->cheb_d0.p;
+    DNS_LPR_SWITCH(h->JT.lpr,
+                   hipLaunchKernelGGL(k_cheb_init<L>, gj, kBlock, 0, h->stream,
+                                      h->nv, h->JT.rowptr.p, h->JT.colidx.p,
+                                      h->JT.vals.p, zp, rbase, ldr, jsel,
+                                      h->dinv.p, 1.0 / h->theta, h->cheb_r.p,
+                                      d0, h->ctl.p));
+    const int gf = grid_for_rows(h->nv, h->F.lpr);
+    double *dbuf[2] = {h->cheb_d0.p, h->cheb_d1.p};
+    for (int s = 0; s < deg - 1; ++s) {
+        const int first = (s == 0), last = (s == deg - 2);
+        DNS_LPR_SWITCH(
+            h->F.lpr,
+            hipLaunchKernelGGL(k_cheb_step<L>, gf, kBlock, 0, h->stream, h->nv,
+                               h->F.rowptr.p, h->F.colidx.p, h->F.vals.p,
+                               h->dinv.p, dbuf[s & 1], dbuf[(s + 1) & 1],
+                               h->cheb_r.p, zv, h->c1[s], h->c2[s], first,
+                               last, h->ctl.p));
+        h->spmv_count++;
+    }
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+int dns_saddle::apply_precond(const double *rbase, size_t ldr, const int *jsel,
+                              double *zout) {
+    double *zp = zout + nv;
+    if (popts.schur == DNS_SCHUR_DENSE) {
+        const int g = std::max(1, std::min((np + 3) / 4, 2048));
+        hipLaunchKernelGGL(k_schur_dense, g, kBlock, 0, stream, np, sinv.p,
+                           rbase, ldr, jsel, nv, zp, ctl.p);
+    } else {
+        hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(np), kBlock, 0,
+                           stream, np, sinv.p, rbase, ldr, jsel, nv, zp,
+                           ctl.p);
+    }
+    return apply_fhat(this, rbase, ldr, jsel, zp, zout);
+}
+
+int dns_saddle::invert_dense(double *a, int nn) {
+    DevBuf<double> prow, pcol;
+    DevBuf<int> flag;
+    DNS_TRY(prow.alloc((size_t)nn));
+    DNS_TRY(pcol.alloc((size_t)nn));
+    DNS_TRY(flag.alloc(1));
+    DNS_TRY(flag.zero(stream));
+    const int g1 = grid_for_elems(nn);
+    const int g2 = grid_for_elems((int64_t)nn * nn);
+    for (int k = 0; k < nn; ++k) {
+        hipLaunchKernelGGL(k_gj_pivot, g1, kBlock, 0, stream, nn, k, a, prow.p,
+                           pcol.p, flag.p);
+        hipLaunchKernelGGL(k_gj_update, g2, kBlock, 0, stream, nn, k, a,
+                           prow.p, pcol.p, flag.p);
+    }
+    DNS_HIP(hipGetLastError());
+    int hflag = 0;
+    DNS_HIP(hipMemcpyAsync(&hflag, flag.p, sizeof(int), hipMemcpyDeviceToHost,
+                           stream));
+    DNS_HIP(hipStreamSynchronize(stream));
+    if (hflag)
+        return fail(DNS_BREAKDOWN, "zero pivot in the dense Schur inverse");
+    return DNS_OK;
+}
+
+int dns_saddle::build_dense_schur() {
+    // S[c, :] = J Fh^-1 JT e_c  (S is symmetric for symmetric F)
+    DNS_TRY(sinv.alloc((size_t)np * np));
+    DNS_TRY(u.zero(stream));
+    DNS_TRY(ctl.zero(stream));
+    double *zp = z.p + nv;
+    for (int c = 0; c < np; ++c) {
+        hipLaunchKernelGGL(k_set_unit, grid_for_elems(np), kBlock, 0, stream,
+                           np, c, -1.0, zp);
+        DNS_TRY(apply_fhat(this, u.p, 0, zero_ptr(), zp, z.p));
+        DNS_TRY(launch_spmv(J, z.p, sinv.p + (size_t)c * np, 1.0, 0.0, nullptr,
+                            DNS_SPMV_VECTOR, stream));
+    }
+    DNS_HIP(hipGetLastError());
+    return invert_dense(sinv.p, np);
+}
+
+int dns_saddle::build_jacobi_schur() {
+    DNS_TRY(sinv.alloc((size_t)np));
+    hipLaunchKernelGGL(k_schur_diag, grid_for_elems(np), kBlock, 0, stream, np,
+                       J.rowptr.p, J.colidx.p, J.vals.p, dinv.p, sinv.p);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+int dns_saddle::setup_precond(const dns_precond_opts *o) {
+    DNS_HIP(hipSetDevice(device));
+    if (o) popts = *o;
+    if (popts.cheb_degree < 1 || popts.cheb_degree > 256)
+        return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
+    precond_ready = false;
+    if (popts.eig_lo > 0.0 && popts.eig_hi > popts.eig_lo) {
+        lam_lo = popts.eig_lo;
+        lam_hi = popts.eig_hi;
+    } else {
+        DNS_TRY(estimate_bounds());
+    }
+    theta = 0.5 * (lam_hi + lam_lo);
+    delta = 0.5 * (lam_hi - lam_lo);
+    c1.clear();
+    c2.clear();
+    {
+        const double sigma1 = theta / delta;
+        double rho = 1.0 / sigma1;
+        for (int s = 0; s < popts.cheb_degree - 1; ++s) {
+            const double rho_new = 1.0 / (2.0 * sigma1 - rho);
+            c1.push_back(rho_new * rho);
+            c2.push_back(2.0 * rho_new / delta);
+            rho = rho_new;
+        }
+    }
+    if (popts.schur == DNS_SCHUR_DENSE) {
+        if ((int64_t)np * np * 8 > (int64_t)64 << 30)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "dense Schur inverse too large for NP=%d", np);
+        DNS_TRY(build_dense_schur());
+    } else if (popts.schur == DNS_SCHUR_JACOBI) {
+        DNS_TRY(build_jacobi_schur());
+    } else {
+        return fail(DNS_ERR_BAD_ARGUMENT, "unknown Schur option %d",
+                    popts.schur);
+    }
+    DNS_HIP(hipStreamSynchronize(stream));
+    precond_ready = true;
+    return DNS_OK;
+}
+
+int dns_saddle::ensure_workspace(int m) {
+    const size_t need = (size_t)(m + 1) * ld;
+    if (V.n < need) DNS_TRY(V.alloc(need));
+    return DNS_OK;
+}
+
+int dns_saddle::read_header() {
+    DNS_HIP(hipMemcpyAsync(hdr_host, ctl.p, sizeof(CtlHeader),
+                           hipMemcpyDeviceToHost, stream));
+    DNS_HIP(hipStreamSynchronize(stream));
+    return DNS_OK;
+}
+
+int dns_saddle::true_residual(const double *b, const double *x, double *out) {
+    DNS_LPR_SWITCH(K.lpr,
+                   hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream,
+                                      n, K.rowptr.p, K.colidx.p, K.vals.p, x,
+                                      r.p, -1.0, 1.0, b, partR.p,
+                                      (const DnsCtl *)nullptr));
+    hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, nred,
+                       scal.p);
+    DNS_HIP(hipGetLastError());
+    DNS_HIP(hipMemcpyAsync(scal_host, scal.p, sizeof(double),
+                           hipMemcpyDeviceToHost, stream));
+    DNS_HIP(hipStreamSynchronize(stream));
+    *out = std::sqrt(scal_host[0]);
+    spmv_count++;
+    return DNS_OK;
+}
+
+int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
+                      dns_solve_stats *st) {
+    const int m = std::max(1, std::min(o->restart, kMaxRestart));
+    const int check = std::max(1, o->check_every);
+    DNS_TRY(ensure_workspace(m));
+    hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream, (int64_t)n, b,
+                       b, partB.p);
+    bool first = true;
+    int total = 0, restarts = 0;
+    history.clear();
+    while (true) {
+        DNS_LPR_SWITCH(
+            K.lpr, hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream,
+                                      n, K.rowptr.p, K.colidx.p, K.vals.p, x,
+                                      r.p, -1.0, 1.0, b, partR.p,
+                                      (const DnsCtl *)nullptr));
+        spmv_count++;
+        hipLaunchKernelGGL(k_gmres_start, nred, kBlock, 0, stream, n, r.p,
+                           V.p, partR.p, nred, ctl.p, first ? 1 : 0, o->rtol,
+                           o->atol, partB.p);
+        first = false;
+        int it = 0;
+        bool done = false;
+        while (it < m && !done) {
+            const int chunk = std::min(check, m - it);
+            for (int c = 0; c < chunk; ++c, ++it) {
+                const int par = it & 1;
+                DNS_TRY(apply_precond(V.p, ld, jsel_ptr(par), z.p));
+                DNS_LPR_SWITCH(
+                    K.lpr,
+                    hipLaunchKernelGGL(k_spmv_guard<L>,
+                                       grid_for_rows(n, K.lpr), kBlock, 0,
+                                       stream, n, K.rowptr.p, K.colidx.p,
+                                       K.vals.p, z.p, w.p, ctl.p));
+                spmv_count++;
+                hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n, V.p,
+                                   ld, w.p, partA.p, nred, ctl.p, par);
+                hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream, n,
+                                   V.p, ld, w.p, partA.p, nred, ctl.p, par, 0,
+                                   o->reorth ? (double *)nullptr : partN.p);
+                if (o->reorth) {
+                    hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n,
+                                       V.p, ld, w.p, partA.p, nred, ctl.p,
+                                       par);
+                    hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream,
+                                       n, V.p, ld, w.p, partA.p, nred, ctl.p,
+                                       par, 1, partN.p);
+                }
+                hipLaunchKernelGGL(k_gmres_close, nred, kBlock, 0, stream, n,
+                                   w.p, V.p, ld, partN.p, nred, ctl.p, par, m,
+                                   o->maxiter);
+            }
+            DNS_HIP(hipGetLastError());
+            DNS_TRY(read_header());
+            done = hdr_host->done != 0;
+        }
+        // completed columns of this cycle
+        const int jcols = std::max(hdr_host->jv[0], hdr_host->jv[1]);
+        if (jcols > 0) {
+            // residual history of the cycle
+            std::vector<double> hh((size_t)jcols + 1);
+            DNS_HIP(hipMemcpyAsync(
+                hh.data(),
+                reinterpret_cast<const char *>(ctl.p) + offsetof(DnsCtl, hist),
+                hh.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+            hipLaunchKernelGGL(k_gmres_solve_y, 1, 64, 0, stream, ctl.p,
+                               jcols);
+            hipLaunchKernelGGL(k_basis_combine, nred, kBlock, 0, stream, n,
+                               V.p, ld, ctl.p, jcols, u.p);
+            // z = P^-1 u must not be skipped: lower the flag for the update
+            DNS_HIP(hipMemsetAsync(reinterpret_cast<char *>(ctl.p) +
+                                       offsetof(DnsCtl, done),
+                                   0, sizeof(int), stream));
+            DNS_TRY(apply_precond(u.p, 0, zero_ptr(), z.p));
+            hipLaunchKernelGGL(k_axpby, grid_for_elems(n), kBlock, 0, stream,
+                               (int64_t)n, 1.0, z.p, 1.0, x);
+            DNS_HIP(hipGetLastError());
+            DNS_HIP(hipStreamSynchronize(stream));
+            const size_t skip = history.empty() ? 0 : 1;
+            history.insert(history.end(), hh.begin() + skip, hh.end());
+        } else if (history.empty()) {
+            history.push_back(hdr_host->resnorm);
+        }
+        total = hdr_host->total_it;
+        st->bnorm = hdr_host->bnorm;
+        st->est_relres = hdr_host->bnorm > 0
+                             ? hdr_host->resnorm / hdr_host->bnorm
+                             : hdr_host->resnorm;
+        if (hdr_host->status != DNS_OK) {
+            st->status = hdr_host->status;
+            break;
+        }
+        const bool conv = !(hdr_host->resnorm > hdr_host->tol);
+        if (conv) {
+            st->status = DNS_OK;
+            break;
+        }
+        if (total >= o->maxiter) {
+            st->status = DNS_NOT_CONVERGED;
+            break;
+        }
+        restarts++;
+    }
+    st->iters = total;
+    st->restarts = restarts;
+    return DNS_OK;
+}
+
+int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
+                         dns_solve_stats *st) {
+    const int check = std::max(1, o->check_every);
+    const size_t hcap = (size_t)o->maxiter + 2;
+    if (bi_rhat.n < ld) {
+        DNS_TRY(bi_rhat.alloc(ld));
+        DNS_TRY(bi_p.alloc(ld));
+        DNS_TRY(bi_v.alloc(ld));
+        DNS_TRY(bi_s.alloc(ld));
+        DNS_TRY(bi_t.alloc(ld));
+        DNS_TRY(bi_y.alloc(ld));
+    }
+    if (histdev.n < hcap) DNS_TRY(histdev.alloc(hcap));
+    hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream, (int64_t)n, b,
+                       b, partB.p);
+    DNS_LPR_SWITCH(K.lpr,
+                   hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream,
+                                      n, K.rowptr.p, K.colidx.p, K.vals.p, x,
+                                      r.p, -1.0, 1.0, b, partR.p,
+                                      (const DnsCtl *)nullptr));
+    spmv_count++;
+    // <rhat, r> = <r, r> at the start: partR doubles as part_rr and part_nn
+    hipLaunchKernelGGL(k_bicg_start, nred, kBlock, 0, stream, n, r.p,
+                       bi_rhat.p, bi_p.p, bi_v.p, partR.p, partB.p, nred,
+                       ctl.p, bctl.p, o->rtol, o->atol, histdev.p);
+    hipLaunchKernelGGL(k_axpby, 1, kBlock, 0, stream, (int64_t)nred, 1.0,
+                       partR.p, 0.0, partN.p);
+    int it = 0;
+    bool done = false;
+    while (!done) {
+        const int chunk = std::min(check, o->maxiter + 1 - it);
+        for (int c = 0; c < chunk; ++c, ++it) {
+            const int par = it & 1;
+            hipLaunchKernelGGL(k_bicg_p, nred, kBlock, 0, stream, n, r.p,
+                               bi_p.p, bi_v.p, partR.p, partN.p, nred, ctl.p,
+                               bctl.p, par, o->maxiter, histdev.p);
+            hipLaunchKernelGGL(k_bicg_flag, 1, 64, 0, stream, ctl.p,
+                               o->maxiter);
+            DNS_TRY(apply_precond(bi_p.p, 0, zero_ptr(), bi_y.p));
+            DNS_LPR_SWITCH(
+                K.lpr,
+                hipLaunchKernelGGL(k_spmv_dot2<L>, nred, kBlock, 0, stream, n,
+                                   K.rowptr.p, K.colidx.p, K.vals.p, bi_y.p,
+                                   bi_v.p, bi_rhat.p, (const double *)nullptr,
+                                   1, partA.p, partA.p + nred, ctl.p));
+            hipLaunchKernelGGL(k_bicg_s, nred, kBlock, 0, stream, n, r.p,
+                               bi_v.p, bi_s.p, partA.p, nred, ctl.p, bctl.p);
+            DNS_TRY(apply_precond(bi_s.p, 0, zero_ptr(), z.p));
+            DNS_LPR_SWITCH(
+                K.lpr,
+                hipLaunchKernelGGL(k_spmv_dot2<L>, nred, kBlock, 0, stream, n,
+                                   K.rowptr.p, K.colidx.p, K.vals.p, z.p,
+                                   bi_t.p, bi_s.p, (const double *)nullptr, 2,
+                                   partA.p, partA.p + nred, ctl.p));
+            spmv_count += 2;
+            hipLaunchKernelGGL(k_bicg_x, nred, kBlock, 0, stream, n, x, r.p,
+                               bi_rhat.p, bi_y.p, z.p, bi_s.p, bi_t.p, partA.p,
+                               partA.p + nred, nred, partR.p, partN.p, ctl.p,
+                               bctl.p, par);
+        }
+        DNS_HIP(hipGetLastError());
+        DNS_TRY(read_header());
+        done = hdr_host->done != 0 || it > o->maxiter;
+    }
+    const int total = hdr_host->total_it;
+    history.assign((size_t)total + 1, 0.0);
+    DNS_HIP(hipMemcpyAsync(history.data(), histdev.p,
+                           history.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, stream));
+    DNS_HIP(hipStreamSynchronize(stream));
+    st->iters = total;
+    st->restarts = 0;
+    st->bnorm = hdr_host->bnorm;
+    st->est_relres = hdr_host->bnorm > 0 ? hdr_host->resnorm / hdr_host->bnorm
+                                         : hdr_host->resnorm;
+    const bool conv = !(hdr_host->resnorm > hdr_host->tol);
+    st->status = conv ? DNS_OK
+                      : (hdr_host->status != DNS_OK ? hdr_host->status
+                                                    : DNS_NOT_CONVERGED);
+    return DNS_OK;
+}
+
+int dns_saddle::solve_device(const double *b, double *x,
+                             const dns_solve_opts *o, dns_solve_stats *st) {
+    if (!precond_ready)
+        return fail(DNS_ERR_NOT_READY,
+                    "dns_saddle_setup_precond must run before a solve");
+    if (o->maxiter < 1 || o->restart < 1)
+        return fail(DNS_ERR_BAD_ARGUMENT, "maxiter/restart must be positive");
+    const int64_t spmv0 = spmv_count;
+    DNS_HIP(hipEventRecord(ev0, stream));
+    if (o->method == DNS_METHOD_GMRES)
+        DNS_TRY(gmres(b, x, o, st));
+    else if (o->method == DNS_METHOD_BICGSTAB)
+        DNS_TRY(bicgstab(b, x, o, st));
+    else
+        return fail(DNS_ERR_BAD_ARGUMENT, "unknown method %d", o->method);
+    DNS_HIP(hipEventRecord(ev1, stream));
+    DNS_HIP(hipEventSynchronize(ev1));
+    float ms = 0.f;
+    DNS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    st->device_seconds = 1e-3 * ms;
+    double tr = 0.0;
+    DNS_TRY(true_residual(b, x, &tr));
+    st->true_relres = st->bnorm > 0 ? tr / st->bnorm : tr;
+    st->spmv_count = (int32_t)(spmv_count - spmv0);
+    return DNS_OK;
+}
+
+// ===========================================================================
+// extern "C"
+// ===========================================================================
+extern "C" {
+
+int dns_version(void) { return 100; }
+
+const char *dns_status_string(int status) {
+    switch (status) {
+        case DNS_OK: return "ok";
+        case DNS_NOT_CONVERGED: return "not converged";
+        case DNS_BREAKDOWN: return "breakdown";
+        case DNS_ERR_HIP: return "HIP error";
+        case DNS_ERR_BAD_ARGUMENT: return "bad argument";
+        case DNS_ERR_NOT_READY: return "not ready";
+        case DNS_ERR_COMM: return "communication error";
+        default: return "unknown status";
+    }
+}
+
+const char *dns_last_error(void) { return g_last_error.c_str(); }
+
+int dns_device_count(int *count) {
+    if (!count) return fail(DNS_ERR_BAD_ARGUMENT, "null count");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(DNS_ERR_HIP, "hipGetDeviceCount: %s",
+                    hipGetErrorString(e));
+    }
+    *count = c;
+    return DNS_OK;
+}
+
+int dns_device_name(int device, char *buf, size_t buflen) {
+    if (!buf || buflen == 0) return fail(DNS_ERR_BAD_ARGUMENT, "null buffer");
+    hipDeviceProp_t prop;
+    DNS_HIP(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+             prop.multiProcessorCount);
+    return DNS_OK;
+}
+
+void dns_default_precond_opts(dns_precond_opts *o) {
+    o->cheb_degree = 4;
+    o->schur = DNS_SCHUR_DENSE;
+    o->eig_lo_safety = 0.9;
+    o->eig_hi_safety = 1.05;
+    o->eig_lo = 0.0;
+    o->eig_hi = 0.0;
+}
+
+void dns_default_solve_opts(dns_solve_opts *o) {
+    o->method = DNS_METHOD_GMRES;
+    o->restart = 60;
+    o->maxiter = 400;
+    o->reorth = 1;
+    o->rtol = 1e-10;
+    o->atol = 0.0;
+    o->check_every = 4;
+    o->use_graph = 0;
+}
+
+int dns_saddle_create(int device, const dns_csr *f, const dns_csr *j,
+                      const dns_csr *jt, dns_saddle **out) {
+    if (!out) return fail(DNS_ERR_BAD_ARGUMENT, "null output handle");
+    *out = nullptr;
+    dns_saddle *h = new (std::nothrow) dns_saddle();
+    if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "out of host memory");
+    const int s = h->init(device, f, j, jt);
+    if (s != DNS_OK) {
+        delete h;
+        return s;
+    }
+    *out = h;
+    return DNS_OK;
+}
+
+void dns_saddle_destroy(dns_saddle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    delete h;
+}
+
+int dns_saddle_update_values(dns_saddle *h, const double *f_vals) {
+    if (!h || !f_vals) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    return h->update_values(f_vals);
+}
+
+int dns_saddle_setup_precond(dns_saddle *h, const dns_precond_opts *opts) {
+    if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "null handle");
+    return h->setup_precond(opts);
+}
+
+int dns_saddle_solve(dns_saddle *h, const double *rhs_v, const double *rhs_p,
+                     const double *x0, double *out_vp,
+                     const dns_solve_opts *opts, dns_solve_stats *stats) {
+    if (!h || !rhs_v || !out_vp)
+        return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    dns_solve_opts o;
+    if (opts)
+        o = *opts;
+    else
+        dns_default_solve_opts(&o);
+    dns_solve_stats local;
+    dns_solve_stats *st = stats ? stats : &local;
+    memset(st, 0, sizeof(*st));
+    DNS_HIP(hipSetDevice(h->device));
+    DNS_TRY(h->bdev.upload(rhs_v, (size_t)h->nv, h->stream));
+    if (rhs_p) {
+        DNS_HIP(hipMemcpyAsync(h->bdev.p + h->nv, rhs_p,
+                               (size_t)h->np * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream));
+    } else {
+        DNS_HIP(hipMemsetAsync(h->bdev.p + h->nv, 0,
+                               (size_t)h->np * sizeof(double), h->stream));
+    }
+    if (x0)
+        DNS_TRY(h->xdev.upload(x0, (size_t)h->n, h->stream));
+    else
+        DNS_TRY(h->xdev.zero(h->stream));
+    DNS_TRY(h->solve_device(h->bdev.p, h->xdev.p, &o, st));
+    DNS_TRY(h->xdev.download(out_vp, (size_t)h->n, h->stream));
+    DNS_HIP(hipStreamSynchronize(h->stream));
+    return DNS_OK;
+}
+
+int dns_saddle_residual_history(dns_saddle *h, double *out, int32_t cap,
+                                int32_t *count) {
+    if (!h || !count) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    const int32_t nh = (int32_t)h->history.size();
+    *count = nh;
+    if (out)
+        for (int32_t i = 0; i < std::min(nh, cap); ++i) out[i] = h->history[i];
+    return DNS_OK;
+}
+
+int dns_saddle_apply(dns_saddle *h, const double *x, double *y) {
+    if (!h || !x || !y) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    DNS_HIP(hipSetDevice(h->device));
+    DNS_TRY(h->xdev.upload(x, (size_t)h->n, h->stream));
+    DNS_TRY(launch_spmv(h->K, h->xdev.p, h->w.p, 1.0, 0.0, nullptr,
+                        DNS_SPMV_VECTOR, h->stream));
+    DNS_TRY(h->w.download(y, (size_t)h->n, h->stream));
+    DNS_HIP(hipStreamSynchronize(h->stream));
+    return DNS_OK;
+}
+
+int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
+    if (!h || !r || !z) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    if (!h->precond_ready)
+        return fail(DNS_ERR_NOT_READY, "preconditioner not set up");
+    DNS_HIP(hipSetDevice(h->device));
+    DNS_TRY(h->ctl.zero(h->stream));
+    DNS_TRY(h->xdev.upload(r, (size_t)h->n, h->stream));
+    DNS_TRY(h->apply_precond(h->xdev.p, 0, h->zero_ptr(), h->z.p));
+    DNS_TRY(h->z.download(z, (size_t)h->n, h->stream));
+    DNS_HIP(hipStreamSynchronize(h->stream));
+    return DNS_OK;
+}
+
+int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi) {
+    if (!h || !lo || !hi) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    *lo = h->lam_lo;
+    *hi = h->lam_hi;
+    return DNS_OK;
+}
+
+// ---- standalone kernels ----------------------------------------------------
+struct ScopedStream {
+    hipStream_t s = nullptr;
+    ~ScopedStream() {
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
+
+int dns_spmv(int device, const dns_csr *a, const double *x, double *y,
+             double alpha, double beta, int32_t variant) {
+    DNS_TRY(check_csr(a, "A"));
+    if (!x || !y) return fail(DNS_ERR_BAD_ARGUMENT, "null vector");
+    DNS_HIP(hipSetDevice(device));
+    ScopedStream ss;
+    DNS_HIP(hipStreamCreate(&ss.s));
+    CsrDev A;
+    DNS_TRY(A.upload(a, ss.s));
+    DevBuf<double> dx, dy, db;
+    DNS_TRY(dx.alloc((size_t)a->ncols));
+    DNS_TRY(dy.alloc((size_t)a->nrows));
+    DNS_TRY(db.alloc((size_t)a->nrows));
+    DNS_TRY(dx.upload(x, (size_t)a->ncols, ss.s));
+    DNS_TRY(db.upload(y, (size_t)a->nrows, ss.s));
+    DNS_TRY(launch_spmv(A, dx.p, dy.p, alpha, beta,
+                        beta != 0.0 ? db.p : nullptr, variant, ss.s));
+    DNS_TRY(dy.download(y, (size_t)a->nrows, ss.s));
+    DNS_HIP(hipStreamSynchronize(ss.s));
+    return DNS_OK;
+}
+
+int dns_dot(int device, int64_t n, const double *x, const double *y,
+            double *out) {
+    if (!x || !y || !out || n < 0)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    DNS_HIP(hipSetDevice(device));
+    ScopedStream ss;
+    DNS_HIP(hipStreamCreate(&ss.s));
+    DevBuf<double> dx, dy, part, res;
+    const int g = grid_for_elems(n);
+    DNS_TRY(dx.alloc((size_t)n));
+    DNS_TRY(dy.alloc((size_t)n));
+    DNS_TRY(part.alloc((size_t)g));
+    DNS_TRY(res.alloc(1));
+    DNS_TRY(dx.upload(x, (size_t)n, ss.s));
+    DNS_TRY(dy.upload(y, (size_t)n, ss.s));
+    hipLaunchKernelGGL(k_dot_partials, g, kBlock, 0, ss.s, n, dx.p, dy.p,
+                       part.p);
+    hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, ss.s, part.p, g, res.p);
+    DNS_HIP(hipGetLastError());
+    DNS_TRY(res.download(out, 1, ss.s));
+    DNS_HIP(hipStreamSynchronize(ss.s));
+    return DNS_OK;
+}
+
+int dns_axpy(int device, int64_t n, double a, const double *x, double *y) {
+    if (!x || !y || n < 0) return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    DNS_HIP(hipSetDevice(device));
+    ScopedStream ss;
+    DNS_HIP(hipStreamCreate(&ss.s));
+    DevBuf<double> dx, dy;
+    DNS_TRY(dx.alloc((size_t)n));
+    DNS_TRY(dy.alloc((size_t)n));
+    DNS_TRY(dx.upload(x, (size_t)n, ss.s));
+    DNS_TRY(dy.upload(y, (size_t)n, ss.s));
+    hipLaunchKernelGGL(k_axpby, grid_for_elems(n), kBlock, 0, ss.s, n, a, dx.p,
+                       1.0, dy.p);
+    DNS_HIP(hipGetLastError());
+    DNS_TRY(dy.download(y, (size_t)n, ss.s));
+    DNS_HIP(hipStreamSynchronize(ss.s));
+    return DNS_OK;
+}
+
+int dns_gemv(int device, int32_t n, const double *a_rowmajor, const double *x,
+             double *y, double alpha) {
+    if (!a_rowmajor || !x || !y || n < 0)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    DNS_HIP(hipSetDevice(device));
+    ScopedStream ss;
+    DNS_HIP(hipStreamCreate(&ss.s));
+    DevBuf<double> da, dx, dy;
+    DNS_TRY(da.alloc((size_t)n * n));
+    DNS_TRY(dx.alloc((size_t)n));
+    DNS_TRY(dy.alloc((size_t)n));
+    DNS_TRY(da.upload(a_rowmajor, (size_t)n * n, ss.s));
+    DNS_TRY(dx.upload(x, (size_t)n, ss.s));
+    hipLaunchKernelGGL(k_gemv_rows, std::max(1, std::min((n + 3) / 4, 2048)),
+                       kBlock, 0, ss.s, n, da.p, dx.p, dy.p, alpha,
+                       (const DnsCtl *)nullptr);
+    DNS_HIP(hipGetLastError());
+    DNS_TRY(dy.download(y, (size_t)n, ss.s));
+    DNS_HIP(hipStreamSynchronize(ss.s));
+    return DNS_OK;
+}
+
+int dns_dense_inverse(int device, int32_t n, double *a_rowmajor) {
+    if (!a_rowmajor || n < 1)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    DNS_HIP(hipSetDevice(device));
+    dns_saddle tmp;   // only its stream and invert_dense are used
+    tmp.device = device;
+    DNS_HIP(hipStreamCreateWithFlags(&tmp.stream, hipStreamNonBlocking));
+    DevBuf<double> da;
+    DNS_TRY(da.alloc((size_t)n * n));
+    DNS_TRY(da.upload(a_rowmajor, (size_t)n * n, tmp.stream));
+    DNS_TRY(tmp.invert_dense(da.p, n));
+    DNS_TRY(da.download(a_rowmajor, (size_t)n * n, tmp.stream));
+    DNS_HIP(hipStreamSynchronize(tmp.stream));
+    return DNS_OK;
+}
+
+int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
+                   int32_t warmup, double *avg_seconds, double *checksum) {
+    DNS_TRY(check_csr(a, "A"));
+    if (!avg_seconds || reps < 1)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    DNS_HIP(hipSetDevice(device));
+    ScopedStream ss;
+    DNS_HIP(hipStreamCreate(&ss.s));
+    CsrDev A;
+    DNS_TRY(A.upload(a, ss.s));
+    DevBuf<double> dx, dy, part, res;
+    DNS_TRY(dx.alloc((size_t)a->ncols));
+    DNS_TRY(dy.alloc((size_t)a->nrows));
+    hipLaunchKernelGGL(k_fill_wave, grid_for_elems(a->ncols), kBlock, 0, ss.s,
+                       a->ncols, dx.p, 0.37, 1.0, 0);
+    for (int i = 0; i < warmup; ++i)
+        DNS_TRY(launch_spmv(A, dx.p, dy.p, 1.0, 0.0, nullptr, variant, ss.s));
+    hipEvent_t e0, e1;
+    DNS_HIP(hipEventCreate(&e0));
+    DNS_HIP(hipEventCreate(&e1));
+    DNS_HIP(hipEventRecord(e0, ss.s));
+    for (int i = 0; i < reps; ++i)
+        DNS_TRY(launch_spmv(A, dx.p, dy.p, 1.0, 0.0, nullptr, variant, ss.s));
+    DNS_HIP(hipEventRecord(e1, ss.s));
+    DNS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DNS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_seconds = 1e-3 * ms / reps;
+    if (checksum) {
+        const int g = grid_for_elems(a->nrows);
+        DNS_TRY(part.alloc((size_t)g));
+        DNS_TRY(res.alloc(1));
+        hipLaunchKernelGGL(k_dot_partials, g, kBlock, 0, ss.s,
+                           (int64_t)a->nrows, dy.p, dy.p, part.p);
+        hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, ss.s, part.p, g,
+                           res.p);
+        DNS_TRY(res.download(checksum, 1, ss.s));
+        DNS_HIP(hipStreamSynchronize(ss.s));
+    }
+    return DNS_OK;
+}
+
+}  // extern "C"
+
+#include "imex_capi.inc"

@@ -1,0 +1,23 @@
+// Device-resident IMEX stepper state (CNAB / SBDF2 inner loops).
+#pragma once
+#include "solver.hpp"
+
+struct dns_imex {
+    dns_saddle *sys = nullptr;
+    dns::CsrDev R1;
+    // two solution-space vectors [v; p~] (current, previous) + work
+    dns::DevBuf<double> xs[3];
+    int cur = 0, prev = 1, work = 2;
+    int nsol = 0;                  // how many valid solution vectors (0,1,2)
+    dns::DevBuf<double> nfc[2];
+    int nc = 0, no = 1;
+    dns::DevBuf<double> g, gp, b;
+    double last_pscale = 1.0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~dns_imex() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    int step_device(const dns_imex_coeffs *cf, const dns_solve_opts *o,
+                    dns_solve_stats *st, bool with_true_residual);
+};

@@ -1,0 +1,173 @@
+// Host-side driver of the saddle-point solve: owns the HBM-resident system,
+// the block preconditioner and the Krylov workspace; enqueues the kernels of
+// kernels.hpp / bicgstab_kernels.hpp on one HIP stream.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+
+#include "bicgstab_kernels.hpp"
+#include "kernels.hpp"
+
+namespace dns {
+
+#define DNS_LPR_SWITCH(lpr, CALL)                                            \
+    switch (lpr) {                                                           \
+        case 2: { constexpr int L = 2; CALL; } break;                        \
+        case 4: { constexpr int L = 4; CALL; } break;                        \
+        case 8: { constexpr int L = 8; CALL; } break;                        \
+        case 16: { constexpr int L = 16; CALL; } break;                      \
+        case 32: { constexpr int L = 32; CALL; } break;                      \
+        default: { constexpr int L = 64; CALL; } break;                      \
+    }
+
+inline int grid_for_rows(int nrows, int lpr) {
+    const int rows_per_block = kBlock / lpr;
+    long g = ((long)nrows + rows_per_block - 1) / rows_per_block;
+    return (int)std::max(1L, std::min(g, 4096L));
+}
+
+inline int grid_for_elems(int64_t n) {
+    int64_t g = (n + kBlock - 1) / kBlock;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, 2048));
+}
+
+inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
+    nrows = a->nrows;
+    ncols = a->ncols;
+    nnz = a->nnz;
+    lpr = pick_lpr(nrows > 0 ? (double)nnz / nrows : 1.0);
+    DNS_TRY(rowptr.alloc((size_t)nrows + 1));
+    DNS_TRY(colidx.alloc((size_t)nnz));
+    DNS_TRY(vals.alloc((size_t)nnz));
+    DNS_TRY(rowptr.upload(a->rowptr, (size_t)nrows + 1, s));
+    DNS_TRY(colidx.upload(a->colidx, (size_t)nnz, s));
+    DNS_TRY(vals.upload(a->vals, (size_t)nnz, s));
+    // row blocks of the LDS-streaming kernel: consecutive rows with at most
+    // kStreamNnz non-zeros and at most kBlock rows; a longer row stands alone
+    std::vector<int> rb;
+    rb.push_back(0);
+    int start = 0;
+    while (start < nrows) {
+        int end = start;
+        int64_t acc = 0;
+        while (end < nrows && (end - start) < kBlock) {
+            const int64_t len = a->rowptr[end + 1] - a->rowptr[end];
+            if (acc + len > kStreamNnz) break;
+            acc += len;
+            ++end;
+        }
+        if (end == start) end = start + 1;   // single long row
+        rb.push_back(end);
+        start = end;
+    }
+    nrowblocks = (int)rb.size() - 1;
+    DNS_TRY(rowblocks.alloc(rb.size()));
+    DNS_TRY(rowblocks.upload(rb.data(), rb.size(), s));
+    DNS_HIP(hipStreamSynchronize(s));       // `rb` is a stack temporary
+    return DNS_OK;
+}
+
+// y = alpha*A*x + beta*b on `s` (device pointers)
+inline int launch_spmv(const CsrDev &A, const double *x, double *y,
+                       double alpha, double beta, const double *b, int variant,
+                       hipStream_t s) {
+    if (A.nrows == 0) return DNS_OK;
+    if (variant == DNS_SPMV_STREAM) {
+        const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
+        const int grid = std::min(A.nrowblocks, 65535);
+        if (avg <= 6)
+            hipLaunchKernelGGL(k_spmv_stream<1>, grid, kBlock, 0, s,
+                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
+                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
+        else if (avg <= 12)
+            hipLaunchKernelGGL(k_spmv_stream<2>, grid, kBlock, 0, s,
+                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
+                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
+        else if (avg <= 48)
+            hipLaunchKernelGGL(k_spmv_stream<4>, grid, kBlock, 0, s,
+                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
+                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
+        else
+            hipLaunchKernelGGL(k_spmv_stream<16>, grid, kBlock, 0, s,
+                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
+                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
+    } else {
+        const int grid = grid_for_rows(A.nrows, A.lpr);
+        DNS_LPR_SWITCH(A.lpr,
+                       hipLaunchKernelGGL(k_spmv_vec<L>, grid, kBlock, 0, s,
+                                          A.nrows, A.rowptr.p, A.colidx.p,
+                                          A.vals.p, x, y, alpha, beta, b));
+    }
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+struct CtlHeader {   // leading part of DnsCtl, copied back to the host
+    int jv[2];
+    int done, status, zero, total_it, pad0, pad1;
+    double beta, tol, resnorm, bnorm;
+};
+
+}  // namespace dns
+
+// the opaque handle of the C-ABI
+struct dns_saddle {
+    int device = 0;
+    int nv = 0, np = 0, n = 0;
+    size_t ld = 0;                   // leading dimension of basis vectors
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    dns::CsrDev F, J, JT, K;
+    dns::DevBuf<double> dinv;        // 1/diag(F)
+    // preconditioner
+    bool precond_ready = false;
+    dns_precond_opts popts;
+    double lam_lo = 0, lam_hi = 0, theta = 0, delta = 0;
+    std::vector<double> c1, c2;      // Chebyshev recurrence coefficients
+    dns::DevBuf<double> sinv;        // dense Schur inverse (np x np) or diag
+    dns::DevBuf<double> cheb_r, cheb_d0, cheb_d1;
+    // Krylov workspace
+    int nred = 64;
+    dns::DevBuf<double> V, w, z, u, r, xdev, bdev;
+    dns::DevBuf<double> partA, partN, partR, partB, partC;
+    dns::DevBuf<double> bi_rhat, bi_p, bi_v, bi_s, bi_t, bi_y, histdev;
+    dns::DevBuf<dns::DnsCtl> ctl;
+    dns::DevBuf<dns::BicgCtl> bctl;
+    dns::DevBuf<double> scal;        // small scalar scratch
+    dns::CtlHeader *hdr_host = nullptr;   // pinned
+    double *scal_host = nullptr;          // pinned
+    std::vector<double> history;
+    int64_t spmv_count = 0;
+
+    ~dns_saddle();
+    int init(int dev, const dns_csr *f, const dns_csr *j, const dns_csr *jt);
+    int update_values(const double *fvals);
+    int setup_precond(const dns_precond_opts *o);
+    int estimate_bounds();
+    int build_dense_schur();
+    int build_jacobi_schur();
+    int invert_dense(double *a, int nn);
+    int ensure_workspace(int m);
+    // z = P^-1 (vector `*jsel` of rbase); all device pointers
+    int apply_precond(const double *rbase, size_t ldr, const int *jsel,
+                      double *zout);
+    int dot_host(int64_t len, const double *x, const double *y, double *out);
+    int read_header();
+    int solve_device(const double *b, double *x, const dns_solve_opts *o,
+                     dns_solve_stats *st);
+    int gmres(const double *b, double *x, const dns_solve_opts *o,
+              dns_solve_stats *st);
+    int bicgstab(const double *b, double *x, const dns_solve_opts *o,
+                 dns_solve_stats *st);
+    int true_residual(const double *b, const double *x, double *out);
+    const int *jsel_ptr(int par) const {
+        return reinterpret_cast<const int *>(
+            reinterpret_cast<const char *>(ctl.p) +
+            offsetof(dns::DnsCtl, jv) + sizeof(int) * par);
+    }
+    const int *zero_ptr() const {
+        return reinterpret_cast<const int *>(
+            reinterpret_cast<const char *>(ctl.p) + offsetof(dns::DnsCtl, zero));
+    }
+};

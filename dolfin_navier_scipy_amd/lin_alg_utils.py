@@ -1,0 +1,241 @@
+"""Drop-in for `sadptprj_riclyap_adi.lin_alg_utils` (`lau`) on MI355X.
+
+The reference binds this module's name at `time_int_utils.py:9`,
+`stokes_navier_utils.py:291,723-724,1614` and `residual_checks.py:7`; call
+`dolfin_navier_scipy_amd.install_as_lau()` before importing it and every
+saddle-point solve of `solve_nse`/`cnab`/`sbdftwo` runs on the GPU.
+
+Surface (reconstructed from the reference's call sites):
+`solve_sadpnt_smw`, `app_prj_via_sadpnt`, `apply_massinv`,
+`SpslaKrylovCounter`.  All arithmetic of the solves is done by the HIP library
+(`include/dns_amd.h`); there is no SciPy/CPU fallback -- a missing library or
+GPU raises.
+
+Differences to a sparse direct solve, by construction: the answer is the
+limit of a block-preconditioned Krylov iteration, stopped at
+`||K x - b|| <= tol * ||b||` (`tol` from `krpslvprms['tol']`, default 1e-12
+when `krylov` is None, i.e. where the reference would factorise).
+"""
+import hashlib
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import _capi as C
+from .saddle import SaddleSystem, solve_opts
+
+__all__ = ['solve_sadpnt_smw', 'app_prj_via_sadpnt', 'apply_massinv',
+           'SpslaKrylovCounter', 'clear_cache', 'DEFAULTS']
+
+DEFAULTS = dict(direct_tol=1e-12, maxiter=600, restart=60, cheb_degree=4,
+                schur='auto', schur_dense_max=6000, refresh_tol=0.1,
+                device=0, cache_size=4)
+
+_cache = {}          # pattern key -> _Entry
+_cache_order = []
+
+
+class _Entry(object):
+    def __init__(self, system, diag, pkw):
+        self.system, self.diag, self.pkw = system, diag, pkw
+
+
+def clear_cache():
+    for ent in _cache.values():
+        ent.system.close()
+    _cache.clear()
+    del _cache_order[:]
+
+
+def _pattern_key(amat, jmat):
+    hsh = hashlib.blake2b(digest_size=16)
+    for arr in (amat.indptr, amat.indices, jmat.indptr, jmat.indices):
+        hsh.update(np.ascontiguousarray(arr, dtype=np.int32).tobytes())
+    return (amat.shape, jmat.shape, amat.nnz, jmat.nnz, hsh.hexdigest())
+
+
+def _canonical(mat):
+    mat = sps.csr_matrix(mat)
+    if not mat.has_canonical_format:
+        mat = mat.copy()
+        mat.sum_duplicates()
+    return mat
+
+
+def _precond_kwargs(NP, krplsprms):
+    prm = dict(krplsprms or {})
+    schur = prm.get('schur', DEFAULTS['schur'])
+    if schur == 'auto':
+        schur = 'dense' if NP <= DEFAULTS['schur_dense_max'] else 'jacobi'
+    return dict(cheb_degree=prm.get('cheb_degree', DEFAULTS['cheb_degree']),
+                schur=schur, eig_lo=prm.get('eig_lo', 0.),
+                eig_hi=prm.get('eig_hi', 0.))
+
+
+def _get_system(amat, jmat, jmatT, krplsprms):
+    """the HBM-resident system for this sparsity pattern; same pattern with new
+    values (Newton/Picard re-linearisation, snu:1484-1491) only re-uploads the
+    values and keeps the preconditioner unless the diagonal moved by more
+    than `refresh_tol`"""
+    amat, jmat = _canonical(amat), _canonical(jmat)
+    key = _pattern_key(amat, jmat)
+    pkw = _precond_kwargs(jmat.shape[0], krplsprms)
+    diag = amat.diagonal()
+    ent = _cache.get(key)
+    if ent is None:
+        system = SaddleSystem(amat, jmat, JT=jmatT, device=DEFAULTS['device'])
+        system.setup_precond(**pkw)
+        ent = _Entry(system, diag, pkw)
+        _cache[key] = ent
+        _cache_order.append(key)
+        while len(_cache_order) > DEFAULTS['cache_size']:
+            old = _cache_order.pop(0)
+            _cache.pop(old).system.close()
+    else:
+        ent.system.update_values(amat.data)
+        moved = np.abs(diag - ent.diag).max() / max(np.abs(ent.diag).max(),
+                                                    1e-300)
+        if moved > DEFAULTS['refresh_tol'] or pkw != ent.pkw:
+            ent.system.setup_precond(**pkw)
+            ent.diag, ent.pkw = diag, pkw
+    return ent.system
+
+
+def _solver_opts(krylov, krpslvprms):
+    prm = krpslvprms if isinstance(krpslvprms, dict) else {}
+    if krylov is None:
+        method, tol = 'gmres', DEFAULTS['direct_tol']
+    else:
+        kname = str(krylov).lower()
+        if kname in ('gmres', 'bicgstab'):
+            method = kname
+        elif kname in ('minres', 'cg'):
+            method = 'gmres'   # symmetric solvers map to GMRES on this path
+        else:
+            raise ValueError('unknown Krylov method `{0}`'.format(krylov))
+        tol = prm.get('tol', 1e-8)
+    return solve_opts(method=method, rtol=tol,
+                      maxiter=prm.get('maxiter', DEFAULTS['maxiter']),
+                      restart=prm.get('restart', DEFAULTS['restart']))
+
+
+class _SaddleSolveFn(object):
+    """what `return_alu=True` hands back (used as `solve_fn((n,1) array)`,
+    reference tiu:605-615): solves with the resident system"""
+
+    def __init__(self, system, opts):
+        self.system, self.opts = system, opts
+
+    def __call__(self, rhs):
+        rhs = np.asarray(rhs, dtype=np.float64)
+        shape = rhs.shape
+        cols = rhs.reshape((self.system.n, -1))
+        out = np.empty_like(cols)
+        NV = self.system.NV
+        for k in range(cols.shape[1]):
+            out[:, k] = self.system.solve(cols[:NV, k], cols[NV:, k],
+                                          opts=self.opts)
+        return out.reshape(shape)
+
+
+def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
+                     umat=None, vmat=None, krylov=None, krpslvprms={},
+                     krplsprms={}, return_alu=False, decouplevp=False,
+                     solve_A=None, symmetric=False, cgtol=1e-8, **kw):
+    """solve `[[A - U V, J^T], [J, 0]] [v; p] = [rhsv; rhsp]` on the GPU
+
+    Parameters as consumed by the reference; returns the
+    `(NV+NP, k)` array `[v; p]`, or `(sol, solve_fn)` if `return_alu`.
+    """
+    if amat is None:
+        raise NotImplementedError(
+            'the decoupled variant (`amat` omitted, `solve_A` callable, '
+            'snu:1622) is not part of the MI355X path')
+    if jmat is None or rhsv is None:
+        raise ValueError('`jmat` and `rhsv` are required')
+    NP, NV = jmat.shape
+    rhsv = np.asarray(rhsv, dtype=np.float64).reshape((NV, -1))
+    ncols = rhsv.shape[1]
+    rhsp = np.zeros((NP, ncols)) if rhsp is None else \
+        np.asarray(rhsp, dtype=np.float64).reshape((NP, -1))
+    system = _get_system(amat, jmat, jmatT, krplsprms)
+    opts = _solver_opts(krylov, krpslvprms)
+    prm = krpslvprms if isinstance(krpslvprms, dict) else {}
+    x0 = prm.get('x0', None)
+
+    def _solve_cols(rv, rp, x0=None):
+        out = np.empty((NV+NP, rv.shape[1]))
+        x0c = None if x0 is None else \
+            np.asarray(x0, dtype=np.float64).reshape((NV+NP, -1))
+        for k in range(rv.shape[1]):
+            xk = None if x0c is None else x0c[:, min(k, x0c.shape[1]-1)]
+            out[:, k] = system.solve(rv[:, k], rp[:, k], x0=xk, opts=opts)
+            if 'convstatsl' in prm:
+                prm['convstatsl'].append(system.residual_history().tolist())
+        return out
+
+    sol = _solve_cols(rhsv, rhsp, x0=x0)
+    if umat is not None:
+        # Sherman-Morrison-Woodbury with the resident system:
+        # (K - Ue Ve)^-1 = K^-1 + K^-1 Ue (I - Ve K^-1 Ue)^-1 Ve K^-1
+        umat = np.asarray(umat.todense()) if sps.issparse(umat) \
+            else np.asarray(umat, dtype=np.float64)
+        vmat = np.asarray(vmat.todense()) if sps.issparse(vmat) \
+            else np.asarray(vmat, dtype=np.float64)
+        r = umat.shape[1]
+        kiu = _solve_cols(umat.reshape((NV, r)), np.zeros((NP, r)))
+        small = np.eye(r) - vmat.dot(kiu[:NV, :])
+        sol = sol + kiu.dot(np.linalg.solve(small, vmat.dot(sol[:NV, :])))
+    if return_alu:
+        return sol, _SaddleSolveFn(system, opts)
+    return sol
+
+
+def app_prj_via_sadpnt(amat=None, jmat=None, rhsv=None, jmatT=None,
+                       umat=None, vmat=None, transposedprj=False, **kw):
+    """apply `Pi = I - A^-1 J^T S^-1 J` (or `Pi^T`) through a saddle solve
+    (reference `residual_checks.py:21-35`, `time_int_utils.py:422-425`)"""
+    NP, NV = jmat.shape
+    rhsv = np.asarray(rhsv, dtype=np.float64).reshape((NV, -1))
+    jT = sps.csr_matrix(jmat.T) if jmatT is None else jmatT
+    if transposedprj:
+        wq = solve_sadpnt_smw(amat=amat, jmat=jmat, jmatT=jT, rhsv=rhsv,
+                              umat=umat, vmat=vmat)
+        return rhsv - jT @ wq[NV:, :]
+    wq = solve_sadpnt_smw(amat=amat, jmat=jmat, jmatT=jT, rhsv=amat @ rhsv,
+                          umat=umat, vmat=vmat)
+    return wq[:NV, :]
+
+
+def apply_massinv(M, rhsa, output=None):
+    """`M^-1 rhsa` column by column with the device Chebyshev/GMRES solve of
+    the degenerate saddle system with an empty constraint block
+    (reference `tests/time_dep_nse_bigchannel.py:33`)"""
+    M = _canonical(M)
+    NV = M.shape[0]
+    dense = np.asarray(rhsa.todense()) if sps.issparse(rhsa) \
+        else np.asarray(rhsa, dtype=np.float64).reshape((NV, -1))
+    jmat = sps.csr_matrix((0, NV))
+    sol = solve_sadpnt_smw(amat=M, jmat=jmat, rhsv=dense,
+                           krplsprms=dict(schur='jacobi', cheb_degree=8))
+    return sps.csr_matrix(sol) if output == 'sparse' else sol
+
+
+class SpslaKrylovCounter(object):
+    """SciPy-style callback object collecting residual norms
+    (reference snu:724,861,876)"""
+
+    def __init__(self, A=None, b=None):
+        self.A, self.b = A, b
+        self.callbacks = []
+        self.niter = 0
+
+    def __call__(self, xk=None):
+        self.niter += 1
+        if self.A is not None and self.b is not None and xk is not None \
+                and np.ndim(xk) > 0:
+            res = np.linalg.norm(self.b.reshape(-1) - self.A.dot(
+                np.asarray(xk).reshape(-1)))
+        else:
+            res = float(xk) if xk is not None and np.ndim(xk) == 0 else np.nan
+        self.callbacks.append(res)

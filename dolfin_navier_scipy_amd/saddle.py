@@ -1,0 +1,262 @@
+"""Python handles on the device objects of `include/dns_amd.h`."""
+import ctypes as ct
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import _capi as C
+
+__all__ = ['SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
+           'dense_inverse', 'spmv_bench', 'solve_opts', 'precond_opts']
+
+_METHODS = {'gmres': C.DNS_METHOD_GMRES, 'bicgstab': C.DNS_METHOD_BICGSTAB}
+_SCHUR = {'dense': C.DNS_SCHUR_DENSE, 'jacobi': C.DNS_SCHUR_JACOBI}
+_VARIANTS = {'vector': C.DNS_SPMV_VECTOR, 'stream': C.DNS_SPMV_STREAM}
+
+
+def solve_opts(method='gmres', restart=60, maxiter=400, reorth=True,
+               rtol=1e-10, atol=0., check_every=4, use_graph=False):
+    o = C.dns_solve_opts()
+    C.load_library().dns_default_solve_opts(ct.byref(o))
+    o.method = _METHODS[method.lower()] if isinstance(method, str) else method
+    o.restart, o.maxiter = int(restart), int(maxiter)
+    o.reorth = 1 if reorth else 0
+    o.rtol, o.atol = float(rtol), float(atol)
+    o.check_every = int(check_every)
+    o.use_graph = 1 if use_graph else 0
+    return o
+
+
+def precond_opts(cheb_degree=4, schur='dense', eig_lo=0., eig_hi=0.,
+                 eig_lo_safety=0.9, eig_hi_safety=1.05):
+    o = C.dns_precond_opts()
+    C.load_library().dns_default_precond_opts(ct.byref(o))
+    o.cheb_degree = int(cheb_degree)
+    o.schur = _SCHUR[schur] if isinstance(schur, str) else schur
+    o.eig_lo, o.eig_hi = float(eig_lo), float(eig_hi)
+    o.eig_lo_safety, o.eig_hi_safety = float(eig_lo_safety), \
+        float(eig_hi_safety)
+    return o
+
+
+class SaddleSystem(object):
+    """`[[F, JT], [J, 0]]` resident in HBM with its block preconditioner"""
+
+    def __init__(self, F, J, JT=None, device=0):
+        self.lib = C.load_library()
+        self._f = C.CsrView(F)
+        self._j = C.CsrView(J)
+        self._jt = C.CsrView(JT) if JT is not None else None
+        self.NP, self.NV = self._j.shape
+        self.n = self.NV + self.NP
+        self.device = device
+        self._h = ct.c_void_p()
+        C.check(self.lib.dns_saddle_create(
+            device, self._f.byref(), self._j.byref(),
+            self._jt.byref() if self._jt is not None else None,
+            ct.byref(self._h)))
+        self.last_stats = None
+        self.precond_ready = False
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.dns_saddle_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update_values(self, fdata):
+        fdata = C.as_f64(fdata, size=self._f.data.size)
+        C.check(self.lib.dns_saddle_update_values(self._h, C.dptr(fdata)))
+
+    def setup_precond(self, **kw):
+        o = precond_opts(**kw)
+        C.check(self.lib.dns_saddle_setup_precond(self._h, ct.byref(o)))
+        self.precond_ready = True
+
+    def cheb_bounds(self):
+        lo, hi = ct.c_double(), ct.c_double()
+        C.check(self.lib.dns_saddle_cheb_bounds(self._h, ct.byref(lo),
+                                                ct.byref(hi)))
+        return lo.value, hi.value
+
+    def solve(self, rhsv, rhsp=None, x0=None, raise_on_fail=True, **kw):
+        """returns `[v; p~]` as a 1-D array of length NV+NP"""
+        o = kw.pop('opts', None)
+        o = solve_opts(**kw) if o is None else o
+        rv = C.as_f64(rhsv, size=self.NV)
+        rp = None if rhsp is None else C.as_f64(rhsp, size=self.NP)
+        xi = None if x0 is None else C.as_f64(x0, size=self.n)
+        out = np.empty(self.n)
+        st = C.dns_solve_stats()
+        C.check(self.lib.dns_saddle_solve(self._h, C.dptr(rv), C.dptr(rp),
+                                          C.dptr(xi), C.dptr(out),
+                                          ct.byref(o), ct.byref(st)))
+        self.last_stats = st.asdict()
+        if raise_on_fail and st.status != C.DNS_OK:
+            cls = C.NotConverged if st.status == C.DNS_NOT_CONVERGED \
+                else C.Breakdown
+            raise cls(st.status, 'Krylov solve stopped after {0} iterations '
+                      'at relative residual {1:.3e}'.format(st.iters,
+                                                            st.est_relres))
+        return out
+
+    def residual_history(self):
+        cnt = ct.c_int32(0)
+        C.check(self.lib.dns_saddle_residual_history(self._h, None, 0,
+                                                     ct.byref(cnt)))
+        out = np.zeros(max(cnt.value, 1))
+        C.check(self.lib.dns_saddle_residual_history(
+            self._h, C.dptr(out), cnt.value, ct.byref(cnt)))
+        return out[:cnt.value]
+
+    def apply(self, x):
+        x = C.as_f64(x, size=self.n)
+        y = np.empty(self.n)
+        C.check(self.lib.dns_saddle_apply(self._h, C.dptr(x), C.dptr(y)))
+        return y
+
+    def apply_precond(self, r):
+        r = C.as_f64(r, size=self.n)
+        z = np.empty(self.n)
+        C.check(self.lib.dns_saddle_apply_precond(self._h, C.dptr(r),
+                                                  C.dptr(z)))
+        return z
+
+
+class ImexStepper(object):
+    """device-resident CNAB/SBDF2 state (`dns_imex_*`)"""
+
+    def __init__(self, system, R1):
+        self.sys = system
+        self.lib = system.lib
+        self._r1 = C.CsrView(R1)
+        self._h = ct.c_void_p()
+        C.check(self.lib.dns_imex_create(system._h, self._r1.byref(),
+                                         ct.byref(self._h)))
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.dns_imex_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, v_c, v_p=None, ptilde_c=None, nfc_c=None, nfc_o=None):
+        NV, NP = self.sys.NV, self.sys.NP
+        args = [C.as_f64(v_c, NV),
+                None if v_p is None else C.as_f64(v_p, NV),
+                None if ptilde_c is None else C.as_f64(ptilde_c, NP),
+                None if nfc_c is None else C.as_f64(nfc_c, NV),
+                None if nfc_o is None else C.as_f64(nfc_o, NV)]
+        C.check(self.lib.dns_imex_set_state(self._h, *[C.dptr(a)
+                                                       for a in args]))
+
+    def set_rhs(self, gvec=None, rhsp=None):
+        g = None if gvec is None else C.as_f64(gvec, self.sys.NV)
+        gp = None if rhsp is None else C.as_f64(rhsp, self.sys.NP)
+        C.check(self.lib.dns_imex_set_rhs(self._h, C.dptr(g), C.dptr(gp)))
+
+    @staticmethod
+    def coeffs(a_c=1., a_p=0., cn_c=0., cn_o=0., pscale=1., extrapolate=True):
+        return C.dns_imex_coeffs(a_c=a_c, a_p=a_p, cn_c=cn_c, cn_o=cn_o,
+                                 pscale=pscale,
+                                 extrapolate_x0=1 if extrapolate else 0, pad=0)
+
+    def step(self, cf, nfc_new=None, opts=None, raise_on_fail=True):
+        o = solve_opts() if opts is None else opts
+        nf = None if nfc_new is None else C.as_f64(nfc_new, self.sys.NV)
+        st = C.dns_solve_stats()
+        C.check(self.lib.dns_imex_step(self._h, C.dptr(nf), ct.byref(cf),
+                                       ct.byref(o), ct.byref(st)))
+        self.last_stats = st.asdict()
+        if raise_on_fail and st.status != C.DNS_OK:
+            raise C.NotConverged(st.status, 'time step solve failed: '
+                                 '{0}'.format(self.last_stats))
+        return self.last_stats
+
+    def run(self, nsteps, cf, opts=None):
+        """`nsteps` steps with frozen convection history; returns
+        `(device_seconds, total_iters, last_stats)`"""
+        o = solve_opts() if opts is None else opts
+        st = C.dns_solve_stats()
+        secs = ct.c_double(0.)
+        its = ct.c_int64(0)
+        C.check(self.lib.dns_imex_run(self._h, int(nsteps), ct.byref(cf),
+                                      ct.byref(o), ct.byref(st),
+                                      ct.byref(secs), ct.byref(its)))
+        self.last_stats = st.asdict()
+        return secs.value, its.value, self.last_stats
+
+    def get_state(self):
+        v = np.empty(self.sys.NV)
+        p = np.empty(self.sys.NP)
+        C.check(self.lib.dns_imex_get_state(self._h, C.dptr(v), C.dptr(p)))
+        return v.reshape((-1, 1)), p.reshape((-1, 1))
+
+    def vnorm(self):
+        out = ct.c_double(0.)
+        C.check(self.lib.dns_imex_vnorm(self._h, ct.byref(out)))
+        return out.value
+
+
+# ---- standalone kernels ---------------------------------------------------
+def spmv(A, x, y=None, alpha=1., beta=0., variant='vector', device=0):
+    lib = C.load_library()
+    view = C.CsrView(A)
+    x = C.as_f64(x, size=view.shape[1])
+    out = np.zeros(view.shape[0]) if y is None else C.as_f64(y).copy()
+    C.check(lib.dns_spmv(device, view.byref(), C.dptr(x), C.dptr(out),
+                         float(alpha), float(beta), _VARIANTS[variant]))
+    return out
+
+
+def dot(x, y, device=0):
+    x, y = C.as_f64(x), C.as_f64(y)
+    out = ct.c_double(0.)
+    C.check(C.load_library().dns_dot(device, x.size, C.dptr(x), C.dptr(y),
+                                     ct.byref(out)))
+    return out.value
+
+
+def axpy(a, x, y, device=0):
+    x = C.as_f64(x)
+    out = C.as_f64(y).copy()
+    C.check(C.load_library().dns_axpy(device, x.size, float(a), C.dptr(x),
+                                      C.dptr(out)))
+    return out
+
+
+def gemv(A, x, alpha=1., device=0):
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    x = C.as_f64(x, size=A.shape[0])
+    y = np.empty(A.shape[0])
+    C.check(C.load_library().dns_gemv(device, A.shape[0], C.dptr(A),
+                                      C.dptr(x), C.dptr(y), float(alpha)))
+    return y
+
+
+def dense_inverse(A, device=0):
+    out = np.array(A, dtype=np.float64, order='C', copy=True)
+    C.check(C.load_library().dns_dense_inverse(device, out.shape[0],
+                                               C.dptr(out)))
+    return out
+
+
+def spmv_bench(A, variant='stream', reps=50, warmup=5, device=0):
+    """average seconds per `y = A x` on resident data, and `||y||^2`"""
+    view = C.CsrView(sps.csr_matrix(A))
+    secs, chk = ct.c_double(0.), ct.c_double(0.)
+    C.check(C.load_library().dns_spmv_bench(
+        device, view.byref(), _VARIANTS[variant], int(reps), int(warmup),
+        ct.byref(secs), ct.byref(chk)))
+    return secs.value, chk.value

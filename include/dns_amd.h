@@ -1,0 +1,208 @@
+/*
+ * dns_amd.h -- C-ABI of the MI355X (gfx950) saddle-point time-stepping path.
+ *
+ * Drop-in boundary for dolfin_navier_scipy's linear-algebra layer.  The
+ * reference reaches its solver through the Python module
+ * `sadptprj_riclyap_adi.lin_alg_utils` (un-vendored; call sites listed below)
+ * and through `scipy.sparse.linalg.factorized`; the Python wrapper
+ * `dolfin_navier_scipy_amd/lin_alg_utils.py` binds the entry points declared
+ * here with `ctypes` and presents that same Python surface.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are HOST pointers unless the
+ *    name ends in `_dev`; buffers are borrowed for the duration of the call;
+ *  - matrices are CSR with int32 indices and float64 values (what
+ *    `dolfin_to_sparrays.mat_dolfin2sparse` produces, reference dts:67-81);
+ *  - every function returns a status code (0 = ok); `dns_last_error()` gives
+ *    the message of the last failure on the calling thread;
+ *  - one host thread per handle, one HIP stream per handle.
+ *
+ * Saddle-point contract:
+ *      [ F   JT ] [ v  ]   [ rhs_v ]
+ *      [ J   0  ] [ p~ ] = [ rhs_p ]      F = M + theta*dt*(A [+ N(v_lin)])
+ */
+#ifndef DNS_AMD_H
+#define DNS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNS_OK               0
+#define DNS_NOT_CONVERGED    1   /* maxiter reached, best iterate returned   */
+#define DNS_BREAKDOWN        2   /* Krylov / factorisation breakdown         */
+#define DNS_ERR_HIP          3   /* a HIP runtime call failed                */
+#define DNS_ERR_BAD_ARGUMENT 4
+#define DNS_ERR_NOT_READY    5   /* e.g. solve before the preconditioner     */
+#define DNS_ERR_COMM         6   /* RCCL failure                             */
+
+#define DNS_METHOD_GMRES     0
+#define DNS_METHOD_BICGSTAB  1
+
+#define DNS_SCHUR_DENSE      0   /* explicit inverse of J Fh^-1 JT (NP small) */
+#define DNS_SCHUR_JACOBI     1   /* diag(J D^-1 JT)^-1  (always available)   */
+
+#define DNS_SPMV_VECTOR      0   /* sub-wave per row, shuffle reduction      */
+#define DNS_SPMV_STREAM      1   /* row blocks streamed through LDS          */
+
+typedef struct dns_saddle dns_saddle;   /* opaque: one saddle-point system  */
+typedef struct dns_imex dns_imex;       /* opaque: device-resident stepper  */
+
+typedef struct dns_csr {         /* host-side CSR view (borrowed)            */
+    int32_t nrows, ncols;
+    int64_t nnz;
+    const int32_t *rowptr;       /* nrows+1 */
+    const int32_t *colidx;       /* nnz     */
+    const double  *vals;         /* nnz     */
+} dns_csr;
+
+typedef struct dns_precond_opts {
+    int32_t cheb_degree;         /* terms of the Jacobi-Chebyshev F^-1 (>=1) */
+    int32_t schur;               /* DNS_SCHUR_*                              */
+    double  eig_lo_safety;       /* multiply the estimated lambda_min (0.9)  */
+    double  eig_hi_safety;       /* multiply the estimated lambda_max (1.05) */
+    double  eig_lo, eig_hi;      /* >0: use these bounds, skip the estimate  */
+} dns_precond_opts;
+
+typedef struct dns_solve_opts {
+    int32_t method;              /* DNS_METHOD_*                             */
+    int32_t restart;             /* GMRES cycle length (<= 64)               */
+    int32_t maxiter;             /* total inner iterations                   */
+    int32_t reorth;              /* 1: twice-applied Gram-Schmidt            */
+    double  rtol;                /* stop at ||r|| <= max(rtol*||b||, atol)   */
+    double  atol;
+    int32_t check_every;         /* host polls the device flag every k its   */
+    int32_t use_graph;           /* replay hipGraph chunks instead of eager  */
+} dns_solve_opts;
+
+typedef struct dns_solve_stats {
+    int32_t iters;               /* Krylov iterations performed              */
+    int32_t status;              /* DNS_OK / DNS_NOT_CONVERGED / ...         */
+    int32_t spmv_count;          /* K applies + F applies (preconditioner)   */
+    int32_t restarts;
+    double  bnorm;               /* ||[rhs_v; rhs_p]||_2                     */
+    double  est_relres;          /* recurrence residual / ||b||              */
+    double  true_relres;         /* ||b - K x|| / ||b|| recomputed at the end*/
+    double  device_seconds;      /* HIP-event time of the solve on its stream*/
+} dns_solve_stats;
+
+/* ---- library ---------------------------------------------------------- */
+int         dns_version(void);
+const char *dns_status_string(int status);
+const char *dns_last_error(void);
+int         dns_device_count(int *count);
+int         dns_device_name(int device, char *buf, size_t buflen);
+
+/* ---- saddle-point systems ---------------------------------------------
+ * Replaces, per call site of `lau.solve_sadpnt_smw(amat=, jmat=, jmatT=,
+ * rhsv=, rhsp=, krylov=, krpslvprms=, ...)`:
+ *   stokes_navier_utils.py:401,458,497 (steady), :894,904 (initial Stokes),
+ *   :1505-1512 (per time step), :1622,1629 (get_pfromv);
+ *   time_int_utils.py:402,408,466 (Heun start), :605 (return_alu);
+ * and `scipy.sparse.linalg.factorized(K)` + `coeffmatlu(rhs)` at
+ *   time_int_utils.py:89-91,134 and :304-306,348.
+ * `jt` may be NULL (the transpose of `j` is formed on the host, as
+ * `jmatT=None -> jmat.T` at time_int_utils.py:605).
+ */
+int dns_saddle_create(int device, const dns_csr *f, const dns_csr *j,
+                      const dns_csr *jt, dns_saddle **out);
+void dns_saddle_destroy(dns_saddle *h);
+
+/* same sparsity pattern, new values of F (Newton/Picard re-linearisation:
+ * `solvmat = M + 0.5*dt*(A + N(v))`, stokes_navier_utils.py:1034,1484-1491) */
+int dns_saddle_update_values(dns_saddle *h, const double *f_vals);
+
+/* build / rebuild the block preconditioner  P = [[Fh, JT], [0, -Sh]] */
+int dns_saddle_setup_precond(dns_saddle *h, const dns_precond_opts *opts);
+
+/* out_vp = [v; p~] (NV+NP); x0 may be NULL (`krpslvprms['x0']`,
+ * stokes_navier_utils.py:1493-1503); rhs_p may be NULL (zero,
+ * stokes_navier_utils.py:1629-1632) */
+int dns_saddle_solve(dns_saddle *h, const double *rhs_v, const double *rhs_p,
+                     const double *x0, double *out_vp,
+                     const dns_solve_opts *opts, dns_solve_stats *stats);
+
+/* residual history of the last solve (`krpslvprms['convstatsl']`,
+ * tests/time_dep_nse_krylov.py:47); returns the number of entries written */
+int dns_saddle_residual_history(dns_saddle *h, double *out, int32_t cap,
+                                int32_t *count);
+
+/* y = K x for the assembled K = [[F, JT],[J, 0]] (parity / residual checks) */
+int dns_saddle_apply(dns_saddle *h, const double *x, double *y);
+/* z = P^-1 r (parity checks of the preconditioner) */
+int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z);
+/* eigenvalue bounds used by the Chebyshev iteration */
+int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi);
+void dns_default_precond_opts(dns_precond_opts *o);
+void dns_default_solve_opts(dns_solve_opts *o);
+
+/* ---- device-resident IMEX time loop -------------------------------------
+ * Replaces the inner loops of `time_int_utils.cnab` (tiu:104-143) and
+ * `time_int_utils.sbdftwo` (tiu:320-353): the state (v, p, history) and the
+ * constant system stay in HBM; per step the host supplies only what the
+ * reference obtains from callbacks.
+ *
+ *   rhs_v = R1 (a_c v_c + a_p v_p) + cn_c*nfc_c + cn_o*nfc_o + gvec
+ *   solve K [v_n; p~] = [rhs_v; rhs_p];   p_n = pscale * p~
+ *
+ *   CNAB : R1 = M - dt/2 A, a_c = 1,   a_p = 0,    cn_c = 3dt/2, cn_o = -dt/2
+ *   SBDF2: R1 = M,          a_c = 4/3, a_p = -1/3, cn_c = 4dt/3, cn_o = -2dt/3
+ */
+typedef struct dns_imex_coeffs {
+    double a_c, a_p;             /* weights of current / previous velocity   */
+    double cn_c, cn_o;           /* weights of current / old convection      */
+    double pscale;               /* p = pscale * p~  (scalep/dt, tiu:137)    */
+    int32_t extrapolate_x0;      /* 1: x0 = 2 x_c - x_p, 0: x0 = x_c         */
+    int32_t pad;
+} dns_imex_coeffs;
+
+int dns_imex_create(dns_saddle *sys, const dns_csr *r1, dns_imex **out);
+void dns_imex_destroy(dns_imex *st);
+/* set the state: current / previous velocity (v_p may be NULL), current p~
+ * (may be NULL = 0; only seeds the warm start), the two convection history
+ * vectors (NULL = 0) */
+int dns_imex_set_state(dns_imex *st, const double *v_c, const double *v_p,
+                       const double *ptilde_c, const double *nfc_c,
+                       const double *nfc_o);
+/* constant (or updated) parts of the right-hand side; NULL keeps the old */
+int dns_imex_set_rhs(dns_imex *st, const double *gvec, const double *rhs_p);
+/* one step; `nfc_new` (host, may be NULL) is the convection vector
+ * f_vdp(v_c) evaluated by the caller at the current velocity -- it becomes
+ * nfc_c, the old nfc_c becomes nfc_o (tiu:112-113).  NULL keeps both. */
+int dns_imex_step(dns_imex *st, const double *nfc_new,
+                  const dns_imex_coeffs *cf, const dns_solve_opts *opts,
+                  dns_solve_stats *stats);
+/* `nsteps` steps back to back with the convection history frozen (the linear
+ * algebra of the step alone); total HIP-event time on the handle's stream */
+int dns_imex_run(dns_imex *st, int32_t nsteps, const dns_imex_coeffs *cf,
+                 const dns_solve_opts *opts, dns_solve_stats *last_stats,
+                 double *device_seconds, int64_t *total_iters);
+/* v (NV) and p = pscale*p~ (NP) of the current state */
+int dns_imex_get_state(dns_imex *st, double *v, double *p);
+/* ||v||_2 of the current velocity (blow-up guard, tiu:94-103) */
+int dns_imex_vnorm(dns_imex *st, double *out);
+
+/* ---- standalone kernels (parity tests, micro-benchmarks) -----------------
+ * upload, run the same device kernels the solver uses, download */
+int dns_spmv(int device, const dns_csr *a, const double *x, double *y,
+             double alpha, double beta, int32_t variant);
+int dns_dot(int device, int64_t n, const double *x, const double *y,
+            double *out);
+int dns_axpy(int device, int64_t n, double a, const double *x, double *y);
+int dns_gemv(int device, int32_t n, const double *a_rowmajor, const double *x,
+             double *y, double alpha);
+/* dense in-place inverse by the device Gauss-Jordan used for the Schur block */
+int dns_dense_inverse(int device, int32_t n, double *a_rowmajor);
+
+/* repeat y = A x `reps` times on resident data; reports the average kernel
+ * time (HIP events on the launch stream) -- the roofline measurement */
+int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
+                   int32_t warmup, double *avg_seconds, double *checksum);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNS_AMD_H */

@@ -1,0 +1,110 @@
+"""CPU-side checks of the boundary: the library builds for gfx950, loads, and
+exports every symbol `include/dns_amd.h` declares; host-only argument checks."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def capi():
+    from dolfin_navier_scipy_amd.build import build_library
+    build_library(verbose=False)
+    from dolfin_navier_scipy_amd import _capi
+    _capi.load_library()
+    return _capi
+
+
+def test_header_symbols_all_exported(capi):
+    hdr = open(os.path.join(ROOT, 'include', 'dns_amd.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(dns_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    assert declared == set(capi.SIGNATURES.keys())
+    lib = capi.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_status_strings_and_defaults(capi):
+    lib = capi.load_library()
+    assert lib.dns_version() >= 100
+    assert lib.dns_status_string(0) == b'ok'
+    assert lib.dns_status_string(1) == b'not converged'
+    import ctypes as ct
+    o = capi.dns_solve_opts()
+    lib.dns_default_solve_opts(ct.byref(o))
+    assert o.restart <= 64 and o.rtol > 0 and o.maxiter > 0
+    p = capi.dns_precond_opts()
+    lib.dns_default_precond_opts(ct.byref(p))
+    assert p.cheb_degree >= 1
+
+
+def test_struct_layout_matches_header(capi):
+    import ctypes as ct
+    assert ct.sizeof(capi.dns_csr) == 40
+    assert ct.sizeof(capi.dns_precond_opts) == 40
+    assert ct.sizeof(capi.dns_solve_opts) == 40
+    assert ct.sizeof(capi.dns_solve_stats) == 48
+    assert ct.sizeof(capi.dns_imex_coeffs) == 48
+
+
+def test_null_and_bad_arguments_fail_cleanly(capi):
+    import ctypes as ct
+    lib = capi.load_library()
+    assert lib.dns_saddle_solve(None, None, None, None, None, None, None) \
+        == capi.DNS_ERR_BAD_ARGUMENT
+    assert b'null' in lib.dns_last_error()
+    assert lib.dns_saddle_setup_precond(None, None) == capi.DNS_ERR_BAD_ARGUMENT
+    out = ct.c_void_p()
+    assert lib.dns_saddle_create(0, None, None, None, ct.byref(out)) \
+        == capi.DNS_ERR_BAD_ARGUMENT
+    # malformed CSR is rejected on the host before any device work
+    A = sps.identity(4, format='csr')
+    view = capi.CsrView(A)
+    view.indices[2] = 9
+    x = np.ones(4)
+    y = np.zeros(4)
+    st = lib.dns_spmv(0, view.byref(), capi.dptr(x), capi.dptr(y), 1.0, 0.0, 0)
+    assert st == capi.DNS_ERR_BAD_ARGUMENT
+
+
+def test_no_device_is_loud(capi):
+    """without a GPU the product path must raise, never fall back"""
+    if capi.device_count() > 0:
+        pytest.skip('a GPU is present')
+    from dolfin_navier_scipy_amd import saddle
+    A = sps.identity(4, format='csr')
+    J = sps.csr_matrix(np.ones((1, 4)))
+    with pytest.raises(capi.DnsError):
+        saddle.SaddleSystem(A, J)
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    with pytest.raises(capi.DnsError):
+        lau.solve_sadpnt_smw(amat=A, jmat=J, rhsv=np.ones((4, 1)))
+
+
+def test_install_as_lau():
+    import sys
+    import dolfin_navier_scipy_amd as pkg
+    mod = pkg.install_as_lau()
+    import sadptprj_riclyap_adi.lin_alg_utils as lau
+    assert lau is mod
+    for name in ('solve_sadpnt_smw', 'app_prj_via_sadpnt',
+                 'SpslaKrylovCounter', 'apply_massinv'):
+        assert hasattr(lau, name)
+    sys.modules.pop('sadptprj_riclyap_adi.lin_alg_utils')
+    sys.modules.pop('sadptprj_riclyap_adi')
+
+
+def test_product_does_not_import_oracle():
+    pkgdir = os.path.join(ROOT, 'dolfin_navier_scipy_amd')
+    for dirpath, _, files in os.walk(pkgdir):
+        for fn in files:
+            if fn.endswith('.py'):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src
+                assert 'krylov_model' not in src

@@ -1,0 +1,98 @@
+"""Parity of the standalone HIP kernels (through the C-ABI) with NumPy/SciPy."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def sad():
+    from dolfin_navier_scipy_amd import saddle, _capi
+    assert _capi.device_count() > 0, 'HIP device required for -m gpu tests'
+    return saddle
+
+
+def _rand_csr(rng, nrows, ncols, density):
+    mat = sps.random(nrows, ncols, density=density, random_state=rng,
+                     format='csr', dtype=np.float64)
+    mat.data = rng.uniform(-1, 1, mat.nnz)
+    return mat
+
+
+@pytest.mark.parametrize('variant', ['vector', 'stream'])
+@pytest.mark.parametrize('shape,density', [((1, 1), 1.0), ((7, 5), 0.5),
+                                           ((300, 300), 0.02),
+                                           ((1000, 1300), 0.03),
+                                           ((257, 4000), 0.9),   # long rows
+                                           ((5000, 64), 0.001)])  # empty rows
+def test_spmv_random(sad, variant, shape, density):
+    rng = np.random.default_rng(shape[0]*7 + shape[1])
+    A = _rand_csr(rng, shape[0], shape[1], density)
+    x = rng.standard_normal(shape[1])
+    y = sad.spmv(A, x, variant=variant)
+    ref = A @ x
+    scale = np.abs(A).dot(np.abs(x)).max() + 1e-300
+    assert np.abs(y - ref).max() <= 1e-13*scale
+
+
+@pytest.mark.parametrize('variant', ['vector', 'stream'])
+def test_spmv_alpha_beta_and_fem_matrix(sad, variant, toy_prob):
+    rng = np.random.default_rng(1)
+    A = toy_prob['smc']['A']
+    x = rng.standard_normal(A.shape[1])
+    b = rng.standard_normal(A.shape[0])
+    y = sad.spmv(A, x, y=b, alpha=-0.5, beta=2.0, variant=variant)
+    ref = -0.5*(A @ x) + 2.0*b
+    assert np.abs(y - ref).max() <= 1e-13*np.abs(ref).max()
+
+
+def test_spmv_empty_matrix(sad):
+    A = sps.csr_matrix((10, 12))
+    for variant in ('vector', 'stream'):
+        y = sad.spmv(A, np.ones(12), variant=variant)
+        assert np.array_equal(y, np.zeros(10))
+
+
+def test_spmv_linearity_full_size(sad):
+    """size-independent property at the benchmark size (cylinder N=2)"""
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=80)
+    A = (sm['M'] + 1e-3*sm['A']).tocsr()
+    rng = np.random.default_rng(2)
+    x1, x2 = rng.standard_normal((2, A.shape[1]))
+    for variant in ('vector', 'stream'):
+        y1 = sad.spmv(A, x1, variant=variant)
+        y2 = sad.spmv(A, x2, variant=variant)
+        y12 = sad.spmv(A, 2*x1 - 3*x2, variant=variant)
+        assert np.abs(y12 - (2*y1 - 3*y2)).max() <= 1e-12*np.abs(y12).max()
+        assert np.abs(y1 - A @ x1).max() <= 1e-13*np.abs(y1).max()
+
+
+@pytest.mark.parametrize('n', [0, 1, 63, 64, 65, 1000, 100003])
+def test_dot_axpy(sad, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal((2, n)) if n else (np.zeros(0), np.zeros(0))
+    d = sad.dot(x, y)
+    assert abs(d - float(x @ y)) <= 1e-12*max(1.0, np.abs(x*y).sum())
+    z = sad.axpy(0.75, x, y)
+    assert np.allclose(z, y + 0.75*x, rtol=0, atol=1e-15*max(1, n))
+
+
+@pytest.mark.parametrize('n', [1, 5, 64, 130, 401])
+def test_gemv_and_dense_inverse(sad, n):
+    rng = np.random.default_rng(n)
+    B = rng.standard_normal((n, n))
+    A = B @ B.T + n*np.eye(n)
+    x = rng.standard_normal(n)
+    y = sad.gemv(A, x, alpha=-1.0)
+    assert np.abs(y + A @ x).max() <= 1e-12*np.abs(A @ x).max()
+    Ai = sad.dense_inverse(A)
+    assert np.abs(Ai @ A - np.eye(n)).max() <= 1e-10
+
+
+def test_dense_inverse_zero_pivot_raises(sad):
+    from dolfin_navier_scipy_amd import _capi
+    A = np.zeros((4, 4))
+    with pytest.raises(_capi.Breakdown):
+        sad.dense_inverse(A)

@@ -1,0 +1,221 @@
+"""Parity of the GPU saddle-point solve with the CPU oracle (direct solve) and
+with the NumPy model of the device algorithm (iteration counts)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import krylov_model as km
+from oracle import saddle_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def sad():
+    from dolfin_navier_scipy_amd import saddle, _capi
+    assert _capi.device_count() > 0, 'HIP device required for -m gpu tests'
+    return saddle
+
+
+@pytest.fixture(scope='module')
+def small(toy_prob):
+    M, A, J = (toy_prob['smc'][k] for k in 'MAJ')
+    dt = 5e-3
+    F = (M + .5*dt*A).tocsr()
+    rng = np.random.default_rng(11)
+    NP, NV = J.shape
+    rhsv = M @ rng.standard_normal(NV)
+    rhsp = 1e-3*rng.standard_normal(NP)
+    ref = saddle_oracle.solve_sadpnt_smw(amat=F, jmat=J, rhsv=rhsv,
+                                         rhsp=rhsp).reshape(-1)
+    return dict(F=F, J=J, M=M, A=A, rhsv=rhsv, rhsp=rhsp, ref=ref, dt=dt)
+
+
+def test_apply_K_and_bounds(sad, small):
+    F, J = small['F'], small['J']
+    system = sad.SaddleSystem(F, J)
+    K = km.saddle(F, J)
+    x = np.random.default_rng(0).standard_normal(K.shape[0])
+    y = system.apply(x)
+    assert np.abs(y - K @ x).max() <= 1e-13*np.abs(K @ x).max()
+    system.setup_precond(cheb_degree=3, schur='dense')
+    lo, hi = system.cheb_bounds()
+    mlo, mhi = km.power_bounds(F, 1/F.diagonal())
+    assert abs(hi - 1.05*mhi) <= 1e-6*mhi
+    assert abs(lo - 0.9*mlo) <= 1e-3*mlo
+    system.close()
+
+
+@pytest.mark.parametrize('degree', [1, 2, 4])
+def test_precond_matches_model(sad, small, degree):
+    F, J = small['F'], small['J']
+    system = sad.SaddleSystem(F, J)
+    system.setup_precond(cheb_degree=degree, schur='dense')
+    lo, hi = system.cheb_bounds()
+    cheb = km.ChebJacobi(F, degree=degree, lmin=lo, lmax=hi)
+    P = km.BlockTriPrecond(F, J, cheb=cheb)
+    r = np.random.default_rng(3).standard_normal(system.n)
+    z = system.apply_precond(r)
+    zm = P.apply(r)
+    assert np.linalg.norm(z - zm) <= 1e-8*np.linalg.norm(zm)
+    system.close()
+
+
+@pytest.mark.parametrize('method', ['gmres', 'bicgstab'])
+@pytest.mark.parametrize('schur', ['dense', 'jacobi'])
+def test_solve_matches_oracle(sad, small, method, schur):
+    system = sad.SaddleSystem(small['F'], small['J'])
+    system.setup_precond(cheb_degree=4, schur=schur)
+    x = system.solve(small['rhsv'], small['rhsp'], method=method, rtol=1e-12,
+                     maxiter=3000)
+    st = system.last_stats
+    assert st['status'] == 0
+    assert st['true_relres'] <= 5e-12
+    NV = small['F'].shape[0]
+    ref = small['ref']
+    assert np.linalg.norm(x[:NV] - ref[:NV]) <= 1e-9*np.linalg.norm(ref[:NV])
+    assert np.linalg.norm(x[NV:] - ref[NV:]) <= 1e-7*np.linalg.norm(ref[NV:])
+    hist = system.residual_history()
+    assert hist.size == st['iters'] + 1
+    assert hist[-1] <= 1e-12*st['bnorm']*1.0001
+    system.close()
+
+
+def test_gmres_iteration_count_matches_model(sad, small):
+    F, J = small['F'], small['J']
+    system = sad.SaddleSystem(F, J)
+    system.setup_precond(cheb_degree=3, schur='dense')
+    lo, hi = system.cheb_bounds()
+    b = np.concatenate([small['rhsv'], small['rhsp']])
+    x = system.solve(small['rhsv'], small['rhsp'], rtol=1e-10)
+    hist = system.residual_history()
+    P = km.BlockTriPrecond(F, J, cheb=km.ChebJacobi(F, degree=3, lmin=lo,
+                                                    lmax=hi))
+    xm, hm, its = km.gmres(km.saddle(F, J), b, P, rtol=1e-10)
+    assert abs(system.last_stats['iters'] - its) <= 1
+    k = min(hist.size, hm.size) - 2
+    assert np.allclose(hist[:k], hm[:k], rtol=1e-3)
+    assert np.linalg.norm(x - xm) <= 1e-8*np.linalg.norm(xm)
+    system.close()
+
+
+def test_restart_and_x0(sad, small):
+    system = sad.SaddleSystem(small['F'], small['J'])
+    system.setup_precond(cheb_degree=2, schur='jacobi')
+    x = system.solve(small['rhsv'], small['rhsp'], rtol=1e-11, restart=20,
+                     maxiter=4000)
+    st = system.last_stats
+    assert st['restarts'] >= 1 and st['true_relres'] <= 5e-11
+    ref = small['ref']
+    assert np.linalg.norm(x - ref) <= 1e-6*np.linalg.norm(ref)
+    # exact initial guess: zero iterations
+    x2 = system.solve(small['rhsv'], small['rhsp'], x0=x, rtol=1e-10)
+    assert system.last_stats['iters'] == 0
+    assert np.array_equal(x2, x)
+    system.close()
+
+
+def test_zero_rhs_and_no_rhsp(sad, small):
+    system = sad.SaddleSystem(small['F'], small['J'])
+    system.setup_precond(cheb_degree=3, schur='dense')
+    x = system.solve(np.zeros(system.NV))
+    assert np.array_equal(x, np.zeros(system.n))
+    x = system.solve(small['rhsv'], rtol=1e-12)      # rhsp omitted -> 0
+    ref = saddle_oracle.solve_sadpnt_smw(amat=small['F'], jmat=small['J'],
+                                         rhsv=small['rhsv']).reshape(-1)
+    assert np.linalg.norm(x - ref) <= 1e-8*np.linalg.norm(ref)
+    system.close()
+
+
+def test_not_converged_raises_and_not_ready(sad, small):
+    from dolfin_navier_scipy_amd import _capi
+    system = sad.SaddleSystem(small['F'], small['J'])
+    with pytest.raises(_capi.DnsError):
+        system.solve(small['rhsv'], small['rhsp'])
+    system.setup_precond(cheb_degree=1, schur='jacobi')
+    with pytest.raises(_capi.NotConverged):
+        system.solve(small['rhsv'], small['rhsp'], rtol=1e-14, maxiter=3)
+    system.close()
+
+
+def test_update_values_same_pattern(sad, small):
+    """Newton/Picard: F <- M + dt/2 (A + N), same pattern (snu:1034)"""
+    M, A, J = small['M'], small['A'], small['J']
+    dt = small['dt']
+    system = sad.SaddleSystem(small['F'], J)
+    system.setup_precond(cheb_degree=4, schur='dense')
+    rng = np.random.default_rng(4)
+    pert = A.copy()
+    pert.data = pert.data*(1 + 0.3*rng.standard_normal(pert.nnz))
+    F2 = (M + .5*dt*pert).tocsr()
+    assert np.array_equal(F2.indices, small['F'].indices)
+    system.update_values(F2.data)
+    x = system.solve(small['rhsv'], small['rhsp'], rtol=1e-12)
+    ref = saddle_oracle.solve_sadpnt_smw(amat=F2, jmat=J, rhsv=small['rhsv'],
+                                         rhsp=small['rhsp']).reshape(-1)
+    assert np.linalg.norm(x - ref) <= 1e-8*np.linalg.norm(ref)
+    system.close()
+
+
+def test_bad_arguments(sad, small):
+    from dolfin_navier_scipy_amd import _capi
+    F, J = small['F'], small['J']
+    with pytest.raises(_capi.DnsError):
+        sad.SaddleSystem(F, J[:, :-1])
+    bad = F.copy()
+    bad.indices = bad.indices.copy()
+    bad.indices[0] = F.shape[1] + 5
+    with pytest.raises(_capi.DnsError):
+        sad.SaddleSystem(bad, J)
+
+
+def test_lau_surface(small):
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    M, A, J = small['M'], small['A'], small['J']
+    NP, NV = J.shape
+    rng = np.random.default_rng(8)
+    rhsv = rng.standard_normal((NV, 2))
+    rhsp = 1e-2*rng.standard_normal((NP, 2))
+    amat = (M + 0.01*A).tocsr()
+    vp = lau.solve_sadpnt_smw(amat=amat, jmat=J, jmatT=J.T, rhsv=rhsv,
+                              rhsp=rhsp)
+    ref = saddle_oracle.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv,
+                                         rhsp=rhsp)
+    assert vp.shape == (NV+NP, 2)
+    assert np.linalg.norm(vp - ref) <= 1e-8*np.linalg.norm(ref)
+    # krylov kwargs, residual history sink, warm start
+    stats = []
+    vpk = lau.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv[:, :1],
+                               rhsp=rhsp[:, :1], krylov='Gmres',
+                               krpslvprms={'tol': 1e-6, 'maxiter': 200,
+                                           'convstatsl': stats,
+                                           'x0': ref[:, :1]})
+    assert len(stats) == 1 and len(stats[0]) == 1   # x0 exact: no iteration
+    assert np.linalg.norm(vpk - ref[:, :1]) <= 1e-5*np.linalg.norm(ref[:, 0])
+    # low-rank update (SMW)
+    U = 1e-3*rng.standard_normal((NV, 2))
+    V = rng.standard_normal((2, NV))
+    vps = lau.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv, rhsp=rhsp,
+                               umat=U, vmat=V)
+    refs = saddle_oracle.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv,
+                                          rhsp=rhsp, umat=U, vmat=V)
+    assert np.linalg.norm(vps - refs) <= 1e-7*np.linalg.norm(refs)
+    # return_alu
+    sol, fn = lau.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=0*rhsv[:, :1],
+                                   return_alu=True)
+    assert np.array_equal(sol, np.zeros((NV+NP, 1)))
+    got = fn(np.vstack([rhsv[:, :1], rhsp[:, :1]]))
+    assert got.shape == (NV+NP, 1)
+    assert np.linalg.norm(got - ref[:, :1]) <= 1e-8*np.linalg.norm(ref[:, 0])
+    # projector
+    f = rng.standard_normal((NV, 1))
+    pf = lau.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=f)
+    assert np.linalg.norm(J @ pf) <= 1e-8*np.linalg.norm(f)
+    ptf = lau.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=f, transposedprj=True)
+    pto = saddle_oracle.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=f,
+                                           transposedprj=True)
+    assert np.linalg.norm(ptf - pto) <= 1e-7*np.linalg.norm(pto)
+    with pytest.raises(NotImplementedError):
+        lau.solve_sadpnt_smw(jmat=J, rhsv=rhsv, decouplevp=True,
+                             symmetric=True, solve_A=lambda x: x)
+    lau.clear_cache()
