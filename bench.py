@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: CNAB time steps of the 2D cylinder wake.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path of `time_int_utils.cnab` (reference
+tiu:104-143) with everything resident in HBM: fused right-hand-side SpMV,
+block-preconditioned GMRES solve of `[[M + dt/2 A, J^T],[J, 0]]`, pressure
+rescale.  The convection history is frozen during the timed region (it is the
+host's FEniCS callback in the reference; SURVEY.md 8d: "convection excluded").
+
+Workload at N=1: Schaefer-Turek cylinder wake, mesh level N=2 (NV=9356,
+NP=1289), Re=100, dt=1/512, Taylor-Hood, CNAB -- the configuration
+BASELINE.json quotes the metric on.  For N>1 every rank runs an independent
+replica of that workload (weak scaling, no data-path collective): the
+row-partitioned solve over RCCL is not built yet (DESIGN.md, row e).
+
+The JSON line also carries
+  roofline     : CSR SpMV `y = K x` (the kernel family that dominates the
+                 step), HIP-event timed inside this script, at the benchmark
+                 size AND on a uniformly refined mesh that leaves the caches
+  cpu_baseline : the oracle's prefactored-SuperLU CNAB step (tiu:89-91,
+                 125-137 restated in oracle/) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def spmv_bytes(A):
+    """algorithmic bytes of y = A x"""
+    r, c = A.shape
+    return 12*A.nnz + 4*(r+1) + 8*c + 8*r
+
+
+def build_problem(N=2, Re=100., refine=0):
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=N, Re=Re,
+                                 refine=refine)
+    return femp, sm, rhsd
+
+
+def saddle_csr(F, J):
+    import scipy.sparse as sps
+    return sps.bmat([[F, J.T], [J, None]], format='csr')
+
+
+def initial_state(sm, rhsd, system_factory):
+    """start from the steady Stokes solution like `start_ssstokes=True`
+    (reference snu:903-907) -- computed here by the GPU path itself with a
+    generous Chebyshev degree (A alone is stiff)"""
+    A, J = sm['A'], sm['J']
+    NP, NV = J.shape
+    system = system_factory(A.tocsr(), J)
+    system.setup_precond(cheb_degree=24, schur='dense')
+    vp = system.solve(rhsd['fv'], rhsd['fp'], rtol=1e-9, maxiter=3000,
+                      raise_on_fail=False)
+    stats = dict(system.last_stats)
+    system.close()
+    return vp[:NV].reshape((-1, 1)), vp[NV:].reshape((-1, 1)), stats
+
+
+def cpu_baseline(sm, rhsd, v0, nfc, dt, budget_s=12.0, max_steps=4000):
+    """oracle leg: factor once (not timed, as the reference does once per
+    run), then time steps of rhs + 2 triangular solves + rescale"""
+    from oracle.saddle_oracle import SaddleLU
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    t0 = time.perf_counter()
+    klu = SaddleLU((M + .5*dt*A).tocsc(), J)
+    tfac = time.perf_counter() - t0
+    v = v0.copy()
+    fv, fp = rhsd['fv'], rhsd['fp']
+    nsteps = 0
+    t0 = time.perf_counter()
+    while nsteps < max_steps and time.perf_counter() - t0 < budget_s:
+        rhs = M @ v - .5*dt*(A @ v) + .5*dt*(3*nfc - nfc) + dt*fv
+        vp = klu(np.vstack([rhs, fp]).flatten())
+        v = vp[:NV].reshape((NV, 1))
+        p = -1./dt*vp[NV:].reshape((NP, 1))
+        nsteps += 1
+    el = time.perf_counter() - t0
+    return dict(value=nsteps/el, unit='timesteps/s', cores=1, kind='port',
+                sample='{0} CNAB steps (convection frozen) with the oracle: '
+                'SuperLU factor once ({1:.3f} s, untimed) + per-step rhs, '
+                '2 triangular solves, rescale'.format(nsteps, tfac)), v, p
+
+
+def roofline_spmv(saddle, Kmat, reps, label):
+    best = None
+    for variant in ('vector', 'stream'):
+        secs, chk = saddle.spmv_bench(Kmat, variant=variant, reps=reps,
+                                      warmup=5)
+        gbs = spmv_bytes(Kmat)/secs/1e9
+        rec = dict(kernel='k_spmv_{0}'.format(variant), achieved=gbs,
+                   avg_us=secs*1e6, bytes=spmv_bytes(Kmat), nnz=int(Kmat.nnz),
+                   rows=int(Kmat.shape[0]), matrix=label)
+        if best is None or gbs > best['achieved']:
+            best = rec
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=400)
+    ap.add_argument('--warmup', type=int, default=40)
+    ap.add_argument('--level', type=int, default=2, help='mesh level N')
+    ap.add_argument('--Re', type=float, default=100.)
+    ap.add_argument('--nts', type=int, default=512, help='dt = 1/nts')
+    ap.add_argument('--method', default='gmres')
+    ap.add_argument('--cheb', type=int, default=4)
+    ap.add_argument('--rtol', type=float, default=1e-10)
+    ap.add_argument('--check-every', type=int, default=4)
+    ap.add_argument('--roofline-refine', type=int, default=3,
+                    help='red refinements of the mesh for the HBM roofline '
+                    'SpMV (0 disables)')
+    ap.add_argument('--no-cpu', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl')
+    device = local_rank if world > 1 else 0
+
+    from dolfin_navier_scipy_amd import saddle, _capi
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    if _capi.device_count() <= device:
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+
+    dt = 1./args.nts
+    femp, sm, rhsd = build_problem(N=args.level, Re=args.Re)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    th, inv = femp['V'], femp['invinds']
+
+    def factory(F, Jm):
+        return saddle.SaddleSystem(F, Jm, device=device)
+
+    v0, pt0, st0 = initial_state(sm, rhsd, factory)
+    vfull = np.zeros((th.vdim, 1))
+    vfull[inv] = v0
+    vfull[femp['dbcinds'], 0] = femp['dbcvals']
+    nfc = -th.convection_vec(vfull)[inv, :]      # snu:1136-1140
+
+    F = (M + .5*dt*A).tocsr()
+    R1 = (M - .5*dt*A).tocsr()
+    t_setup = time.perf_counter()
+    system = factory(F, J)
+    system.setup_precond(cheb_degree=args.cheb, schur='dense')
+    _capi.device_synchronize(device)
+    t_setup = time.perf_counter() - t_setup
+    stepper = saddle.ImexStepper(system, R1)
+    stepper.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+    stepper.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
+                                   pscale=-1./dt, extrapolate=True)
+    opts = saddle.solve_opts(method=args.method, rtol=args.rtol, maxiter=400,
+                             restart=60, check_every=args.check_every)
+
+    def barrier():
+        _capi.device_synchronize(device)
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    stepper.run(args.warmup, cf, opts)
+    barrier()
+    t0 = time.perf_counter()
+    dev_s, iters, last = stepper.run(args.steps, cf, opts)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tw = torch.tensor([wall], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    v_gpu, p_gpu = stepper.get_state()
+
+    out = None
+    if rank == 0:
+        value = world*args.steps/wall
+        roof = roofline_spmv(saddle, saddle_csr(F, J), 200,
+                             'K at the benchmark size (cache resident)')
+        roof_hbm = None
+        if args.roofline_refine > 0:
+            _, smr, _ = build_problem(N=args.level, Re=args.Re,
+                                      refine=args.roofline_refine)
+            Kr = saddle_csr((smr['M'] + .5*dt*smr['A']).tocsr(), smr['J'])
+            roof_hbm = roofline_spmv(
+                saddle, Kr, 30, 'K on the mesh refined {0}x (n={1})'.format(
+                    args.roofline_refine, Kr.shape[0]))
+        main_roof = roof_hbm if roof_hbm is not None else roof
+        roofline = dict(bound='hbm', achieved=main_roof['achieved'],
+                        peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=main_roof['achieved']/HBM_PEAK_GBS, traffic=None,
+                        kernel=main_roof['kernel'], detail=main_roof,
+                        at_benchmark_size=roof)
+        cpu = None
+        parity = None
+        if not args.no_cpu:
+            cpu, v_cpu, p_cpu = cpu_baseline(
+                sm, rhsd, v0, nfc, dt,
+                max_steps=args.warmup + args.steps)
+            nsame = args.warmup + args.steps
+            if '{0} CNAB'.format(nsame) in cpu['sample']:
+                # same number of steps on both sides: compare the iterates
+                mn = lambda x: float(np.sqrt((x.T @ (M @ x)).item()))
+                parity = dict(
+                    v_rel_Mnorm=mn(v_gpu - v_cpu)/mn(v_cpu),
+                    p_rel_l2=float(np.linalg.norm(p_gpu - p_cpu)
+                                   / np.linalg.norm(p_cpu)))
+        out = dict(
+            metric='timesteps/sec, 2D cylinder wake Re={0:g} (CNAB step: rhs '
+                   'SpMV + preconditioned Krylov saddle solve + p rescale)'
+                   .format(args.Re),
+            value=value, unit='timesteps/s', n_gpus=world, steps=args.steps,
+            warmup=args.warmup, ms_per_step=1e3*wall/args.steps,
+            higher_is_better=True, scaling='weak', vs_baseline=None,
+            dtype='f64', data='synthetic',
+            config=dict(workload='cylinderwake N={0} Re={1:g} CNAB dt=1/{2} '
+                        'Taylor-Hood NV={3} NP={4}; convection history frozen'
+                        .format(args.level, args.Re, args.nts, NV, NP),
+                        parallelism='replicas' if world > 1 else 'single',
+                        method=args.method, cheb_degree=args.cheb,
+                        schur='dense', rtol=args.rtol,
+                        krylov_iters_per_step=iters/float(args.steps),
+                        true_relres_last=last['true_relres'],
+                        device_ms_per_step=1e3*dev_s/args.steps,
+                        precond_setup_s=t_setup,
+                        initial_stokes=st0,
+                        device=_capi.device_name(device)),
+            roofline=roofline, cpu_baseline=cpu, parity=parity)
+        print(json.dumps(out))
+    stepper.close()
+    system.close()
+    lau.clear_cache()
+    if dist is not None:
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == '__main__':
+    main()

@@ -86,6 +86,7 @@ SIGNATURES = {
     'dns_last_error': (ct.c_char_p, []),
     'dns_device_count': (ct.c_int, [ct.POINTER(ct.c_int)]),
     'dns_device_name': (ct.c_int, [ct.c_int, ct.c_char_p, ct.c_size_t]),
+    'dns_device_synchronize': (ct.c_int, [ct.c_int]),
     'dns_saddle_create': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr),
                                      ct.POINTER(dns_csr), ct.POINTER(dns_csr),
                                      ct.POINTER(_VP)]),
@@ -210,6 +211,10 @@ def device_count():
     except DnsError:
         return 0
     return n.value
+
+
+def device_synchronize(device=0):
+    check(load_library().dns_device_synchronize(device))
 
 
 def device_name(device=0):

@@ -663,6 +663,12 @@ int dns_device_name(int device, char *buf, size_t buflen) {
     return DNS_OK;
 }
 
+int dns_device_synchronize(int device) {
+    DNS_HIP(hipSetDevice(device));
+    DNS_HIP(hipDeviceSynchronize());
+    return DNS_OK;
+}
+
 void dns_default_precond_opts(dns_precond_opts *o) {
     o->cheb_degree = 4;
     o->schur = DNS_SCHUR_DENSE;

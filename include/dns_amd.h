@@ -95,6 +95,8 @@ const char *dns_status_string(int status);
 const char *dns_last_error(void);
 int         dns_device_count(int *count);
 int         dns_device_name(int device, char *buf, size_t buflen);
+/* block until all work queued on `device` has finished */
+int         dns_device_synchronize(int device);
 
 /* ---- saddle-point systems ---------------------------------------------
  * Replaces, per call site of `lau.solve_sadpnt_smw(amat=, jmat=, jmatT=,
