@@ -120,7 +120,9 @@ def main():
     ap.add_argument('--method', default='gmres')
     ap.add_argument('--cheb', type=int, default=4)
     ap.add_argument('--rtol', type=float, default=1e-10)
-    ap.add_argument('--check-every', type=int, default=4)
+    ap.add_argument('--check-every', type=int, default=2)
+    ap.add_argument('--eager', action='store_true',
+                    help='plain launches instead of hipGraph replay')
     ap.add_argument('--roofline-refine', type=int, default=3,
                     help='red refinements of the mesh for the HBM roofline '
                     'SpMV (0 disables)')
@@ -171,7 +173,8 @@ def main():
     cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
                                    pscale=-1./dt, extrapolate=True)
     opts = saddle.solve_opts(method=args.method, rtol=args.rtol, maxiter=400,
-                             restart=60, check_every=args.check_every)
+                             restart=60, check_every=args.check_every,
+                             use_graph=not args.eager)
 
     def barrier():
         _capi.device_synchronize(device)
@@ -240,6 +243,7 @@ def main():
                         parallelism='replicas' if world > 1 else 'single',
                         method=args.method, cheb_degree=args.cheb,
                         schur='dense', rtol=args.rtol,
+                        launch='eager' if args.eager else 'hipGraph',
                         krylov_iters_per_step=iters/float(args.steps),
                         true_relres_last=last['true_relres'],
                         device_ms_per_step=1e3*dev_s/args.steps,

@@ -75,6 +75,8 @@ k_bicg_start(int n, const double *__restrict__ r, double *__restrict__ rhat,
         ctl->total_it = 0;
         ctl->status = DNS_OK;
         ctl->done = !(beta > tol) ? 1 : 0;
+        ctl->conv = !(beta > tol) ? 1 : 0;
+        ctl->hist_len = 0;
         bc->sc[0].rho = bc->sc[0].alpha = bc->sc[0].omega = 1.0;
         bc->sc[1] = bc->sc[0];
         hist[0] = beta;

@@ -48,6 +48,7 @@ static void host_transpose(const dns_csr *a, std::vector<int> &rp,
 }  // namespace dns
 
 dns_saddle::~dns_saddle() {
+    drop_graphs();
     if (hdr_host) (void)hipHostFree(hdr_host);
     if (scal_host) (void)hipHostFree(scal_host);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -238,7 +239,8 @@ int dns_saddle::estimate_bounds() {
 }
 
 static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
-                      const int *jsel, const double *zp, double *zv) {
+                      const int *jsel, const double *zp, double *zv,
+                      const int *guard) {
     const int deg = h->popts.cheb_degree;
     const int gj = grid_for_rows(h->nv, h->JT.lpr);
     double *d0 = (deg == 1) ? zv : h->cheb_d0.p;
@@ -247,7 +249,7 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
                                       h->nv, h->JT.rowptr.p, h->JT.colidx.p,
                                       h->JT.vals.p, zp, rbase, ldr, jsel,
                                       h->dinv.p, 1.0 / h->theta, h->cheb_r.p,
-                                      d0, h->ctl.p));
+                                      d0, guard));
     const int gf = grid_for_rows(h->nv, h->F.lpr);
     double *dbuf[2] = {h->cheb_d0.p, h->cheb_d1.p};
     for (int s = 0; s < deg - 1; ++s) {
@@ -258,7 +260,7 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
                                h->F.rowptr.p, h->F.colidx.p, h->F.vals.p,
                                h->dinv.p, dbuf[s & 1], dbuf[(s + 1) & 1],
                                h->cheb_r.p, zv, h->c1[s], h->c2[s], first,
-                               last, h->ctl.p));
+                               last, guard));
         h->spmv_count++;
     }
     DNS_HIP(hipGetLastError());
@@ -266,18 +268,18 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
 }
 
 int dns_saddle::apply_precond(const double *rbase, size_t ldr, const int *jsel,
-                              double *zout) {
+                              double *zout, const int *guard) {
     double *zp = zout + nv;
     if (popts.schur == DNS_SCHUR_DENSE) {
         const int g = std::max(1, std::min((np + 3) / 4, 2048));
         hipLaunchKernelGGL(k_schur_dense, g, kBlock, 0, stream, np, sinv.p,
-                           rbase, ldr, jsel, nv, zp, ctl.p);
+                           rbase, ldr, jsel, nv, zp, guard);
     } else {
         hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(np), kBlock, 0,
                            stream, np, sinv.p, rbase, ldr, jsel, nv, zp,
-                           ctl.p);
+                           guard);
     }
-    return apply_fhat(this, rbase, ldr, jsel, zp, zout);
+    return apply_fhat(this, rbase, ldr, jsel, zp, zout, guard);
 }
 
 int dns_saddle::invert_dense(double *a, int nn) {
@@ -314,7 +316,7 @@ int dns_saddle::build_dense_schur() {
     for (int c = 0; c < np; ++c) {
         hipLaunchKernelGGL(k_set_unit, grid_for_elems(np), kBlock, 0, stream,
                            np, c, -1.0, zp);
-        DNS_TRY(apply_fhat(this, u.p, 0, zero_ptr(), zp, z.p));
+        DNS_TRY(apply_fhat(this, u.p, 0, zero_ptr(), zp, z.p, zero_ptr()));
         DNS_TRY(launch_spmv(J, z.p, sinv.p + (size_t)c * np, 1.0, 0.0, nullptr,
                             DNS_SPMV_VECTOR, stream));
     }
@@ -336,6 +338,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     if (popts.cheb_degree < 1 || popts.cheb_degree > 256)
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
+    drop_graphs();   // captured kernel arguments (coefficients, buffers)
     if (popts.eig_lo > 0.0 && popts.eig_hi > popts.eig_lo) {
         lam_lo = popts.eig_lo;
         lam_hi = popts.eig_hi;
@@ -374,7 +377,11 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
 
 int dns_saddle::ensure_workspace(int m) {
     const size_t need = (size_t)(m + 1) * ld;
-    if (V.n < need) DNS_TRY(V.alloc(need));
+    if (V.n < need) {
+        DNS_HIP(hipStreamSynchronize(stream));
+        drop_graphs();               // graphs hold the old buffer address
+        DNS_TRY(V.alloc(need));
+    }
     return DNS_OK;
 }
 
@@ -402,111 +409,168 @@ int dns_saddle::true_residual(const double *b, const double *x, double *out) {
     return DNS_OK;
 }
 
-int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
-                      dns_solve_stats *st) {
-    const int m = std::max(1, std::min(o->restart, kMaxRestart));
-    const int check = std::max(1, o->check_every);
-    DNS_TRY(ensure_workspace(m));
-    hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream, (int64_t)n, b,
-                       b, partB.p);
-    bool first = true;
-    int total = 0, restarts = 0;
-    history.clear();
-    while (true) {
+void dns_saddle::drop_graphs() {
+    for (auto &g : graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    graphs.clear();
+}
+
+// Run `body` (which only enqueues work on `stream`) either eagerly or as a
+// hipGraph captured on first use and replayed afterwards.  Launch-bound loops
+// of ~50 tiny kernels replay at the device's kernel-boundary rate instead of
+// the host's launch rate.
+template <typename Body>
+int dns_saddle::run_cached(const std::vector<uint64_t> &key, bool use_graph,
+                           Body body) {
+    if (!use_graph) return body();
+    for (auto &g : graphs)
+        if (g.key == key) {
+            DNS_HIP(hipGraphLaunch(g.exec, stream));
+            return DNS_OK;
+        }
+    GraphEntry ge;
+    ge.key = key;
+    DNS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    hipError_t e = hipStreamEndCapture(stream, &ge.graph);
+    if (rc != DNS_OK) {
+        if (ge.graph) (void)hipGraphDestroy(ge.graph);
+        return rc;
+    }
+    if (e != hipSuccess)
+        return fail(DNS_ERR_HIP, "hipStreamEndCapture: %s",
+                    hipGetErrorString(e));
+    DNS_HIP(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+    if (graphs.size() > 64) drop_graphs();
+    graphs.push_back(ge);
+    DNS_HIP(hipGraphLaunch(ge.exec, stream));
+    return DNS_OK;
+}
+
+static inline uint64_t bits_of(double v) {
+    uint64_t u;
+    memcpy(&u, &v, sizeof(u));
+    return u;
+}
+
+// One restart cycle of right-preconditioned GMRES with `c` Arnoldi steps:
+// residual, start, c x (precondition, K apply, Gram-Schmidt, close), then the
+// correction x += P^-1 (V y).  Kernels after convergence return at once
+// (ctl->done), so `c` may overshoot.  Nothing here synchronises or allocates.
+int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
+                              const dns_solve_opts *o) {
+    DNS_LPR_SWITCH(
+        K.lpr, hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream, n,
+                                  K.rowptr.p, K.colidx.p, K.vals.p, x, r.p,
+                                  -1.0, 1.0, b, partR.p,
+                                  (const DnsCtl *)nullptr));
+    hipLaunchKernelGGL(k_gmres_start, nred, kBlock, 0, stream, n, r.p, V.p,
+                       partR.p, nred, ctl.p, o->rtol, o->atol, partB.p,
+                       o->maxiter);
+    for (int it = 0; it < c; ++it) {
+        const int par = it & 1;
+        DNS_TRY(apply_precond(V.p, ld, jsel_ptr(par), z.p, done_ptr()));
         DNS_LPR_SWITCH(
-            K.lpr, hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream,
-                                      n, K.rowptr.p, K.colidx.p, K.vals.p, x,
-                                      r.p, -1.0, 1.0, b, partR.p,
-                                      (const DnsCtl *)nullptr));
-        spmv_count++;
-        hipLaunchKernelGGL(k_gmres_start, nred, kBlock, 0, stream, n, r.p,
-                           V.p, partR.p, nred, ctl.p, first ? 1 : 0, o->rtol,
-                           o->atol, partB.p);
-        first = false;
-        int it = 0;
-        bool done = false;
-        while (it < m && !done) {
-            const int chunk = std::min(check, m - it);
-            for (int c = 0; c < chunk; ++c, ++it) {
-                const int par = it & 1;
-                DNS_TRY(apply_precond(V.p, ld, jsel_ptr(par), z.p));
-                DNS_LPR_SWITCH(
-                    K.lpr,
-                    hipLaunchKernelGGL(k_spmv_guard<L>,
-                                       grid_for_rows(n, K.lpr), kBlock, 0,
-                                       stream, n, K.rowptr.p, K.colidx.p,
-                                       K.vals.p, z.p, w.p, ctl.p));
-                spmv_count++;
-                hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n, V.p,
-                                   ld, w.p, partA.p, nred, ctl.p, par);
-                hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream, n,
-                                   V.p, ld, w.p, partA.p, nred, ctl.p, par, 0,
-                                   o->reorth ? (double *)nullptr : partN.p);
-                if (o->reorth) {
-                    hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n,
-                                       V.p, ld, w.p, partA.p, nred, ctl.p,
-                                       par);
-                    hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream,
-                                       n, V.p, ld, w.p, partA.p, nred, ctl.p,
-                                       par, 1, partN.p);
-                }
-                hipLaunchKernelGGL(k_gmres_close, nred, kBlock, 0, stream, n,
-                                   w.p, V.p, ld, partN.p, nred, ctl.p, par, m,
-                                   o->maxiter);
+            K.lpr, hipLaunchKernelGGL(k_spmv_guard<L>, grid_for_rows(n, K.lpr),
+                                      kBlock, 0, stream, n, K.rowptr.p,
+                                      K.colidx.p, K.vals.p, z.p, w.p, ctl.p));
+        hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n, V.p, ld,
+                           w.p, partA.p, nred, ctl.p, par);
+        hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream, n, V.p, ld,
+                           w.p, partA.p, nred, ctl.p, par, 0,
+                           o->reorth ? (double *)nullptr : partN.p);
+        if (o->reorth) {
+            hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n, V.p, ld,
+                               w.p, partA.p, nred, ctl.p, par);
+            hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream, n, V.p,
+                               ld, w.p, partA.p, nred, ctl.p, par, 1,
+                               partN.p);
+        }
+        hipLaunchKernelGGL(k_gmres_close, nred, kBlock, 0, stream, n, w.p, V.p,
+                           ld, partN.p, nred, ctl.p, par, c, o->maxiter);
+    }
+    hipLaunchKernelGGL(k_gmres_finish_y, 1, 64, 0, stream, ctl.p, histdev.p,
+                       (int)hist_cap);
+    hipLaunchKernelGGL(k_basis_combine, nred, kBlock, 0, stream, n, V.p, ld,
+                       ctl.p, u.p);
+    DNS_TRY(apply_precond(u.p, 0, zero_ptr(), z.p, zero_ptr()));
+    hipLaunchKernelGGL(k_axpby, grid_for_elems(n), kBlock, 0, stream,
+                       (int64_t)n, 1.0, z.p, 1.0, x);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
+                      dns_solve_stats *st, const std::function<int()> &prologue,
+                      uint64_t prologue_key) {
+    const int m = std::max(1, std::min(o->restart, kMaxRestart));
+    DNS_TRY(ensure_workspace(m));
+    const size_t need_hist = (size_t)o->maxiter + 2 * kMaxRestart + 8;
+    if (histdev.n < need_hist) {
+        DNS_HIP(hipStreamSynchronize(stream));
+        drop_graphs();               // graphs hold the old buffer address
+        DNS_TRY(histdev.alloc(need_hist));
+    }
+    hist_cap = histdev.n;
+    const bool graph = o->use_graph != 0;
+    // first cycle length: what the previous solve needed plus slack (time
+    // stepping repeats itself), rounded to the polling granularity
+    const int gran = std::max(2, (o->check_every + 1) / 2 * 2);
+    int c = (last_iters >= 0) ? last_iters + 2 : std::min(m, 16);
+    c = std::min(m, std::max(gran, (c + gran - 1) / gran * gran));
+    int restarts = 0;
+    bool first = true;
+    while (true) {
+        std::vector<uint64_t> key = {
+            1u, (uint64_t)(uintptr_t)b, (uint64_t)(uintptr_t)x, (uint64_t)c,
+            (uint64_t)o->reorth, (uint64_t)o->maxiter, bits_of(o->rtol),
+            bits_of(o->atol), first ? prologue_key : 0u,
+            (uint64_t)popts.cheb_degree, (uint64_t)popts.schur,
+            (uint64_t)first};
+        DNS_TRY(run_cached(key, graph, [&]() -> int {
+            if (first) {
+                if (prologue) DNS_TRY(prologue());
+                // reset total_it, hist_len, conv, status for this solve
+                DNS_HIP(hipMemsetAsync(ctl.p, 0, sizeof(CtlHeader), stream));
+                hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream,
+                                   (int64_t)n, b, b, partB.p);
             }
-            DNS_HIP(hipGetLastError());
-            DNS_TRY(read_header());
-            done = hdr_host->done != 0;
-        }
-        // completed columns of this cycle
-        const int jcols = std::max(hdr_host->jv[0], hdr_host->jv[1]);
-        if (jcols > 0) {
-            // residual history of the cycle
-            std::vector<double> hh((size_t)jcols + 1);
-            DNS_HIP(hipMemcpyAsync(
-                hh.data(),
-                reinterpret_cast<const char *>(ctl.p) + offsetof(DnsCtl, hist),
-                hh.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-            hipLaunchKernelGGL(k_gmres_solve_y, 1, 64, 0, stream, ctl.p,
-                               jcols);
-            hipLaunchKernelGGL(k_basis_combine, nred, kBlock, 0, stream, n,
-                               V.p, ld, ctl.p, jcols, u.p);
-            // z = P^-1 u must not be skipped: lower the flag for the update
-            DNS_HIP(hipMemsetAsync(reinterpret_cast<char *>(ctl.p) +
-                                       offsetof(DnsCtl, done),
-                                   0, sizeof(int), stream));
-            DNS_TRY(apply_precond(u.p, 0, zero_ptr(), z.p));
-            hipLaunchKernelGGL(k_axpby, grid_for_elems(n), kBlock, 0, stream,
-                               (int64_t)n, 1.0, z.p, 1.0, x);
-            DNS_HIP(hipGetLastError());
-            DNS_HIP(hipStreamSynchronize(stream));
-            const size_t skip = history.empty() ? 0 : 1;
-            history.insert(history.end(), hh.begin() + skip, hh.end());
-        } else if (history.empty()) {
-            history.push_back(hdr_host->resnorm);
-        }
-        total = hdr_host->total_it;
-        st->bnorm = hdr_host->bnorm;
-        st->est_relres = hdr_host->bnorm > 0
-                             ? hdr_host->resnorm / hdr_host->bnorm
-                             : hdr_host->resnorm;
-        if (hdr_host->status != DNS_OK) {
-            st->status = hdr_host->status;
+            return enqueue_cycle(b, x, c, o);
+        }));
+        first = false;
+        DNS_TRY(read_header());
+        if (hdr_host->status != DNS_OK || hdr_host->conv ||
+            hdr_host->total_it >= o->maxiter || std::isnan(hdr_host->resnorm))
             break;
-        }
-        const bool conv = !(hdr_host->resnorm > hdr_host->tol);
-        if (conv) {
-            st->status = DNS_OK;
-            break;
-        }
-        if (total >= o->maxiter) {
-            st->status = DNS_NOT_CONVERGED;
-            break;
-        }
         restarts++;
+        c = std::min(m, std::max(c, 2 * gran));
+    }
+    const int total = hdr_host->total_it;
+    last_iters = total;
+    history.assign((size_t)std::max(1, hdr_host->hist_len), hdr_host->resnorm);
+    if (hdr_host->hist_len > 0) {
+        DNS_HIP(hipMemcpyAsync(history.data(), histdev.p,
+                               history.size() * sizeof(double),
+                               hipMemcpyDeviceToHost, stream));
+        DNS_HIP(hipStreamSynchronize(stream));
     }
     st->iters = total;
     st->restarts = restarts;
+    st->bnorm = hdr_host->bnorm;
+    st->est_relres = hdr_host->bnorm > 0 ? hdr_host->resnorm / hdr_host->bnorm
+                                         : hdr_host->resnorm;
+    if (hdr_host->status != DNS_OK)
+        st->status = hdr_host->status;
+    else if (hdr_host->conv)
+        st->status = DNS_OK;
+    else
+        st->status = DNS_NOT_CONVERGED;
+    // K applies + F applies: per iteration 1 + (deg-1); per cycle one residual
+    // and one correction
+    spmv_count += (int64_t)total * popts.cheb_degree +
+                  (int64_t)(restarts + 1) * (1 + popts.cheb_degree - 1);
     return DNS_OK;
 }
 
@@ -522,7 +586,11 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
         DNS_TRY(bi_t.alloc(ld));
         DNS_TRY(bi_y.alloc(ld));
     }
-    if (histdev.n < hcap) DNS_TRY(histdev.alloc(hcap));
+    if (histdev.n < hcap) {
+        DNS_HIP(hipStreamSynchronize(stream));
+        drop_graphs();
+        DNS_TRY(histdev.alloc(hcap));
+    }
     hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream, (int64_t)n, b,
                        b, partB.p);
     DNS_LPR_SWITCH(K.lpr,
@@ -548,7 +616,7 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
                                bctl.p, par, o->maxiter, histdev.p);
             hipLaunchKernelGGL(k_bicg_flag, 1, 64, 0, stream, ctl.p,
                                o->maxiter);
-            DNS_TRY(apply_precond(bi_p.p, 0, zero_ptr(), bi_y.p));
+            DNS_TRY(apply_precond(bi_p.p, 0, zero_ptr(), bi_y.p, done_ptr()));
             DNS_LPR_SWITCH(
                 K.lpr,
                 hipLaunchKernelGGL(k_spmv_dot2<L>, nred, kBlock, 0, stream, n,
@@ -557,7 +625,7 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
                                    1, partA.p, partA.p + nred, ctl.p));
             hipLaunchKernelGGL(k_bicg_s, nred, kBlock, 0, stream, n, r.p,
                                bi_v.p, bi_s.p, partA.p, nred, ctl.p, bctl.p);
-            DNS_TRY(apply_precond(bi_s.p, 0, zero_ptr(), z.p));
+            DNS_TRY(apply_precond(bi_s.p, 0, zero_ptr(), z.p, done_ptr()));
             DNS_LPR_SWITCH(
                 K.lpr,
                 hipLaunchKernelGGL(k_spmv_dot2<L>, nred, kBlock, 0, stream, n,
@@ -782,7 +850,8 @@ int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
     DNS_HIP(hipSetDevice(h->device));
     DNS_TRY(h->ctl.zero(h->stream));
     DNS_TRY(h->xdev.upload(r, (size_t)h->n, h->stream));
-    DNS_TRY(h->apply_precond(h->xdev.p, 0, h->zero_ptr(), h->z.p));
+    DNS_TRY(h->apply_precond(h->xdev.p, 0, h->zero_ptr(), h->z.p,
+                             h->zero_ptr()));
     DNS_TRY(h->z.download(z, (size_t)h->n, h->stream));
     DNS_HIP(hipStreamSynchronize(h->stream));
     return DNS_OK;

@@ -21,9 +21,10 @@ struct DnsCtl {
     int jv[2];
     int done;        // != 0: all later kernels of this solve return at once
     int status;      // DNS_OK / DNS_BREAKDOWN
-    int zero;        // constant 0 (vector selector for non-Arnoldi callers)
+    int zero;        // constant 0 (vector selector / never-raised guard)
     int total_it;
-    int pad0, pad1;
+    int hist_len;    // entries appended to the solve's residual history
+    int conv;        // 1 once ||r|| <= tol was observed
     double beta, tol, resnorm, bnorm;
     // BiCGStab scalars
     double rho, alpha, omega;
@@ -323,8 +324,8 @@ k_cheb_init(int nv, const int *__restrict__ rowptr,
             size_t ld, const int *__restrict__ jsel,
             const double *__restrict__ dinv, double inv_theta,
             double *__restrict__ r, double *__restrict__ d,
-            const DnsCtl *ctl) {
-    if (ctl->done) return;
+            const int *__restrict__ guard) {
+    if (*guard) return;
     const double *rv = rbase + (size_t)(*jsel) * ld;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
@@ -349,8 +350,8 @@ k_cheb_step(int nv, const int *__restrict__ rowptr,
             const double *__restrict__ dinv, const double *__restrict__ d_in,
             double *__restrict__ d_out, double *__restrict__ r,
             double *__restrict__ x, double c1, double c2, int first, int last,
-            const DnsCtl *ctl) {
-    if (ctl->done) return;
+            const int *__restrict__ guard) {
+    if (*guard) return;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
@@ -377,8 +378,8 @@ __global__ void __launch_bounds__(kBlock)
 k_schur_jacobi(int np, const double *__restrict__ sdinv,
                const double *__restrict__ rbase, size_t ld,
                const int *__restrict__ jsel, int nv, double *__restrict__ zp,
-               const DnsCtl *ctl) {
-    if (ctl->done) return;
+               const int *__restrict__ guard) {
+    if (*guard) return;
     const double *rp = rbase + (size_t)(*jsel) * ld + nv;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
          i += gridDim.x * kBlock)
@@ -390,8 +391,8 @@ __global__ void __launch_bounds__(kBlock)
 k_schur_dense(int np, const double *__restrict__ sinv,
               const double *__restrict__ rbase, size_t ld,
               const int *__restrict__ jsel, int nv, double *__restrict__ zp,
-              const DnsCtl *ctl) {
-    if (ctl->done) return;
+              const int *__restrict__ guard) {
+    if (*guard) return;
     const double *rp = rbase + (size_t)(*jsel) * ld + nv;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -451,27 +452,25 @@ k_spmv_guard(int nrows, const int *__restrict__ rowptr,
     }
 }
 
-// cycle start: beta = sqrt(sum partials); V[0] = r/beta; control block reset
+// cycle start: beta = sqrt(sum partials); V[0] = r/beta; per-cycle reset of
+// the control block.  Identical for every cycle of a solve (the host zeroes
+// `total_it/hist_len/conv/status` once before the first), so one captured
+// graph serves all cycles.
 __global__ void __launch_bounds__(kBlock)
 k_gmres_start(int n, const double *__restrict__ r, double *__restrict__ v0,
               const double *__restrict__ partials, int nparts, DnsCtl *ctl,
-              int first_cycle, double rtol, double atol,
-              const double *__restrict__ bnorm_partials) {
+              double rtol, double atol,
+              const double *__restrict__ bnorm_partials, int maxiter) {
     __shared__ double sc[2];
     reduce_partials(partials, nparts, nparts, 1, sc);
-    if (first_cycle) {
-        reduce_partials(bnorm_partials, nparts, nparts, 1, sc + 1);
-    }
+    reduce_partials(bnorm_partials, nparts, nparts, 1, sc + 1);
     const double beta = sqrt(sc[0]);
-    double tol;
-    if (first_cycle) {
-        const double bn = sqrt(sc[1]);
-        tol = fmax(rtol * bn, atol);
-    } else {
-        tol = ctl->tol;
-    }
+    const double bn = sqrt(sc[1]);
+    const double tol = fmax(rtol * bn, atol);
     const bool conv = !(beta > tol);
-    if (!conv) {
+    const bool stop = conv || isnan(beta) || ctl->total_it >= maxiter ||
+                      ctl->status != DNS_OK;
+    if (!stop) {
         const double ib = 1.0 / beta;
         for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
              i += gridDim.x * kBlock)
@@ -483,15 +482,12 @@ k_gmres_start(int n, const double *__restrict__ r, double *__restrict__ v0,
         ctl->zero = 0;
         ctl->beta = beta;
         ctl->resnorm = beta;
+        ctl->bnorm = bn;
+        ctl->tol = tol;
         ctl->g[0] = beta;
         ctl->hist[0] = beta;
-        if (first_cycle) {
-            ctl->bnorm = sqrt(sc[1]);
-            ctl->tol = tol;
-            ctl->total_it = 0;
-            ctl->status = DNS_OK;
-        }
-        ctl->done = conv ? 1 : 0;
+        if (conv) ctl->conv = 1;
+        ctl->done = stop ? 1 : 0;
     }
 }
 
@@ -610,6 +606,7 @@ k_gmres_close(int n, const double *__restrict__ w, double *__restrict__ V,
         ctl->total_it += 1;
         const bool conv = !(res > ctl->tol);
         if (status != DNS_OK) ctl->status = status;
+        if (conv) ctl->conv = 1;
         if (conv || status != DNS_OK || !(hn > 0.0) || isnan(res) ||
             ctl->total_it >= maxiter)
             ctl->done = 1;
@@ -617,9 +614,12 @@ k_gmres_close(int n, const double *__restrict__ w, double *__restrict__ V,
     }
 }
 
-// y = R^-1 g for the `jcols` completed columns (single thread; tiny)
-__global__ void k_gmres_solve_y(DnsCtl *ctl, int jcols) {
+// end of a cycle (single thread): y = R^-1 g for the completed columns and
+// the cycle's residual norms appended to the solve's history
+__global__ void k_gmres_finish_y(DnsCtl *ctl, double *__restrict__ histbuf,
+                                 int hist_cap) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int jcols = max(ctl->jv[0], ctl->jv[1]);
     for (int i = jcols - 1; i >= 0; --i) {
         double s = ctl->g[i];
         for (int k = i + 1; k < jcols; ++k)
@@ -627,13 +627,18 @@ __global__ void k_gmres_solve_y(DnsCtl *ctl, int jcols) {
         const double d = ctl->R[(size_t)i * (kMaxRestart + 1) + i];
         ctl->y[i] = (d != 0.0) ? s / d : 0.0;
     }
+    int hl = ctl->hist_len;
+    for (int i = (hl > 0 ? 1 : 0); i <= jcols && hl < hist_cap; ++i)
+        histbuf[hl++] = ctl->hist[i];
+    ctl->hist_len = hl;
 }
 
-// u = sum_{i<jcols} y_i V_i
+// u = sum_{i<jcols} y_i V_i   (jcols read from the control block)
 __global__ void __launch_bounds__(kBlock)
 k_basis_combine(int n, const double *__restrict__ V, size_t ld,
-                const DnsCtl *ctl, int jcols, double *__restrict__ u) {
+                const DnsCtl *ctl, double *__restrict__ u) {
     __shared__ double y[kMaxRestart];
+    const int jcols = max(ctl->jv[0], ctl->jv[1]);
     if (threadIdx.x < jcols) y[threadIdx.x] = ctl->y[threadIdx.x];
     __syncthreads();
     for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;

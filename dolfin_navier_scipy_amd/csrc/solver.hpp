@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <functional>
 
 #include "bicgstab_kernels.hpp"
 #include "kernels.hpp"
@@ -105,8 +106,15 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
 
 struct CtlHeader {   // leading part of DnsCtl, copied back to the host
     int jv[2];
-    int done, status, zero, total_it, pad0, pad1;
+    int done, status, zero, total_it, hist_len, conv;
     double beta, tol, resnorm, bnorm;
+};
+
+// a captured chunk of work, replayed with hipGraphLaunch
+struct GraphEntry {
+    std::vector<uint64_t> key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 }  // namespace dns
@@ -139,6 +147,18 @@ struct dns_saddle {
     double *scal_host = nullptr;          // pinned
     std::vector<double> history;
     int64_t spmv_count = 0;
+    int last_iters = -1;              // iteration count of the previous solve
+    size_t hist_cap = 0;
+    std::vector<dns::GraphEntry> graphs;
+    typedef int (*enqueue_fn)(void *ctx);
+    // enqueue one GMRES cycle of `c` iterations (capturable: no sync inside)
+    int enqueue_cycle(const double *b, double *x, int c,
+                      const dns_solve_opts *o);
+    // run `body` eagerly or as a cached graph identified by `key`
+    template <typename Body>
+    int run_cached(const std::vector<uint64_t> &key, bool use_graph,
+                   Body body);
+    void drop_graphs();
 
     ~dns_saddle();
     int init(int dev, const dns_csr *f, const dns_csr *j, const dns_csr *jt);
@@ -151,13 +171,17 @@ struct dns_saddle {
     int ensure_workspace(int m);
     // z = P^-1 (vector `*jsel` of rbase); all device pointers
     int apply_precond(const double *rbase, size_t ldr, const int *jsel,
-                      double *zout);
+                      double *zout, const int *guard);
     int dot_host(int64_t len, const double *x, const double *y, double *out);
     int read_header();
     int solve_device(const double *b, double *x, const dns_solve_opts *o,
                      dns_solve_stats *st);
+    // `prologue` enqueues caller work (e.g. the IMEX right-hand side) in front
+    // of the first cycle so that it is captured into the same graph
     int gmres(const double *b, double *x, const dns_solve_opts *o,
-              dns_solve_stats *st);
+              dns_solve_stats *st,
+              const std::function<int()> &prologue = nullptr,
+              uint64_t prologue_key = 0);
     int bicgstab(const double *b, double *x, const dns_solve_opts *o,
                  dns_solve_stats *st);
     int true_residual(const double *b, const double *x, double *out);
@@ -165,6 +189,10 @@ struct dns_saddle {
         return reinterpret_cast<const int *>(
             reinterpret_cast<const char *>(ctl.p) +
             offsetof(dns::DnsCtl, jv) + sizeof(int) * par);
+    }
+    const int *done_ptr() const {
+        return reinterpret_cast<const int *>(
+            reinterpret_cast<const char *>(ctl.p) + offsetof(dns::DnsCtl, done));
     }
     const int *zero_ptr() const {
         return reinterpret_cast<const int *>(

@@ -29,7 +29,7 @@ __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 # solver settings of the time loops; `rtol` is relative to ||rhs||
 SOLVER = dict(method='gmres', rtol=1e-12, maxiter=400, restart=60,
               cheb_degree=4, schur='auto', extrapolate=True, device=0,
-              check_every=4)
+              check_every=2, use_graph=True)
 
 
 def _checkuniformgrid(trange):
@@ -88,7 +88,8 @@ def _device_system(fmat, J, prm):
     system.setup_precond(cheb_degree=prm['cheb_degree'], schur=schur)
     opts = solve_opts(method=prm['method'], rtol=prm['rtol'],
                       maxiter=prm['maxiter'], restart=prm['restart'],
-                      check_every=prm['check_every'])
+                      check_every=prm['check_every'],
+                      use_graph=prm['use_graph'])
     return system, opts
 
 

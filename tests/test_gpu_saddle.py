@@ -61,13 +61,18 @@ def test_precond_matches_model(sad, small, degree):
     system.close()
 
 
-@pytest.mark.parametrize('method', ['gmres', 'bicgstab'])
+@pytest.mark.parametrize('method,graph', [('gmres', False), ('gmres', True),
+                                          ('bicgstab', False)])
 @pytest.mark.parametrize('schur', ['dense', 'jacobi'])
-def test_solve_matches_oracle(sad, small, method, schur):
+def test_solve_matches_oracle(sad, small, method, graph, schur):
     system = sad.SaddleSystem(small['F'], small['J'])
     system.setup_precond(cheb_degree=4, schur=schur)
     x = system.solve(small['rhsv'], small['rhsp'], method=method, rtol=1e-12,
-                     maxiter=3000)
+                     maxiter=3000, use_graph=graph)
+    if graph:   # replay of the cached graphs must give the same answer
+        x2 = system.solve(small['rhsv'], small['rhsp'], method=method,
+                          rtol=1e-12, maxiter=3000, use_graph=True)
+        assert np.linalg.norm(x2 - x) <= 1e-10*np.linalg.norm(x)
     st = system.last_stats
     assert st['status'] == 0
     assert st['true_relres'] <= 5e-12
