@@ -120,6 +120,15 @@ def main():
     ap.add_argument('--method', default='gmres')
     ap.add_argument('--cheb', type=int, default=4)
     ap.add_argument('--rtol', type=float, default=1e-10)
+    ap.add_argument('--fp32', type=int, default=1,
+                    help='store the explicit preconditioner matrices in fp32')
+    ap.add_argument('--drop', type=float, default=3e-3,
+                    help='relative drop tolerance of the explicit polynomial')
+    ap.add_argument('--reorth', type=int, default=1,
+                    help='1: Gram-Schmidt applied twice (CGS2), 0: once')
+    ap.add_argument('--fhat', default='auto',
+                    help="F^-1 approximation: 'cheb' recurrence, 'explicit' "
+                    "polynomial matrix, 'auto'")
     ap.add_argument('--check-every', type=int, default=2)
     ap.add_argument('--eager', action='store_true',
                     help='plain launches instead of hipGraph replay')
@@ -164,7 +173,8 @@ def main():
     R1 = (M - .5*dt*A).tocsr()
     t_setup = time.perf_counter()
     system = factory(F, J)
-    system.setup_precond(cheb_degree=args.cheb, schur='dense')
+    system.setup_precond(cheb_degree=args.cheb, schur='dense', fhat=args.fhat,
+                         fp32_store=bool(args.fp32), drop_tol=args.drop)
     _capi.device_synchronize(device)
     t_setup = time.perf_counter() - t_setup
     stepper = saddle.ImexStepper(system, R1)
@@ -174,7 +184,8 @@ def main():
                                    pscale=-1./dt, extrapolate=True)
     opts = saddle.solve_opts(method=args.method, rtol=args.rtol, maxiter=400,
                              restart=60, check_every=args.check_every,
-                             use_graph=not args.eager)
+                             use_graph=not args.eager,
+                             reorth=bool(args.reorth))
 
     def barrier():
         _capi.device_synchronize(device)

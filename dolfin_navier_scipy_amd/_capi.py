@@ -19,6 +19,7 @@ DNS_ERR_HIP, DNS_ERR_BAD_ARGUMENT, DNS_ERR_NOT_READY, DNS_ERR_COMM = 3, 4, 5, 6
 DNS_METHOD_GMRES, DNS_METHOD_BICGSTAB = 0, 1
 DNS_SCHUR_DENSE, DNS_SCHUR_JACOBI = 0, 1
 DNS_SPMV_VECTOR, DNS_SPMV_STREAM = 0, 1
+DNS_FHAT_CHEB, DNS_FHAT_EXPLICIT, DNS_FHAT_AUTO = 0, 1, 2
 
 
 class DnsError(RuntimeError):
@@ -50,8 +51,10 @@ class dns_csr(ct.Structure):
 
 class dns_precond_opts(ct.Structure):
     _fields_ = [('cheb_degree', ct.c_int32), ('schur', ct.c_int32),
+                ('fhat', ct.c_int32), ('fp32_store', ct.c_int32),
                 ('eig_lo_safety', ct.c_double), ('eig_hi_safety', ct.c_double),
-                ('eig_lo', ct.c_double), ('eig_hi', ct.c_double)]
+                ('eig_lo', ct.c_double), ('eig_hi', ct.c_double),
+                ('drop_tol', ct.c_double)]
 
 
 class dns_solve_opts(ct.Structure):

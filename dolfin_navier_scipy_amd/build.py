@@ -9,6 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['dns_amd.hip']
 HEADERS = ['common.hpp', 'kernels.hpp', 'bicgstab_kernels.hpp', 'solver.hpp',
+           'hostcsr.hpp', 'gmres_kernels.hpp',
            'imex.hpp', 'imex_capi.inc',
            os.path.join('..', '..', 'include', 'dns_amd.h')]
 LIB = os.path.join(CSRC, 'libdnsamd.so')

@@ -66,7 +66,7 @@ k_bicg_start(int n, const double *__restrict__ r, double *__restrict__ rhat,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const double beta = sqrt(sc[0]), bn = sqrt(sc[1]);
         const double tol = fmax(rtol * bn, atol);
-        ctl->jv[0] = ctl->jv[1] = 0;
+        ctl->jdone = 0;
         ctl->zero = 0;
         ctl->beta = beta;
         ctl->resnorm = beta;

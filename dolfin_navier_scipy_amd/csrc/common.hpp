@@ -98,8 +98,11 @@ struct CsrDev {
 };
 
 inline int pick_lpr(double avg_nnz_per_row) {
+    // smallest power of two that covers an average row in ONE pass of the
+    // sub-wave: the reference-size systems are latency bound and every extra
+    // pass is another dependent (col,val) -> x[col] round trip
     int lpr = 2;
-    while (lpr < 64 && lpr * 2 <= avg_nnz_per_row) lpr *= 2;
+    while (lpr < 64 && lpr < avg_nnz_per_row) lpr *= 2;
     return lpr;
 }
 

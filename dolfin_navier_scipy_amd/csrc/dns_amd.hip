@@ -99,6 +99,9 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     DNS_TRY(F.upload(f, stream));
     DNS_TRY(J.upload(j, stream));
     DNS_TRY(JT.upload(&jth, stream));
+    Fh = host_copy(f);
+    Jh = host_copy(j);
+    JTh = host_copy(&jth);
     // assembled K = [[F, JT], [J, 0]]
     {
         std::vector<int> krp((size_t)n + 1), kci;
@@ -155,11 +158,19 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     DNS_TRY(r.alloc(ld));
     DNS_TRY(xdev.alloc(ld));
     DNS_TRY(bdev.alloc(ld));
-    DNS_TRY(partA.alloc((size_t)(kMaxRestart + 1) * nred));
-    DNS_TRY(partN.alloc((size_t)nred));
-    DNS_TRY(partR.alloc((size_t)nred));
-    DNS_TRY(partB.alloc((size_t)nred));
-    DNS_TRY(partC.alloc((size_t)nred));
+    // GMRES grids: SpMV-shaped kernels (one partial per workgroup, summed by
+    // the consumer) stay at <= 512 workgroups; vector kernels use one thread
+    // per entry up to 1024 workgroups
+    gridS = gridC = std::max(1, std::min(grid_for_rows(n, K.lpr), 2048));
+    gridD = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock,
+                                                       1024));
+    const size_t pmax = (size_t)std::max(std::max(gridS, gridD), nred);
+    DNS_TRY(partA.alloc((size_t)(kMaxRestart + 1) * pmax));
+    DNS_TRY(partE.alloc((size_t)(kMaxRestart + 1) * pmax));
+    DNS_TRY(partN.alloc(pmax));
+    DNS_TRY(partR.alloc(pmax));
+    DNS_TRY(partB.alloc(pmax));
+    DNS_TRY(partC.alloc(pmax));
     DNS_TRY(u.zero(stream));
     DNS_HIP(hipStreamSynchronize(stream));
     dns_default_precond_opts(&popts);
@@ -168,6 +179,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
 
 int dns_saddle::update_values(const double *fvals) {
     DNS_HIP(hipSetDevice(device));
+    Fh.vals.assign(fvals, fvals + F.nnz);
     DNS_TRY(F.vals.upload(fvals, (size_t)F.nnz, stream));
     hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
                        stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p, K.vals.p);
@@ -267,19 +279,119 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
     return DNS_OK;
 }
 
-int dns_saddle::apply_precond(const double *rbase, size_t ldr, const int *jsel,
-                              double *zout, const int *guard) {
+// velocity part of the preconditioner:  zv = Fh^-1 (rv - JT zp)
+// (`xacc`: also x_v += zv, the fused correction at the end of a cycle)
+int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
+                                double *zv, const int *guard, double *xacc) {
+    if (fhat_explicit) {
+        const int g = grid_for_rows(nv, Gc.lpr);
+        if (fp32_store) {
+            DNS_LPR_SWITCH(
+                Gc.lpr,
+                hipLaunchKernelGGL((k_spmv_split<L, float>), g, kBlock, 0,
+                                   stream, nv, Gc.rowptr.p, Gc.colidx.p,
+                                   gc32.p, rvec, (size_t)0, zero_ptr(), zp, zv,
+                                   guard, xacc));
+        } else {
+            DNS_LPR_SWITCH(
+                Gc.lpr,
+                hipLaunchKernelGGL((k_spmv_split<L, double>), g, kBlock, 0,
+                                   stream, nv, Gc.rowptr.p, Gc.colidx.p,
+                                   Gc.vals.p, rvec, (size_t)0, zero_ptr(), zp,
+                                   zv, guard, xacc));
+        }
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
+    }
+    DNS_TRY(apply_fhat(this, rvec, 0, zero_ptr(), zp, zv, guard));
+    if (xacc) {
+        hipLaunchKernelGGL(k_axpby, grid_for_elems(nv), kBlock, 0, stream,
+                           (int64_t)nv, 1.0, zv, 1.0, xacc);
+        DNS_HIP(hipGetLastError());
+    }
+    return DNS_OK;
+}
+
+// z = P^-1 r for one n-vector r (device pointers); xacc != null: x += z
+int dns_saddle::apply_precond(const double *rvec, double *zout,
+                              const int *guard, double *xacc) {
     double *zp = zout + nv;
+    double *xp = xacc ? xacc + nv : nullptr;
     if (popts.schur == DNS_SCHUR_DENSE) {
-        const int g = std::max(1, std::min((np + 3) / 4, 2048));
-        hipLaunchKernelGGL(k_schur_dense, g, kBlock, 0, stream, np, sinv.p,
-                           rbase, ldr, jsel, nv, zp, guard);
+        const int g = std::max(1, std::min(np, 2048));
+        if (fp32_store)
+            hipLaunchKernelGGL(k_schur_dense<float>, g, kBlock, 0, stream, np,
+                               sinv32.p, rvec, (size_t)0, zero_ptr(), nv, zp,
+                               guard, xp);
+        else
+            hipLaunchKernelGGL(k_schur_dense<double>, g, kBlock, 0, stream, np,
+                               sinv.p, rvec, (size_t)0, zero_ptr(), nv, zp,
+                               guard, xp);
     } else {
         hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(np), kBlock, 0,
-                           stream, np, sinv.p, rbase, ldr, jsel, nv, zp,
-                           guard);
+                           stream, np, sinv.p, rvec, (size_t)0, zero_ptr(), nv,
+                           zp, guard, xp);
     }
-    return apply_fhat(this, rbase, ldr, jsel, zp, zout, guard);
+    return apply_fhat_part(rvec, zp, zout, guard, xacc);
+}
+
+int dns_saddle::to_f32(const double *in, DevBuf<float> &out, size_t count) {
+    DNS_TRY(out.alloc(count));
+    hipLaunchKernelGGL(k_to_f32, grid_for_elems((int64_t)count), kBlock, 0,
+                       stream, (int64_t)count, in, out.p);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+// Explicit polynomial approximate inverse, formed on the host at set-up:
+//   G = p(D^-1 F) D^-1 with p the degree-(k-1) Chebyshev polynomial of
+//   k_cheb_init/k_cheb_step (so G b == the recurrence applied to b),
+//   Gc = [G, -G JT],  S = J G JT (dense Schur complement of the SAME Fh).
+int dns_saddle::build_explicit(bool dense_schur) {
+    std::vector<double> dv((size_t)nv, 1.0);
+    for (int i = 0; i < nv; ++i) {
+        double d = 0.0;
+        for (int k = Fh.rowptr[i]; k < Fh.rowptr[i + 1]; ++k)
+            if (Fh.colidx[k] == i) d += Fh.vals[k];
+        dv[i] = (d != 0.0) ? 1.0 / d : 1.0;
+    }
+    HostCsr DF = Fh;
+    host_scale_rows(dv, DF);
+    HostCsr R = host_diag(dv);
+    HostCsr Dm = R;
+    for (auto &v : Dm.vals) v /= theta;
+    HostCsr X;
+    X.nrows = X.ncols = nv;
+    X.rowptr.assign((size_t)nv + 1, 0);
+    for (size_t s = 0; s < c1.size(); ++s) {
+        X = host_add(1.0, X, 1.0, Dm);
+        R = host_add(1.0, R, -1.0, host_spgemm(DF, Dm));
+        Dm = host_add(c1[s], Dm, c2[s], R);
+    }
+    HostCsr G = host_add(1.0, X, 1.0, Dm);
+    // the polynomial's entries decay quickly away from the diagonal: drop what
+    // is below drop_tol * (row maximum); S below is built from the SAME
+    // dropped G, so P stays an exact block factorisation of its own [[Fh,JT],..]
+    if (popts.drop_tol > 0.0) host_drop_small(G, popts.drop_tol);
+    HostCsr GJT = host_spgemm(G, JTh);
+    HostCsr negGJT = GJT;
+    for (auto &v : negGJT.vals) v = -v;
+    HostCsr Gch = host_hstack(G, negGJT);
+    dns_csr gv = Gch.view();
+    DNS_TRY(Gc.upload(&gv, stream));
+    if (fp32_store) DNS_TRY(to_f32(Gc.vals.p, gc32, (size_t)Gc.nnz));
+    if (dense_schur) {
+        HostCsr S = host_spgemm(Jh, GJT);
+        std::vector<double> sd((size_t)np * np, 0.0);
+        for (int i = 0; i < np; ++i)
+            for (int k = S.rowptr[i]; k < S.rowptr[i + 1]; ++k)
+                sd[(size_t)i * np + S.colidx[k]] = S.vals[k];
+        DNS_TRY(sinv.alloc((size_t)np * np));
+        DNS_TRY(sinv.upload(sd.data(), sd.size(), stream));
+        DNS_HIP(hipStreamSynchronize(stream));
+        DNS_TRY(invert_dense(sinv.p, np));
+    }
+    return DNS_OK;
 }
 
 int dns_saddle::invert_dense(double *a, int nn) {
@@ -359,11 +471,27 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
             rho = rho_new;
         }
     }
-    if (popts.schur == DNS_SCHUR_DENSE) {
-        if ((int64_t)np * np * 8 > (int64_t)64 << 30)
-            return fail(DNS_ERR_BAD_ARGUMENT,
-                        "dense Schur inverse too large for NP=%d", np);
+    if (popts.schur != DNS_SCHUR_DENSE && popts.schur != DNS_SCHUR_JACOBI)
+        return fail(DNS_ERR_BAD_ARGUMENT, "unknown Schur option %d",
+                    popts.schur);
+    if (popts.schur == DNS_SCHUR_DENSE &&
+        (int64_t)np * np * 8 > (int64_t)64 << 30)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "dense Schur inverse too large for NP=%d", np);
+    // explicit polynomial matrix: worth it while the apply is launch-latency
+    // bound (pattern of F^(k-1): more bytes, far fewer dependent launches)
+    fhat_explicit = (popts.fhat == DNS_FHAT_EXPLICIT) ||
+                    (popts.fhat == DNS_FHAT_AUTO && nv <= 200000 &&
+                     popts.cheb_degree >= 2 && popts.cheb_degree <= 6);
+    fp32_store = popts.fp32_store != 0;
+    if (fhat_explicit) {
+        DNS_TRY(build_explicit(popts.schur == DNS_SCHUR_DENSE));
+        if (popts.schur == DNS_SCHUR_JACOBI) DNS_TRY(build_jacobi_schur());
+        if (fp32_store && popts.schur == DNS_SCHUR_DENSE)
+            DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
+    } else if (popts.schur == DNS_SCHUR_DENSE) {
         DNS_TRY(build_dense_schur());
+        if (fp32_store) DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
     } else if (popts.schur == DNS_SCHUR_JACOBI) {
         DNS_TRY(build_jacobi_schur());
     } else {
@@ -394,11 +522,10 @@ int dns_saddle::read_header() {
 
 int dns_saddle::true_residual(const double *b, const double *x, double *out) {
     DNS_LPR_SWITCH(K.lpr,
-                   hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream,
+                   hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x,
-                                      r.p, -1.0, 1.0, b, partR.p,
-                                      (const DnsCtl *)nullptr));
-    hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, nred,
+                                      b, r.p, partR.p, (double *)nullptr));
+    hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, gridS,
                        scal.p);
     DNS_HIP(hipGetLastError());
     DNS_HIP(hipMemcpyAsync(scal_host, scal.p, sizeof(double),
@@ -461,43 +588,70 @@ static inline uint64_t bits_of(double v) {
 // (ctl->done), so `c` may overshoot.  Nothing here synchronises or allocates.
 int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                               const dns_solve_opts *o) {
+    // r = b - K x, ||r||^2, ||b||^2
     DNS_LPR_SWITCH(
-        K.lpr, hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream, n,
-                                  K.rowptr.p, K.colidx.p, K.vals.p, x, r.p,
-                                  -1.0, 1.0, b, partR.p,
-                                  (const DnsCtl *)nullptr));
-    hipLaunchKernelGGL(k_gmres_start, nred, kBlock, 0, stream, n, r.p, V.p,
-                       partR.p, nred, ctl.p, o->rtol, o->atol, partB.p,
-                       o->maxiter);
-    for (int it = 0; it < c; ++it) {
-        const int par = it & 1;
-        DNS_TRY(apply_precond(V.p, ld, jsel_ptr(par), z.p, done_ptr()));
-        DNS_LPR_SWITCH(
-            K.lpr, hipLaunchKernelGGL(k_spmv_guard<L>, grid_for_rows(n, K.lpr),
-                                      kBlock, 0, stream, n, K.rowptr.p,
-                                      K.colidx.p, K.vals.p, z.p, w.p, ctl.p));
-        hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n, V.p, ld,
-                           w.p, partA.p, nred, ctl.p, par);
-        hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream, n, V.p, ld,
-                           w.p, partA.p, nred, ctl.p, par, 0,
-                           o->reorth ? (double *)nullptr : partN.p);
-        if (o->reorth) {
-            hipLaunchKernelGGL(k_multidot, nred, kBlock, 0, stream, n, V.p, ld,
-                               w.p, partA.p, nred, ctl.p, par);
-            hipLaunchKernelGGL(k_orth_update, nred, kBlock, 0, stream, n, V.p,
-                               ld, w.p, partA.p, nred, ctl.p, par, 1,
-                               partN.p);
+        K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream, n,
+                                  K.rowptr.p, K.colidx.p, K.vals.p, x, b, r.p,
+                                  partR.p, partB.p));
+    const bool dense = popts.schur == DNS_SCHUR_DENSE;
+    // workgroups of the head kernel: one wavefront per Schur row
+    const int gridA = dense ? std::max(gridD, std::min(np, 2048)) : gridD;
+    double *zp = z.p + nv;
+    for (int j = 0; j < c; ++j) {
+        const double *src = (j == 0) ? r.p : w.p;
+        const double *spart = (j == 0) ? partR.p : partN.p;
+        const int snp = (j == 0) ? gridS : gridD;
+        if (dense && fp32_store)
+            hipLaunchKernelGGL(k_arn_head<2>, gridA, kBlock, 0, stream, n, nv,
+                               np, j, src, spart, snp, V.p, ld,
+                               (const void *)sinv32.p, zp, ctl.p, o->rtol,
+                               o->atol, partB.p, gridS, o->maxiter);
+        else if (dense)
+            hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, stream, n, nv,
+                               np, j, src, spart, snp, V.p, ld,
+                               (const void *)sinv.p, zp, ctl.p, o->rtol,
+                               o->atol, partB.p, gridS, o->maxiter);
+        else
+            hipLaunchKernelGGL(k_arn_head<0>, gridA, kBlock, 0, stream, n, nv,
+                               np, j, src, spart, snp, V.p, ld,
+                               (const void *)sinv.p, zp, ctl.p, o->rtol,
+                               o->atol, partB.p, gridS, o->maxiter);
+        DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, z.p, done_ptr(),
+                                nullptr));
+        if (fuse_dots) {
+            DNS_LPR_SWITCH(
+                K.lpr,
+                hipLaunchKernelGGL(k_spmv_multidot<L>, gridC, kBlock, 0,
+                                   stream, n, K.rowptr.p, K.colidx.p,
+                                   K.vals.p, z.p, w.p, V.p, ld, j, partA.p,
+                                   gridC, ctl.p));
+        } else {
+            DNS_LPR_SWITCH(
+                K.lpr,
+                hipLaunchKernelGGL(k_spmv_guard<L>, grid_for_rows(n, K.lpr),
+                                   kBlock, 0, stream, n, K.rowptr.p,
+                                   K.colidx.p, K.vals.p, z.p, w.p, ctl.p));
+            hipLaunchKernelGGL(k_multidot, gridC, kBlock, 0, stream, n, V.p,
+                               ld, w.p, partA.p, gridC, j, ctl.p);
         }
-        hipLaunchKernelGGL(k_gmres_close, nred, kBlock, 0, stream, n, w.p, V.p,
-                           ld, partN.p, nred, ctl.p, par, c, o->maxiter);
+        if (o->reorth) {
+            hipLaunchKernelGGL(k_orth<1>, gridD, kBlock, 0, stream, n, V.p, ld,
+                               w.p, partA.p, gridC, j, 0, partE.p, gridD,
+                               ctl.p);
+            hipLaunchKernelGGL(k_orth<0>, gridD, kBlock, 0, stream, n, V.p, ld,
+                               w.p, partE.p, gridD, j, 1, partN.p, gridD,
+                               ctl.p);
+        } else {
+            hipLaunchKernelGGL(k_orth<0>, gridD, kBlock, 0, stream, n, V.p, ld,
+                               w.p, partA.p, gridC, j, 0, partN.p, gridD,
+                               ctl.p);
+        }
     }
-    hipLaunchKernelGGL(k_gmres_finish_y, 1, 64, 0, stream, ctl.p, histdev.p,
-                       (int)hist_cap);
-    hipLaunchKernelGGL(k_basis_combine, nred, kBlock, 0, stream, n, V.p, ld,
+    hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
+                       ctl.p, histdev.p, (int)hist_cap, o->maxiter);
+    hipLaunchKernelGGL(k_basis_combine, gridD, kBlock, 0, stream, n, V.p, ld,
                        ctl.p, u.p);
-    DNS_TRY(apply_precond(u.p, 0, zero_ptr(), z.p, zero_ptr()));
-    hipLaunchKernelGGL(k_axpby, grid_for_elems(n), kBlock, 0, stream,
-                       (int64_t)n, 1.0, z.p, 1.0, x);
+    DNS_TRY(apply_precond(u.p, z.p, zero_ptr(), x));
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }
@@ -517,9 +671,11 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     const bool graph = o->use_graph != 0;
     // first cycle length: what the previous solve needed plus slack (time
     // stepping repeats itself), rounded to the polling granularity
-    const int gran = std::max(2, (o->check_every + 1) / 2 * 2);
-    int c = (last_iters >= 0) ? last_iters + 2 : std::min(m, 16);
+    const int gran = std::max(1, o->check_every);
+    int c = (last_iters >= 0) ? last_iters + 1 : std::min(m, 16);
     c = std::min(m, std::max(gran, (c + gran - 1) / gran * gran));
+    // dots fused into the K apply while the system is launch-latency bound
+    fuse_dots = n <= 400000;
     int restarts = 0;
     bool first = true;
     while (true) {
@@ -528,14 +684,12 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             (uint64_t)o->reorth, (uint64_t)o->maxiter, bits_of(o->rtol),
             bits_of(o->atol), first ? prologue_key : 0u,
             (uint64_t)popts.cheb_degree, (uint64_t)popts.schur,
-            (uint64_t)first};
+            (uint64_t)first, (uint64_t)fhat_explicit, (uint64_t)fuse_dots};
         DNS_TRY(run_cached(key, graph, [&]() -> int {
             if (first) {
                 if (prologue) DNS_TRY(prologue());
                 // reset total_it, hist_len, conv, status for this solve
                 DNS_HIP(hipMemsetAsync(ctl.p, 0, sizeof(CtlHeader), stream));
-                hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream,
-                                   (int64_t)n, b, b, partB.p);
             }
             return enqueue_cycle(b, x, c, o);
         }));
@@ -545,7 +699,7 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             hdr_host->total_it >= o->maxiter || std::isnan(hdr_host->resnorm))
             break;
         restarts++;
-        c = std::min(m, std::max(c, 2 * gran));
+        c = std::min(m, std::max(2 * c, 8));
     }
     const int total = hdr_host->total_it;
     last_iters = total;
@@ -591,13 +745,10 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
         drop_graphs();
         DNS_TRY(histdev.alloc(hcap));
     }
-    hipLaunchKernelGGL(k_dot_partials, nred, kBlock, 0, stream, (int64_t)n, b,
-                       b, partB.p);
     DNS_LPR_SWITCH(K.lpr,
-                   hipLaunchKernelGGL(k_spmv_norm<L>, nred, kBlock, 0, stream,
+                   hipLaunchKernelGGL(k_resid_norm<L>, nred, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x,
-                                      r.p, -1.0, 1.0, b, partR.p,
-                                      (const DnsCtl *)nullptr));
+                                      b, r.p, partR.p, partB.p));
     spmv_count++;
     // <rhat, r> = <r, r> at the start: partR doubles as part_rr and part_nn
     hipLaunchKernelGGL(k_bicg_start, nred, kBlock, 0, stream, n, r.p,
@@ -616,7 +767,7 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
                                bctl.p, par, o->maxiter, histdev.p);
             hipLaunchKernelGGL(k_bicg_flag, 1, 64, 0, stream, ctl.p,
                                o->maxiter);
-            DNS_TRY(apply_precond(bi_p.p, 0, zero_ptr(), bi_y.p, done_ptr()));
+            DNS_TRY(apply_precond(bi_p.p, bi_y.p, done_ptr(), nullptr));
             DNS_LPR_SWITCH(
                 K.lpr,
                 hipLaunchKernelGGL(k_spmv_dot2<L>, nred, kBlock, 0, stream, n,
@@ -625,7 +776,7 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
                                    1, partA.p, partA.p + nred, ctl.p));
             hipLaunchKernelGGL(k_bicg_s, nred, kBlock, 0, stream, n, r.p,
                                bi_v.p, bi_s.p, partA.p, nred, ctl.p, bctl.p);
-            DNS_TRY(apply_precond(bi_s.p, 0, zero_ptr(), z.p, done_ptr()));
+            DNS_TRY(apply_precond(bi_s.p, z.p, done_ptr(), nullptr));
             DNS_LPR_SWITCH(
                 K.lpr,
                 hipLaunchKernelGGL(k_spmv_dot2<L>, nred, kBlock, 0, stream, n,
@@ -740,6 +891,9 @@ int dns_device_synchronize(int device) {
 void dns_default_precond_opts(dns_precond_opts *o) {
     o->cheb_degree = 4;
     o->schur = DNS_SCHUR_DENSE;
+    o->fhat = DNS_FHAT_AUTO;
+    o->fp32_store = 1;
+    o->drop_tol = 3e-3;
     o->eig_lo_safety = 0.9;
     o->eig_hi_safety = 1.05;
     o->eig_lo = 0.0;
@@ -850,8 +1004,7 @@ int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
     DNS_HIP(hipSetDevice(h->device));
     DNS_TRY(h->ctl.zero(h->stream));
     DNS_TRY(h->xdev.upload(r, (size_t)h->n, h->stream));
-    DNS_TRY(h->apply_precond(h->xdev.p, 0, h->zero_ptr(), h->z.p,
-                             h->zero_ptr()));
+    DNS_TRY(h->apply_precond(h->xdev.p, h->z.p, h->zero_ptr(), nullptr));
     DNS_TRY(h->z.download(z, (size_t)h->n, h->stream));
     DNS_HIP(hipStreamSynchronize(h->stream));
     return DNS_OK;

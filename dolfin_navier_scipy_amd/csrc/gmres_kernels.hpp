@@ -1,0 +1,366 @@
+// Fused Arnoldi kernels of right-preconditioned GMRES (gfx950, fp64).
+//
+// The reference-size systems (n ~ 1e4) are launch/latency bound: a kernel costs
+// 3-4 us whatever it does, so the cycle is cut into as few dependent launches
+// as the data dependencies allow.  Per Arnoldi step j:
+//
+//   A  k_arn_head      close column j-1 (Givens, residual, flags) +
+//                      V[j] = w/||w|| + Schur block  zp = -Sh^-1 V[j]_p
+//   B  k_spmv_split    zv = Gc [V[j]_v; zp]        (or the Chebyshev kernels)
+//   C  k_spmv_multidot w = K z  fused with  h_i = <V_i, w>, i <= j
+//   D  k_orth          w -= V h  (+ ||w||^2, or the second-pass dots of CGS2)
+//  (E  k_orth          second Gram-Schmidt pass + ||w||^2)
+//
+// and per cycle: k_resid_norm (r = b - K x, ||r||^2, ||b||^2) in front,
+// k_arn_tail (last column, y = R^-1 g, history), k_basis_combine and the
+// correction x += P^-1 (V y) behind.  `j` is a plain kernel argument: a cycle
+// is captured as ONE hipGraph, every node has its own arguments, and the
+// device flag `ctl->done` turns the nodes after convergence into no-ops.
+//
+// Reductions: producers write one partial per workgroup, consumers sum them
+// (fixed order, no atomics); workgroup 0 alone writes the control block.
+#pragma once
+#include "kernels.hpp"
+
+namespace dns {
+
+// r = b - K x with partials of ||r||^2 and ||b||^2 (one per workgroup)
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_resid_norm(int nrows, const int *__restrict__ rowptr,
+             const int *__restrict__ colidx, const double *__restrict__ vals,
+             const double *__restrict__ x, const double *__restrict__ b,
+             double *__restrict__ r, double *__restrict__ part_rr,
+             double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    double arr = 0.0, abb = 0.0;
+    for (int row = sub; row < nrows; row += nsub) {
+        double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, row, sublane);
+        if (sublane == 0) {
+            const double bv = b[row];
+            const double v = bv - s;
+            r[row] = v;
+            arr = fma(v, v, arr);
+            abb = fma(bv, bv, abb);
+        }
+    }
+    arr = block_sum(arr, red);
+    abb = block_sum(abb, red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = arr;
+        if (part_bb) part_bb[blockIdx.x] = abb;
+    }
+}
+
+// Givens update of column j (thread 0 of workgroup 0 only)
+__device__ inline void givens_close(DnsCtl *ctl, int j, double hn,
+                                    int maxiter) {
+    double *Rc = ctl->R + (size_t)j * (kMaxRestart + 1);
+    for (int i = 0; i <= j; ++i) Rc[i] = ctl->hcol[i];
+    for (int i = 0; i < j; ++i) {
+        const double t = ctl->cs[i] * Rc[i] + ctl->sn[i] * Rc[i + 1];
+        Rc[i + 1] = -ctl->sn[i] * Rc[i] + ctl->cs[i] * Rc[i + 1];
+        Rc[i] = t;
+    }
+    const double den = hypot(Rc[j], hn);
+    int status = DNS_OK;
+    double c = 1.0, s = 0.0;
+    if (den > 0.0) {
+        c = Rc[j] / den;
+        s = hn / den;
+    } else {
+        status = DNS_BREAKDOWN;
+    }
+    ctl->cs[j] = c;
+    ctl->sn[j] = s;
+    Rc[j] = den;
+    ctl->g[j + 1] = -s * ctl->g[j];
+    ctl->g[j] = c * ctl->g[j];
+    const double res = fabs(ctl->g[j + 1]);
+    ctl->resnorm = res;
+    ctl->hist[j + 1] = res;
+    ctl->jdone = j + 1;
+    ctl->total_it += 1;
+    const bool conv = !(res > ctl->tol);
+    if (status != DNS_OK) ctl->status = status;
+    if (conv) ctl->conv = 1;
+    if (conv || status != DNS_OK || !(hn > 0.0) || isnan(res) ||
+        ctl->total_it >= maxiter)
+        ctl->done = 1;
+}
+
+// head of Arnoldi step j.  `src` is the un-normalised new basis vector (the
+// residual r for j == 0, else w of step j-1) with its ||.||^2 partials.
+//   SK 1/2: zp = -Sinv * src_p / ||src||  (Sinv dense fp64 / fp32)
+//   SK 0  : zp = -sdinv .* src_p / ||src||
+template <int SK>
+__global__ void __launch_bounds__(kBlock)
+k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
+           const double *__restrict__ src_part, int src_nparts,
+           double *__restrict__ V, size_t ld, const void *__restrict__ sinv,
+           double *__restrict__ zp, DnsCtl *ctl, double rtol, double atol,
+           const double *__restrict__ bb_part, int bb_nparts, int maxiter) {
+    if (j > 0 && ctl->done) return;
+    __shared__ double sc[2];
+    __shared__ double red4[4];
+    reduce_partials(src_part, src_nparts, src_nparts, 1, sc);
+    if (j == 0) reduce_partials(bb_part, bb_nparts, bb_nparts, 1, sc + 1);
+    const double hn = sqrt(sc[0]);
+    bool stop = false;
+    double tol = 0.0, bn = 0.0;
+    if (j == 0) {
+        bn = sqrt(sc[1]);
+        tol = fmax(rtol * bn, atol);
+        stop = !(hn > tol) || isnan(hn) || ctl->total_it >= maxiter ||
+               ctl->status != DNS_OK;
+    }
+    if (!stop && hn > 0.0) {
+        const double scale = 1.0 / hn;
+        double *vj = V + (size_t)j * ld;
+        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+             e += gridDim.x * kBlock)
+            vj[e] = src[e] * scale;
+        const double *sp = src + nv;
+        if (SK == 1) {
+            dense_rows_block<double>((const double *)sinv, sp, np, -scale, zp,
+                                     nullptr, red4);
+        } else if (SK == 2) {
+            dense_rows_block<float>((const float *)sinv, sp, np, -scale, zp,
+                                    nullptr, red4);
+        } else {
+            const double *sd = (const double *)sinv;
+            for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
+                 i += gridDim.x * kBlock)
+                zp[i] = -sd[i] * sp[i] * scale;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (j == 0) {
+            ctl->jdone = 0;
+            ctl->zero = 0;
+            ctl->beta = hn;
+            ctl->resnorm = hn;
+            ctl->bnorm = bn;
+            ctl->tol = tol;
+            ctl->g[0] = hn;
+            ctl->hist[0] = hn;
+            if (!(hn > tol)) ctl->conv = 1;
+            ctl->done = stop ? 1 : 0;
+        } else {
+            givens_close(ctl, j - 1, hn, maxiter);
+        }
+    }
+}
+
+// w = K z fused with the Gram-Schmidt dots  part[i*nparts + wg] = <V_i, w>
+// (i <= j).  After the row sum is known in all LPR lanes of the sub-wave,
+// lane l accumulates the dots with V_i, i = l (mod LPR).
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
+                const int *__restrict__ colidx,
+                const double *__restrict__ vals, const double *__restrict__ z,
+                double *__restrict__ w, const double *__restrict__ V, size_t ld,
+                int j, double *__restrict__ part, int nparts,
+                const DnsCtl *ctl) {
+    if (ctl->done) return;
+    constexpr int NQ = (kMaxRestart + LPR) / LPR;   // dots per lane
+    __shared__ double wred[kBlock / 64][NQ * LPR];
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    const int nvec = j + 1;
+    double acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+    for (int row = sub; row < nrows; row += nsub) {
+        // basis entries first: their loads overlap the row's own load chain
+        double vq[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = q * LPR + sublane;
+            vq[q] = (i < nvec) ? V[(size_t)i * ld + row] : 0.0;
+        }
+        const double s = csr_row_dot<LPR>(rowptr, colidx, vals, z, row, sublane);
+        if (sublane == 0) w[row] = s;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[q] = fma(vq[q], s, acc[q]);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double v = acc[q];
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+        if (lane < LPR) wred[wave][q * LPR + lane] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvec; i += kBlock) {
+        double s = 0.0;
+        for (int ww = 0; ww < kBlock / 64; ++ww) s += wred[ww][i];
+        part[(size_t)i * nparts + blockIdx.x] = s;
+    }
+}
+
+// plain w = K z (guarded), used when the dots run as their own kernel
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_guard(int nrows, const int *__restrict__ rowptr,
+             const int *__restrict__ colidx, const double *__restrict__ vals,
+             const double *__restrict__ x, double *__restrict__ w,
+             const DnsCtl *ctl) {
+    if (ctl->done) return;
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    for (int row = sub; row < nrows; row += nsub) {
+        double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, row, sublane);
+        if (sublane == 0) w[row] = s;
+    }
+}
+
+// part[i*nparts + wg] = <V_i, w>, i <= j  (streaming form for large n)
+__global__ void __launch_bounds__(kBlock)
+k_multidot(int n, const double *__restrict__ V, size_t ld,
+           const double *__restrict__ w, double *__restrict__ part, int nparts,
+           int j, const DnsCtl *ctl) {
+    if (ctl->done) return;
+    const int nvec = j + 1;
+    __shared__ double wred[kBlock / 64][8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < nvec; i0 += 8) {
+        double acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
+        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+             e += gridDim.x * kBlock) {
+            const double we = w[e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i0 + q < nvec)
+                    acc[q] = fma(V[(size_t)(i0 + q) * ld + e], we, acc[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = wave_sum(acc[q]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wred[wave][q] = acc[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && i0 + threadIdx.x < nvec) {
+            double s = 0.0;
+            for (int ww = 0; ww < kBlock / 64; ++ww) s += wred[ww][threadIdx.x];
+            part[(size_t)(i0 + threadIdx.x) * nparts + blockIdx.x] = s;
+        }
+    }
+}
+
+// Gram-Schmidt update  w -= sum_i h_i V_i,  h_i = sum of `part_in`.
+//   pass 0: hcol = h      pass 1: hcol += h   (workgroup 0)
+//   MODE 0: partial of ||w||^2 -> out[wg]
+//   MODE 1: second-pass dots   -> out[i*out_nparts + wg] = <V_i, w_new>
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_orth(int n, const double *__restrict__ V, size_t ld, double *__restrict__ w,
+       const double *__restrict__ part_in, int in_nparts, int j, int pass,
+       double *__restrict__ out, int out_nparts, DnsCtl *ctl) {
+    if (ctl->done) return;
+    const int nvec = j + 1;
+    __shared__ double h[kMaxRestart + 1];
+    __shared__ double red[4];
+    __shared__ double wred[kBlock / 64][8];
+    reduce_partials(part_in, in_nparts, in_nparts, nvec, h);
+    if (blockIdx.x == 0 && threadIdx.x < nvec)
+        ctl->hcol[threadIdx.x] =
+            (pass == 0 ? 0.0 : ctl->hcol[threadIdx.x]) + h[threadIdx.x];
+    double acc = 0.0;
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+         e += gridDim.x * kBlock) {
+        double we = w[e];
+        for (int i = 0; i < nvec; ++i)
+            we = fma(-h[i], V[(size_t)i * ld + e], we);
+        w[e] = we;
+        acc = fma(we, we, acc);
+    }
+    if (MODE == 0) {
+        acc = block_sum(acc, red);
+        if (threadIdx.x == 0) out[blockIdx.x] = acc;
+        return;
+    }
+    // MODE 1: dots of the updated w with every V_i (own elements re-read)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < nvec; i0 += 8) {
+        double a8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a8[q] = 0.0;
+        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+             e += gridDim.x * kBlock) {
+            const double we = w[e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (i0 + q < nvec)
+                    a8[q] = fma(V[(size_t)(i0 + q) * ld + e], we, a8[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a8[q] = wave_sum(a8[q]);
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wred[wave][q] = a8[q];
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && i0 + threadIdx.x < nvec) {
+            double s = 0.0;
+            for (int ww = 0; ww < kBlock / 64; ++ww) s += wred[ww][threadIdx.x];
+            out[(size_t)(i0 + threadIdx.x) * out_nparts + blockIdx.x] = s;
+        }
+    }
+}
+
+// tail of a cycle of `c` steps (ONE workgroup): close the last column unless
+// the cycle already stopped, y = R^-1 g, append the cycle's residual norms to
+// the solve's history
+__global__ void __launch_bounds__(kBlock)
+k_arn_tail(int c, const double *__restrict__ norm_part, int nparts,
+           DnsCtl *ctl, double *__restrict__ histbuf, int hist_cap,
+           int maxiter) {
+    __shared__ double sc[1];
+    reduce_partials(norm_part, nparts, nparts, 1, sc);
+    if (threadIdx.x != 0) return;
+    if (!ctl->done && c > 0) givens_close(ctl, c - 1, sqrt(sc[0]), maxiter);
+    const int jcols = ctl->jdone;
+    for (int i = jcols - 1; i >= 0; --i) {
+        double s = ctl->g[i];
+        for (int k = i + 1; k < jcols; ++k)
+            s -= ctl->R[(size_t)k * (kMaxRestart + 1) + i] * ctl->y[k];
+        const double d = ctl->R[(size_t)i * (kMaxRestart + 1) + i];
+        ctl->y[i] = (d != 0.0) ? s / d : 0.0;
+    }
+    int hl = ctl->hist_len;
+    for (int i = (hl > 0 ? 1 : 0); i <= jcols && hl < hist_cap; ++i)
+        histbuf[hl++] = ctl->hist[i];
+    ctl->hist_len = hl;
+}
+
+// u = sum_{i<jdone} y_i V_i
+__global__ void __launch_bounds__(kBlock)
+k_basis_combine(int n, const double *__restrict__ V, size_t ld,
+                const DnsCtl *ctl, double *__restrict__ u) {
+    __shared__ double y[kMaxRestart];
+    const int jcols = ctl->jdone;
+    if (threadIdx.x < jcols) y[threadIdx.x] = ctl->y[threadIdx.x];
+    __syncthreads();
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+         e += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int i = 0; i < jcols; ++i)
+            s = fma(y[i], V[(size_t)i * ld + e], s);
+        u[e] = s;
+    }
+}
+
+}  // namespace dns

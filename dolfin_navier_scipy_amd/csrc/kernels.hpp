@@ -13,12 +13,10 @@ namespace dns {
 // ---------------------------------------------------------------------------
 // Krylov control block, lives in HBM; written only by workgroup 0 of the
 // kernels that close an iteration, read (never written) by everyone else.
-// `jv[par]` is the Arnoldi column of the iteration with parity `par`; the
-// closing kernel writes `jv[par ^ 1]`, so no kernel reads a slot that is
-// written in the same launch.
 // ---------------------------------------------------------------------------
 struct DnsCtl {
-    int jv[2];
+    int jdone;       // completed Arnoldi columns of the current cycle
+    int jpad;
     int done;        // != 0: all later kernels of this solve return at once
     int status;      // DNS_OK / DNS_BREAKDOWN
     int zero;        // constant 0 (vector selector / never-raised guard)
@@ -70,9 +68,32 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nw = blockDim.x >> 6;
     for (int s = wave; s < nscal; s += nw) {
-        double a = 0.0;
-        for (int p = lane; p < nparts; p += 64)
-            a += part[(size_t)s * pstride + p];
+        // 8 independent loads in flight per lane: the partials sit in L2 /
+        // Infinity Cache and a dependent chain of loads would cost a round
+        // trip each (fixed summation order -> deterministic)
+        const double *ps = part + (size_t)s * pstride;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        double a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+        int p = lane;
+        for (; p + 448 < nparts; p += 512) {
+            a0 += ps[p];
+            a1 += ps[p + 64];
+            a2 += ps[p + 128];
+            a3 += ps[p + 192];
+            a4 += ps[p + 256];
+            a5 += ps[p + 320];
+            a6 += ps[p + 384];
+            a7 += ps[p + 448];
+        }
+        const double t0 = (p < nparts) ? ps[p] : 0.0;
+        const double t1 = (p + 64 < nparts) ? ps[p + 64] : 0.0;
+        const double t2 = (p + 128 < nparts) ? ps[p + 128] : 0.0;
+        const double t3 = (p + 192 < nparts) ? ps[p + 192] : 0.0;
+        const double t4 = (p + 256 < nparts) ? ps[p + 256] : 0.0;
+        const double t5 = (p + 320 < nparts) ? ps[p + 320] : 0.0;
+        const double t6 = (p + 384 < nparts) ? ps[p + 384] : 0.0;
+        double a = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+        a += ((t0 + t1) + (t2 + t3)) + ((t4 + t5) + t6);
         a = wave_sum(a);
         if (lane == 0) out[s] = a;
     }
@@ -91,10 +112,17 @@ __device__ __forceinline__ double csr_row_dot(const int *__restrict__ rowptr,
                                               const double *__restrict__ x,
                                               int row, int sublane) {
     const int k1 = rowptr[row + 1];
-    double s = 0.0;
-    for (int k = rowptr[row] + sublane; k < k1; k += LPR)
-        s = fma(vals[k], x[colidx[k]], s);
-    return subwave_sum<LPR>(s);
+    int k = rowptr[row] + sublane;
+    double s0 = 0.0, s1 = 0.0;
+    // two (col,val) pairs and then two gathers in flight per lane
+    for (; k + LPR < k1; k += 2 * LPR) {
+        const int c0 = colidx[k], c1 = colidx[k + LPR];
+        const double v0 = vals[k], v1 = vals[k + LPR];
+        s0 = fma(v0, x[c0], s0);
+        s1 = fma(v1, x[c1], s1);
+    }
+    if (k < k1) s0 = fma(vals[k], x[colidx[k]], s0);
+    return subwave_sum<LPR>(s0 + s1);
 }
 
 // y = alpha*A*x + beta*b   (b may be null -> beta ignored)
@@ -373,281 +401,124 @@ k_cheb_step(int nv, const int *__restrict__ rowptr,
     }
 }
 
-// Jacobi Schur fallback: zp = -sdinv * rp
+// explicit approximate inverse: zv = Gc [rv; zp], Gc = [G, -G JT] (NV x (NV+NP))
+// with G = p(D^-1 F) D^-1 the SAME Chebyshev polynomial as k_cheb_*, formed once
+// on the host: one SpMV instead of `degree` dependent launches (latency-bound
+// sizes).  Columns < nv read the selected input vector, the rest read zp.
+template <int LPR, typename VT>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_split(int nv, const int *__restrict__ rowptr,
+             const int *__restrict__ colidx, const VT *__restrict__ vals,
+             const double *__restrict__ rbase, size_t ld,
+             const int *__restrict__ jsel, const double *__restrict__ zp,
+             double *__restrict__ zv, const int *__restrict__ guard,
+             double *__restrict__ xacc) {
+    if (*guard) return;
+    const double *rv = rbase + (size_t)(*jsel) * ld;
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    for (int row = sub; row < nv; row += nsub) {
+        const int k1 = rowptr[row + 1];
+        int k = rowptr[row] + sublane;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        for (; k + 3 * LPR < k1; k += 4 * LPR) {
+            const int c0 = colidx[k], c1 = colidx[k + LPR];
+            const int c2 = colidx[k + 2 * LPR], c3 = colidx[k + 3 * LPR];
+            const double v0 = (double)vals[k], v1 = (double)vals[k + LPR];
+            const double v2 = (double)vals[k + 2 * LPR];
+            const double v3 = (double)vals[k + 3 * LPR];
+            s0 = fma(v0, c0 < nv ? rv[c0] : zp[c0 - nv], s0);
+            s1 = fma(v1, c1 < nv ? rv[c1] : zp[c1 - nv], s1);
+            s2 = fma(v2, c2 < nv ? rv[c2] : zp[c2 - nv], s2);
+            s3 = fma(v3, c3 < nv ? rv[c3] : zp[c3 - nv], s3);
+        }
+        for (; k < k1; k += LPR) {
+            const int c = colidx[k];
+            s0 = fma((double)vals[k], c < nv ? rv[c] : zp[c - nv], s0);
+        }
+        const double s = subwave_sum<LPR>((s0 + s1) + (s2 + s3));
+        if (sublane == 0) {
+            zv[row] = s;
+            if (xacc) xacc[row] += s;      // fused correction x_v += z_v
+        }
+    }
+}
+
+// Jacobi Schur fallback: zp = -sdinv * rp   (xacc: x_p += z_p)
 __global__ void __launch_bounds__(kBlock)
 k_schur_jacobi(int np, const double *__restrict__ sdinv,
                const double *__restrict__ rbase, size_t ld,
                const int *__restrict__ jsel, int nv, double *__restrict__ zp,
-               const int *__restrict__ guard) {
+               const int *__restrict__ guard, double *__restrict__ xacc) {
     if (*guard) return;
     const double *rp = rbase + (size_t)(*jsel) * ld + nv;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
-         i += gridDim.x * kBlock)
-        zp[i] = -sdinv[i] * rp[i];
+         i += gridDim.x * kBlock) {
+        const double v = -sdinv[i] * rp[i];
+        zp[i] = v;
+        if (xacc) xacc[i] += v;
+    }
+}
+
+// out[row] = scale * <A[row,:], x> for the rows of this workgroup (row =
+// blockIdx.x, += gridDim.x): the WHOLE workgroup works on one dense row so
+// that every load of the row is in flight at once (latency, not bandwidth,
+// bounds the n ~ 1e3 Schur block); `red` holds >= 4 doubles of LDS
+template <typename VT>
+__device__ __forceinline__ void dense_rows_block(const VT *__restrict__ a,
+                                                 const double *__restrict__ x,
+                                                 int n, double scale,
+                                                 double *__restrict__ out,
+                                                 double *__restrict__ xacc,
+                                                 double *red) {
+    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+        const VT *ar = a + (size_t)row * n;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = threadIdx.x;
+        for (; c + 3 * kBlock < n; c += 4 * kBlock) {
+            const double a0 = (double)ar[c], a1 = (double)ar[c + kBlock];
+            const double a2 = (double)ar[c + 2 * kBlock];
+            const double a3 = (double)ar[c + 3 * kBlock];
+            s0 = fma(a0, x[c], s0);
+            s1 = fma(a1, x[c + kBlock], s1);
+            s2 = fma(a2, x[c + 2 * kBlock], s2);
+            s3 = fma(a3, x[c + 3 * kBlock], s3);
+        }
+        const double t0 = (c < n) ? (double)ar[c] * x[c] : 0.0;
+        const double t1 =
+            (c + kBlock < n) ? (double)ar[c + kBlock] * x[c + kBlock] : 0.0;
+        const double t2 = (c + 2 * kBlock < n)
+                              ? (double)ar[c + 2 * kBlock] * x[c + 2 * kBlock]
+                              : 0.0;
+        double s = ((s0 + s1) + (s2 + s3)) + ((t0 + t1) + t2);
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) {
+            const double v = scale * s;
+            out[row] = v;
+            if (xacc) xacc[row] += v;
+        }
+    }
 }
 
 // dense Schur: zp = -Sinv rp  (rp = selected vector's pressure part)
+template <typename VT>
 __global__ void __launch_bounds__(kBlock)
-k_schur_dense(int np, const double *__restrict__ sinv,
+k_schur_dense(int np, const VT *__restrict__ sinv,
               const double *__restrict__ rbase, size_t ld,
               const int *__restrict__ jsel, int nv, double *__restrict__ zp,
-              const int *__restrict__ guard) {
+              const int *__restrict__ guard, double *__restrict__ xacc) {
     if (*guard) return;
+    __shared__ double red[4];
     const double *rp = rbase + (size_t)(*jsel) * ld + nv;
-    const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    const int nwaves = (gridDim.x * kBlock) >> 6;
-    for (int row = wave; row < np; row += nwaves) {
-        const double *ar = sinv + (size_t)row * np;
-        double s = 0.0;
-        for (int c = lane; c < np; c += 64) s = fma(ar[c], rp[c], s);
-        s = wave_sum(s);
-        if (lane == 0) zp[row] = -s;
-    }
+    dense_rows_block<VT>(sinv, rp, np, -1.0, zp, xacc, red);
 }
 
-// ---------------------------------------------------------------------------
-// GMRES kernels
-// ---------------------------------------------------------------------------
-// w = alpha*K*x + beta*b with a fused partial of ||w||^2 (one per workgroup)
-template <int LPR>
 __global__ void __launch_bounds__(kBlock)
-k_spmv_norm(int nrows, const int *__restrict__ rowptr,
-            const int *__restrict__ colidx, const double *__restrict__ vals,
-            const double *__restrict__ x, double *__restrict__ w, double alpha,
-            double beta, const double *__restrict__ b,
-            double *__restrict__ partials, const DnsCtl *ctl) {
-    if (ctl && ctl->done) return;
-    __shared__ double red[4];
-    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
-    const int sublane = threadIdx.x % LPR;
-    const int nsub = gridDim.x * (kBlock / LPR);
-    double acc = 0.0;
-    for (int row = sub; row < nrows; row += nsub) {
-        double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, row, sublane);
-        if (sublane == 0) {
-            const double v = b ? fma(alpha, s, beta * b[row]) : alpha * s;
-            w[row] = v;
-            acc = fma(v, v, acc);
-        }
-    }
-    acc = block_sum(acc, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
-}
-
-// plain w = K z inside the Arnoldi loop (guarded by ctl->done)
-template <int LPR>
-__global__ void __launch_bounds__(kBlock)
-k_spmv_guard(int nrows, const int *__restrict__ rowptr,
-             const int *__restrict__ colidx, const double *__restrict__ vals,
-             const double *__restrict__ x, double *__restrict__ w,
-             const DnsCtl *ctl) {
-    if (ctl->done) return;
-    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
-    const int sublane = threadIdx.x % LPR;
-    const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < nrows; row += nsub) {
-        double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, row, sublane);
-        if (sublane == 0) w[row] = s;
-    }
-}
-
-// cycle start: beta = sqrt(sum partials); V[0] = r/beta; per-cycle reset of
-// the control block.  Identical for every cycle of a solve (the host zeroes
-// `total_it/hist_len/conv/status` once before the first), so one captured
-// graph serves all cycles.
-__global__ void __launch_bounds__(kBlock)
-k_gmres_start(int n, const double *__restrict__ r, double *__restrict__ v0,
-              const double *__restrict__ partials, int nparts, DnsCtl *ctl,
-              double rtol, double atol,
-              const double *__restrict__ bnorm_partials, int maxiter) {
-    __shared__ double sc[2];
-    reduce_partials(partials, nparts, nparts, 1, sc);
-    reduce_partials(bnorm_partials, nparts, nparts, 1, sc + 1);
-    const double beta = sqrt(sc[0]);
-    const double bn = sqrt(sc[1]);
-    const double tol = fmax(rtol * bn, atol);
-    const bool conv = !(beta > tol);
-    const bool stop = conv || isnan(beta) || ctl->total_it >= maxiter ||
-                      ctl->status != DNS_OK;
-    if (!stop) {
-        const double ib = 1.0 / beta;
-        for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
-             i += gridDim.x * kBlock)
-            v0[i] = r[i] * ib;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl->jv[0] = 0;
-        ctl->jv[1] = 0;
-        ctl->zero = 0;
-        ctl->beta = beta;
-        ctl->resnorm = beta;
-        ctl->bnorm = bn;
-        ctl->tol = tol;
-        ctl->g[0] = beta;
-        ctl->hist[0] = beta;
-        if (conv) ctl->conv = 1;
-        ctl->done = stop ? 1 : 0;
-    }
-}
-
-// partials[i*nparts + block] = <V_i, w>,  i <= j
-__global__ void __launch_bounds__(kBlock)
-k_multidot(int n, const double *__restrict__ V, size_t ld,
-           const double *__restrict__ w, double *__restrict__ partials,
-           int nparts, const DnsCtl *ctl, int par) {
-    if (ctl->done) return;
-    const int nvec = ctl->jv[par] + 1;
-    __shared__ double wred[4][8];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i0 = 0; i0 < nvec; i0 += 8) {
-        double acc[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.0;
-        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
-             e += gridDim.x * kBlock) {
-            const double we = w[e];
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (i0 + q < nvec)
-                    acc[q] = fma(V[(size_t)(i0 + q) * ld + e], we, acc[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = wave_sum(acc[q]);
-        __syncthreads();
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) wred[wave][q] = acc[q];
-        }
-        __syncthreads();
-        if (threadIdx.x < 8 && i0 + threadIdx.x < nvec) {
-            double s = 0.0;
-            for (int ww = 0; ww < (kBlock >> 6); ++ww)
-                s += wred[ww][threadIdx.x];
-            partials[(size_t)(i0 + threadIdx.x) * nparts + blockIdx.x] = s;
-        }
-    }
-}
-
-// w -= sum_i h_i V_i with h_i = sum of the partials of k_multidot;
-// workgroup 0 accumulates the Hessenberg column; optional partial of ||w||^2
-__global__ void __launch_bounds__(kBlock)
-k_orth_update(int n, const double *__restrict__ V, size_t ld,
-              double *__restrict__ w, const double *__restrict__ partials,
-              int nparts, DnsCtl *ctl, int par, int pass,
-              double *__restrict__ norm_partials) {
-    if (ctl->done) return;
-    const int nvec = ctl->jv[par] + 1;
-    __shared__ double h[kMaxRestart + 1];
-    __shared__ double red[4];
-    reduce_partials(partials, nparts, nparts, nvec, h);
-    if (blockIdx.x == 0 && threadIdx.x < nvec)
-        ctl->hcol[threadIdx.x] =
-            (pass == 0 ? 0.0 : ctl->hcol[threadIdx.x]) + h[threadIdx.x];
-    double acc = 0.0;
-    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
-         e += gridDim.x * kBlock) {
-        double we = w[e];
-        for (int i = 0; i < nvec; ++i)
-            we = fma(-h[i], V[(size_t)i * ld + e], we);
-        w[e] = we;
-        acc = fma(we, we, acc);
-    }
-    if (norm_partials) {
-        acc = block_sum(acc, red);
-        if (threadIdx.x == 0) norm_partials[blockIdx.x] = acc;
-    }
-}
-
-// V[j+1] = w/||w||; workgroup 0: Givens rotations, residual estimate, flags
-__global__ void __launch_bounds__(kBlock)
-k_gmres_close(int n, const double *__restrict__ w, double *__restrict__ V,
-              size_t ld, const double *__restrict__ norm_partials, int nparts,
-              DnsCtl *ctl, int par, int mcycle, int maxiter) {
-    if (ctl->done) return;
-    const int j = ctl->jv[par];
-    __shared__ double sc[1];
-    reduce_partials(norm_partials, nparts, nparts, 1, sc);
-    const double hn = sqrt(sc[0]);
-    if (hn > 0.0) {
-        const double ih = 1.0 / hn;
-        double *vn = V + (size_t)(j + 1) * ld;
-        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
-             e += gridDim.x * kBlock)
-            vn[e] = w[e] * ih;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double *Rc = ctl->R + (size_t)j * (kMaxRestart + 1);
-        for (int i = 0; i <= j; ++i) Rc[i] = ctl->hcol[i];
-        double hj1 = hn;
-        for (int i = 0; i < j; ++i) {
-            const double t = ctl->cs[i] * Rc[i] + ctl->sn[i] * Rc[i + 1];
-            Rc[i + 1] = -ctl->sn[i] * Rc[i] + ctl->cs[i] * Rc[i + 1];
-            Rc[i] = t;
-        }
-        const double den = hypot(Rc[j], hj1);
-        int status = DNS_OK;
-        double c = 1.0, s = 0.0;
-        if (den > 0.0) {
-            c = Rc[j] / den;
-            s = hj1 / den;
-        } else {
-            status = DNS_BREAKDOWN;
-        }
-        ctl->cs[j] = c;
-        ctl->sn[j] = s;
-        Rc[j] = den;
-        ctl->g[j + 1] = -s * ctl->g[j];
-        ctl->g[j] = c * ctl->g[j];
-        const double res = fabs(ctl->g[j + 1]);
-        ctl->resnorm = res;
-        ctl->hist[j + 1] = res;
-        ctl->jv[par ^ 1] = j + 1;
-        ctl->total_it += 1;
-        const bool conv = !(res > ctl->tol);
-        if (status != DNS_OK) ctl->status = status;
-        if (conv) ctl->conv = 1;
-        if (conv || status != DNS_OK || !(hn > 0.0) || isnan(res) ||
-            ctl->total_it >= maxiter)
-            ctl->done = 1;
-        (void)mcycle;
-    }
-}
-
-// end of a cycle (single thread): y = R^-1 g for the completed columns and
-// the cycle's residual norms appended to the solve's history
-__global__ void k_gmres_finish_y(DnsCtl *ctl, double *__restrict__ histbuf,
-                                 int hist_cap) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int jcols = max(ctl->jv[0], ctl->jv[1]);
-    for (int i = jcols - 1; i >= 0; --i) {
-        double s = ctl->g[i];
-        for (int k = i + 1; k < jcols; ++k)
-            s -= ctl->R[(size_t)k * (kMaxRestart + 1) + i] * ctl->y[k];
-        const double d = ctl->R[(size_t)i * (kMaxRestart + 1) + i];
-        ctl->y[i] = (d != 0.0) ? s / d : 0.0;
-    }
-    int hl = ctl->hist_len;
-    for (int i = (hl > 0 ? 1 : 0); i <= jcols && hl < hist_cap; ++i)
-        histbuf[hl++] = ctl->hist[i];
-    ctl->hist_len = hl;
-}
-
-// u = sum_{i<jcols} y_i V_i   (jcols read from the control block)
-__global__ void __launch_bounds__(kBlock)
-k_basis_combine(int n, const double *__restrict__ V, size_t ld,
-                const DnsCtl *ctl, double *__restrict__ u) {
-    __shared__ double y[kMaxRestart];
-    const int jcols = max(ctl->jv[0], ctl->jv[1]);
-    if (threadIdx.x < jcols) y[threadIdx.x] = ctl->y[threadIdx.x];
-    __syncthreads();
-    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
-         e += gridDim.x * kBlock) {
-        double s = 0.0;
-        for (int i = 0; i < jcols; ++i)
-            s = fma(y[i], V[(size_t)i * ld + e], s);
-        u[e] = s;
-    }
+k_to_f32(int64_t n, const double *__restrict__ in, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kBlock)
+        out[i] = (float)in[i];
 }
 
 }  // namespace dns

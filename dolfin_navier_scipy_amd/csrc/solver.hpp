@@ -8,6 +8,8 @@
 #include <functional>
 
 #include "bicgstab_kernels.hpp"
+#include "gmres_kernels.hpp"
+#include "hostcsr.hpp"
 #include "kernels.hpp"
 
 namespace dns {
@@ -105,7 +107,7 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
 }
 
 struct CtlHeader {   // leading part of DnsCtl, copied back to the host
-    int jv[2];
+    int jdone, jpad;
     int done, status, zero, total_it, hist_len, conv;
     double beta, tol, resnorm, bnorm;
 };
@@ -134,11 +136,21 @@ struct dns_saddle {
     double lam_lo = 0, lam_hi = 0, theta = 0, delta = 0;
     std::vector<double> c1, c2;      // Chebyshev recurrence coefficients
     dns::DevBuf<double> sinv;        // dense Schur inverse (np x np) or diag
+    bool fhat_explicit = false;
+    bool fp32_store = false;         // fp32 copies of Gc values / dense Sinv
+    dns::DevBuf<float> sinv32, gc32;
+    int to_f32(const double *in, dns::DevBuf<float> &out, size_t count);
+    dns::CsrDev Gc;                  // [G, -G JT], explicit polynomial F^-1
+    dns::HostCsr Fh, Jh, JTh;        // host copies for preconditioner set-up
+    int build_explicit(bool dense_schur);
     dns::DevBuf<double> cheb_r, cheb_d0, cheb_d1;
     // Krylov workspace
-    int nred = 64;
+    int nred = 64;                   // partial count of the BiCGStab kernels
+    int gridS = 64, gridC = 64, gridD = 64;   // GMRES: residual / K apply /
+                                              // vector kernels
+    bool fuse_dots = true;
     dns::DevBuf<double> V, w, z, u, r, xdev, bdev;
-    dns::DevBuf<double> partA, partN, partR, partB, partC;
+    dns::DevBuf<double> partA, partN, partR, partB, partC, partE;
     dns::DevBuf<double> bi_rhat, bi_p, bi_v, bi_s, bi_t, bi_y, histdev;
     dns::DevBuf<dns::DnsCtl> ctl;
     dns::DevBuf<dns::BicgCtl> bctl;
@@ -169,9 +181,11 @@ struct dns_saddle {
     int build_jacobi_schur();
     int invert_dense(double *a, int nn);
     int ensure_workspace(int m);
-    // z = P^-1 (vector `*jsel` of rbase); all device pointers
-    int apply_precond(const double *rbase, size_t ldr, const int *jsel,
-                      double *zout, const int *guard);
+    // z = P^-1 r (device pointers); `xacc` != null: also x += z
+    int apply_precond(const double *rvec, double *zout, const int *guard,
+                      double *xacc);
+    int apply_fhat_part(const double *rvec, const double *zp, double *zv,
+                        const int *guard, double *xacc);
     int dot_host(int64_t len, const double *x, const double *y, double *out);
     int read_header();
     int solve_device(const double *b, double *x, const dns_solve_opts *o,
@@ -185,11 +199,6 @@ struct dns_saddle {
     int bicgstab(const double *b, double *x, const dns_solve_opts *o,
                  dns_solve_stats *st);
     int true_residual(const double *b, const double *x, double *out);
-    const int *jsel_ptr(int par) const {
-        return reinterpret_cast<const int *>(
-            reinterpret_cast<const char *>(ctl.p) +
-            offsetof(dns::DnsCtl, jv) + sizeof(int) * par);
-    }
     const int *done_ptr() const {
         return reinterpret_cast<const int *>(
             reinterpret_cast<const char *>(ctl.p) + offsetof(dns::DnsCtl, done));

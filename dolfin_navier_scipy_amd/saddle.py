@@ -12,6 +12,8 @@ __all__ = ['SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
 _METHODS = {'gmres': C.DNS_METHOD_GMRES, 'bicgstab': C.DNS_METHOD_BICGSTAB}
 _SCHUR = {'dense': C.DNS_SCHUR_DENSE, 'jacobi': C.DNS_SCHUR_JACOBI}
 _VARIANTS = {'vector': C.DNS_SPMV_VECTOR, 'stream': C.DNS_SPMV_STREAM}
+_FHAT = {'cheb': C.DNS_FHAT_CHEB, 'explicit': C.DNS_FHAT_EXPLICIT,
+         'auto': C.DNS_FHAT_AUTO}
 
 
 def solve_opts(method='gmres', restart=60, maxiter=400, reorth=True,
@@ -27,12 +29,18 @@ def solve_opts(method='gmres', restart=60, maxiter=400, reorth=True,
     return o
 
 
-def precond_opts(cheb_degree=4, schur='dense', eig_lo=0., eig_hi=0.,
-                 eig_lo_safety=0.9, eig_hi_safety=1.05):
+def precond_opts(cheb_degree=4, schur='dense', fhat='auto', eig_lo=0.,
+                 eig_hi=0., eig_lo_safety=0.9, eig_hi_safety=1.05,
+                 fp32_store=None, drop_tol=None):
     o = C.dns_precond_opts()
     C.load_library().dns_default_precond_opts(ct.byref(o))
+    if fp32_store is not None:
+        o.fp32_store = 1 if fp32_store else 0
+    if drop_tol is not None:
+        o.drop_tol = float(drop_tol)
     o.cheb_degree = int(cheb_degree)
     o.schur = _SCHUR[schur] if isinstance(schur, str) else schur
+    o.fhat = _FHAT[fhat] if isinstance(fhat, str) else fhat
     o.eig_lo, o.eig_hi = float(eig_lo), float(eig_hi)
     o.eig_lo_safety, o.eig_hi_safety = float(eig_lo_safety), \
         float(eig_hi_safety)

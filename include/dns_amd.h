@@ -59,12 +59,22 @@ typedef struct dns_csr {         /* host-side CSR view (borrowed)            */
     const double  *vals;         /* nnz     */
 } dns_csr;
 
+#define DNS_FHAT_CHEB        0   /* Chebyshev recurrence: degree-1 SpMVs/apply */
+#define DNS_FHAT_EXPLICIT    1   /* same polynomial as ONE explicit CSR matrix */
+#define DNS_FHAT_AUTO        2   /* explicit while the system is launch-bound  */
+
 typedef struct dns_precond_opts {
     int32_t cheb_degree;         /* terms of the Jacobi-Chebyshev F^-1 (>=1) */
     int32_t schur;               /* DNS_SCHUR_*                              */
+    int32_t fhat;                /* DNS_FHAT_*                               */
+    int32_t fp32_store;          /* 1: keep the explicit preconditioner
+                                    matrices (Gc values, Schur inverse) in
+                                    fp32 -- halves their bytes; the Krylov
+                                    iteration itself stays fp64             */
     double  eig_lo_safety;       /* multiply the estimated lambda_min (0.9)  */
     double  eig_hi_safety;       /* multiply the estimated lambda_max (1.05) */
     double  eig_lo, eig_hi;      /* >0: use these bounds, skip the estimate  */
+    double  drop_tol;            /* explicit Gc: drop |g_ij| < tol*max_j|g_ij| */
 } dns_precond_opts;
 
 typedef struct dns_solve_opts {

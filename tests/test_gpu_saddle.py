@@ -46,11 +46,13 @@ def test_apply_K_and_bounds(sad, small):
     system.close()
 
 
+@pytest.mark.parametrize('fhat', ['cheb', 'explicit'])
 @pytest.mark.parametrize('degree', [1, 2, 4])
-def test_precond_matches_model(sad, small, degree):
+def test_precond_matches_model(sad, small, degree, fhat):
     F, J = small['F'], small['J']
     system = sad.SaddleSystem(F, J)
-    system.setup_precond(cheb_degree=degree, schur='dense')
+    system.setup_precond(cheb_degree=degree, schur='dense', fhat=fhat,
+                         fp32_store=False, drop_tol=0.)
     lo, hi = system.cheb_bounds()
     cheb = km.ChebJacobi(F, degree=degree, lmin=lo, lmax=hi)
     P = km.BlockTriPrecond(F, J, cheb=cheb)
@@ -89,7 +91,8 @@ def test_solve_matches_oracle(sad, small, method, graph, schur):
 def test_gmres_iteration_count_matches_model(sad, small):
     F, J = small['F'], small['J']
     system = sad.SaddleSystem(F, J)
-    system.setup_precond(cheb_degree=3, schur='dense')
+    system.setup_precond(cheb_degree=3, schur='dense', fp32_store=False,
+                         drop_tol=0.)
     lo, hi = system.cheb_bounds()
     b = np.concatenate([small['rhsv'], small['rhsp']])
     x = system.solve(small['rhsv'], small['rhsp'], rtol=1e-10)
@@ -101,6 +104,24 @@ def test_gmres_iteration_count_matches_model(sad, small):
     k = min(hist.size, hm.size) - 2
     assert np.allclose(hist[:k], hm[:k], rtol=1e-3)
     assert np.linalg.norm(x - xm) <= 1e-8*np.linalg.norm(xm)
+    system.close()
+
+
+@pytest.mark.parametrize('fp32,drop', [(True, 3e-3), (True, 0.), (False, 1e-2)])
+def test_inexact_preconditioner_same_answer(sad, small, fp32, drop):
+    """fp32 storage / dropped entries only change the PRECONDITIONER: the
+    fp64 Krylov iteration still converges to the oracle's solution"""
+    system = sad.SaddleSystem(small['F'], small['J'])
+    system.setup_precond(cheb_degree=4, schur='dense', fhat='explicit',
+                         fp32_store=fp32, drop_tol=drop)
+    x = system.solve(small['rhsv'], small['rhsp'], rtol=1e-12, use_graph=True)
+    st = system.last_stats
+    assert st['status'] == 0 and st['true_relres'] <= 5e-12
+    assert st['iters'] <= 40
+    NV = small['F'].shape[0]
+    ref = small['ref']
+    assert np.linalg.norm(x[:NV] - ref[:NV]) <= 1e-9*np.linalg.norm(ref[:NV])
+    assert np.linalg.norm(x[NV:] - ref[NV:]) <= 1e-7*np.linalg.norm(ref[NV:])
     system.close()
 
 
