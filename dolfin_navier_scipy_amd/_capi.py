@@ -105,6 +105,8 @@ SIGNATURES = {
     'dns_saddle_apply': (ct.c_int, [_VP, c_double_p, c_double_p]),
     'dns_saddle_apply_precond': (ct.c_int, [_VP, c_double_p, c_double_p]),
     'dns_saddle_cheb_bounds': (ct.c_int, [_VP, c_double_p, c_double_p]),
+    'dns_saddle_probe': (ct.c_int, [_VP, ct.c_int32, ct.c_int32, ct.c_int32,
+                                    c_double_p]),
     'dns_default_precond_opts': (None, [ct.POINTER(dns_precond_opts)]),
     'dns_default_solve_opts': (None, [ct.POINTER(dns_solve_opts)]),
     'dns_imex_create': (ct.c_int, [_VP, ct.POINTER(dns_csr),

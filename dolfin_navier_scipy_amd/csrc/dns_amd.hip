@@ -75,7 +75,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
-                          sizeof(CtlHeader)));
+                          sizeof(CtlHeaderAcc)));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&scal_host),
                           16 * sizeof(double)));
     // J^T: given or formed here
@@ -514,7 +514,7 @@ int dns_saddle::ensure_workspace(int m) {
 }
 
 int dns_saddle::read_header() {
-    DNS_HIP(hipMemcpyAsync(hdr_host, ctl.p, sizeof(CtlHeader),
+    DNS_HIP(hipMemcpyAsync(hdr_host, ctl.p, sizeof(CtlHeaderAcc),
                            hipMemcpyDeviceToHost, stream));
     DNS_HIP(hipStreamSynchronize(stream));
     return DNS_OK;
@@ -674,6 +674,7 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     const int gran = std::max(1, o->check_every);
     int c = (last_iters >= 0) ? last_iters + 1 : std::min(m, 16);
     c = std::min(m, std::max(gran, (c + gran - 1) / gran * gran));
+    if (pipeline_c > 0) c = std::min(m, pipeline_c);
     // dots fused into the K apply while the system is launch-latency bound
     fuse_dots = n <= 400000;
     int restarts = 0;
@@ -694,6 +695,13 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             return enqueue_cycle(b, x, c, o);
         }));
         first = false;
+        if (pipeline_c > 0) {
+            // pipelined time stepping: one cycle, nobody waits; the device
+            // accumulates iterations / failures for the batch (k_arn_tail)
+            st->iters = -1;
+            st->status = DNS_OK;
+            return DNS_OK;
+        }
         DNS_TRY(read_header());
         if (hdr_host->status != DNS_OK || hdr_host->conv ||
             hdr_host->total_it >= o->maxiter || std::isnan(hdr_host->resnorm))
@@ -704,7 +712,7 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     const int total = hdr_host->total_it;
     last_iters = total;
     history.assign((size_t)std::max(1, hdr_host->hist_len), hdr_host->resnorm);
-    if (hdr_host->hist_len > 0) {
+    if (hdr_host->hist_len > 0 && want_history) {
         DNS_HIP(hipMemcpyAsync(history.data(), histdev.p,
                                history.size() * sizeof(double),
                                hipMemcpyDeviceToHost, stream));
@@ -1007,6 +1015,130 @@ int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
     DNS_TRY(h->apply_precond(h->xdev.p, h->z.p, h->zero_ptr(), nullptr));
     DNS_TRY(h->z.download(z, (size_t)h->n, h->stream));
     DNS_HIP(hipStreamSynchronize(h->stream));
+    return DNS_OK;
+}
+
+int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
+                     int32_t reps, double *us_per_launch) {
+    if (!h || !us_per_launch || chain < 1 || reps < 1)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    if (!h->precond_ready) return fail(DNS_ERR_NOT_READY, "no preconditioner");
+    DNS_HIP(hipSetDevice(h->device));
+    DNS_TRY(h->ensure_workspace(8));
+    if (h->histdev.n < 1024) DNS_TRY(h->histdev.alloc(1024));
+    h->hist_cap = h->histdev.n;
+    hipStream_t s = h->stream;
+    const int j = 3, n = h->n, nv = h->nv, np = h->np;
+    const bool dense = h->popts.schur == DNS_SCHUR_DENSE;
+    const int gridA = dense ? std::max(h->gridD, std::min(np, 2048)) : h->gridD;
+    double *zp = h->z.p + nv;
+    auto body = [&]() -> int {
+        // which == 8: the four kernels of one Arnoldi step in sequence;
+        // which = 1000 + 10 a + b: the pair (a, b) in sequence
+        int seq[4] = {which, 0, 0, 0};
+        int nseq = 1;
+        if (which == 8) {
+            nseq = 4;
+            for (int q = 0; q < 4; ++q) seq[q] = q;
+        } else if (which >= 1000) {
+            nseq = 2;
+            seq[0] = (which - 1000) / 10;
+            seq[1] = (which - 1000) % 10;
+        }
+        for (int k0 = 0; k0 < chain; ++k0) {
+            for (int sub = 0; sub < nseq; ++sub)
+            switch (seq[sub]) {
+                case 0:
+                    if (dense && h->fp32_store)
+                        hipLaunchKernelGGL(k_arn_head<2>, gridA, kBlock, 0, s, n,
+                                           nv, np, j, h->w.p, h->partN.p,
+                                           h->gridD, h->V.p, h->ld,
+                                           (const void *)h->sinv32.p, zp,
+                                           h->ctl.p, 1e-10, 0.0, h->partB.p,
+                                           h->gridS, 1 << 30);
+                    else
+                        hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, s, n,
+                                           nv, np, j, h->w.p, h->partN.p,
+                                           h->gridD, h->V.p, h->ld,
+                                           (const void *)h->sinv.p, zp,
+                                           h->ctl.p, 1e-10, 0.0, h->partB.p,
+                                           h->gridS, 1 << 30);
+                    break;
+                case 1:
+                    DNS_TRY(h->apply_fhat_part(h->V.p + (size_t)j * h->ld, zp,
+                                               h->z.p, h->zero_ptr(), nullptr));
+                    break;
+                case 2:
+                    DNS_LPR_SWITCH(
+                        h->K.lpr,
+                        hipLaunchKernelGGL(k_spmv_multidot<L>, h->gridC, kBlock,
+                                           0, s, n, h->K.rowptr.p,
+                                           h->K.colidx.p, h->K.vals.p, h->z.p,
+                                           h->w.p, h->V.p, h->ld, j,
+                                           h->partA.p, h->gridC, h->ctl.p));
+                    break;
+                case 3:
+                    hipLaunchKernelGGL(k_orth<0>, h->gridD, kBlock, 0, s, n,
+                                       h->V.p, h->ld, h->w.p, h->partA.p,
+                                       h->gridC, j, 0, h->partN.p, h->gridD,
+                                       h->ctl.p);
+                    break;
+                case 4:
+                    DNS_LPR_SWITCH(
+                        h->K.lpr,
+                        hipLaunchKernelGGL(k_resid_norm<L>, h->gridS, kBlock, 0,
+                                           s, n, h->K.rowptr.p, h->K.colidx.p,
+                                           h->K.vals.p, h->xdev.p, h->bdev.p,
+                                           h->r.p, h->partR.p, h->partB.p));
+                    break;
+                case 5:
+                    hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, s, 0,
+                                       h->partN.p, h->gridD, h->ctl.p,
+                                       h->histdev.p, 0, 1 << 30);
+                    break;
+                case 6:
+                    hipLaunchKernelGGL(k_basis_combine, h->gridD, kBlock, 0, s,
+                                       n, h->V.p, h->ld, h->ctl.p, h->u.p);
+                    break;
+                default:
+                    DNS_TRY(h->apply_precond(h->u.p, h->z.p, h->zero_ptr(),
+                                             nullptr));
+                    break;
+            }
+        }
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
+    };
+    // clear the stop flag so that the guarded kernels do their work, and make
+    // the convergence test of the head kernel unreachable (tol = -1)
+    {
+        CtlHeader hd;
+        memset(&hd, 0, sizeof(hd));
+        hd.tol = -1.0;
+        DNS_HIP(hipMemcpyAsync(h->ctl.p, &hd, sizeof(hd), hipMemcpyHostToDevice,
+                               s));
+        DNS_HIP(hipStreamSynchronize(s));
+    }
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    DNS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    DNS_HIP(hipStreamEndCapture(s, &g));
+    if (rc != DNS_OK) return rc;
+    DNS_HIP(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    DNS_HIP(hipGraphLaunch(ge, s));
+    DNS_HIP(hipStreamSynchronize(s));
+    DNS_HIP(hipEventRecord(h->ev0, s));
+    for (int r = 0; r < reps; ++r) DNS_HIP(hipGraphLaunch(ge, s));
+    DNS_HIP(hipEventRecord(h->ev1, s));
+    DNS_HIP(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    DNS_HIP(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+    const int per =
+        (which == 7) ? 2 : (which == 8 ? 4 : (which >= 1000 ? 2 : 1));
+    *us_per_launch = 1e3 * ms / ((double)reps * chain * per);
     return DNS_OK;
 }
 

@@ -344,6 +344,12 @@ k_arn_tail(int c, const double *__restrict__ norm_part, int nparts,
     for (int i = (hl > 0 ? 1 : 0); i <= jcols && hl < hist_cap; ++i)
         histbuf[hl++] = ctl->hist[i];
     ctl->hist_len = hl;
+    // bookkeeping for pipelined time stepping (one cycle per solve there; the
+    // host looks at these once per batch of steps instead of once per step)
+    ctl->acc_solves += 1;
+    ctl->acc_iters += ctl->total_it;
+    if (ctl->total_it > ctl->acc_maxit) ctl->acc_maxit = ctl->total_it;
+    if (!ctl->conv) ctl->acc_fail += 1;
 }
 
 // u = sum_{i<jdone} y_i V_i

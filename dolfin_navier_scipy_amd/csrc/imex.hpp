@@ -7,6 +7,7 @@ struct dns_imex {
     dns::CsrDev R1;
     // two solution-space vectors [v; p~] (current, previous) + work
     dns::DevBuf<double> xs[3];
+    dns::DevBuf<double> ck[2];     // checkpoint of (cur, prev) for a batch
     int cur = 0, prev = 1, work = 2;
     int nsol = 0;                  // how many valid solution vectors (0,1,2)
     dns::DevBuf<double> nfc[2];

@@ -24,6 +24,9 @@ struct DnsCtl {
     int hist_len;    // entries appended to the solve's residual history
     int conv;        // 1 once ||r|| <= tol was observed
     double beta, tol, resnorm, bnorm;
+    // accumulated over the solves of a pipelined batch of time steps (never
+    // reset by a solve; the host zeroes them at the start of a batch)
+    int acc_solves, acc_fail, acc_iters, acc_maxit;
     // BiCGStab scalars
     double rho, alpha, omega;
     double pad2;

@@ -112,6 +112,11 @@ struct CtlHeader {   // leading part of DnsCtl, copied back to the host
     double beta, tol, resnorm, bnorm;
 };
 
+struct CtlHeaderAcc {   // header + the batch accumulators behind it
+    CtlHeader h;
+    int acc_solves, acc_fail, acc_iters, acc_maxit;
+};
+
 // a captured chunk of work, replayed with hipGraphLaunch
 struct GraphEntry {
     std::vector<uint64_t> key;
@@ -160,6 +165,8 @@ struct dns_saddle {
     std::vector<double> history;
     int64_t spmv_count = 0;
     int last_iters = -1;              // iteration count of the previous solve
+    int pipeline_c = 0;               // > 0: one cycle of this length, no sync
+    bool want_history = true;         // copy the residual history back
     size_t hist_cap = 0;
     std::vector<dns::GraphEntry> graphs;
     typedef int (*enqueue_fn)(void *ctx);

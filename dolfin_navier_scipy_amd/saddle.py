@@ -113,6 +113,17 @@ class SaddleSystem(object):
                                                             st.est_relres))
         return out
 
+    PROBES = ('head', 'fhat', 'kapply_dots', 'orth', 'resid_norm', 'tail',
+              'combine', 'precond', 'arnoldi_step_seq')
+
+    def probe(self, which, chain=64, reps=20):
+        """microseconds per launch of one cycle kernel in a replayed graph"""
+        idx = self.PROBES.index(which) if isinstance(which, str) else which
+        out = ct.c_double(0.)
+        C.check(self.lib.dns_saddle_probe(self._h, idx, chain, reps,
+                                          ct.byref(out)))
+        return out.value
+
     def residual_history(self):
         cnt = ct.c_int32(0)
         C.check(self.lib.dns_saddle_residual_history(self._h, None, 0,

@@ -146,6 +146,12 @@ int dns_saddle_residual_history(dns_saddle *h, double *out, int32_t cap,
 int dns_saddle_apply(dns_saddle *h, const double *x, double *y);
 /* z = P^-1 r (parity checks of the preconditioner) */
 int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z);
+/* profiling aid: replay a hipGraph chain of `chain` identical launches of one
+ * kernel of the GMRES cycle on the handle's resident data (which: 0 head,
+ * 1 Fh^-1 part, 2 K apply + dots, 3 Gram-Schmidt update, 4 residual+norms,
+ * 5 tail, 6 basis combine, 7 Schur block) and report microseconds per launch */
+int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
+                     int32_t reps, double *us_per_launch);
 /* eigenvalue bounds used by the Chebyshev iteration */
 int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi);
 void dns_default_precond_opts(dns_precond_opts *o);
