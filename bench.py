@@ -95,9 +95,22 @@ def cpu_baseline(sm, rhsd, v0, nfc, dt, budget_s=12.0, max_steps=4000):
                 '2 triangular solves, rescale'.format(nsteps, tfac)), v, p
 
 
-def roofline_spmv(saddle, Kmat, reps, label):
+def pmc_traffic(Kmat):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes
+    (profiles/spmv_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950) -- only if they were taken on this very matrix"""
+    path = os.path.join(ROOT, 'profiles', 'spmv_traffic.json')
+    if not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get('nnz') != int(Kmat.nnz) or rec.get('rows') != Kmat.shape[0]:
+        return None
+    return rec['hbm_bytes_per_launch']
+
+
+def roofline_spmv(saddle, Kmat, reps, label, variants=('vector', 'stream')):
     best = None
-    for variant in ('vector', 'stream'):
+    for variant in variants:
         secs, chk = saddle.spmv_bench(Kmat, variant=variant, reps=reps,
                                       warmup=5)
         gbs = spmv_bytes(Kmat)/secs/1e9
@@ -118,13 +131,13 @@ def main():
     ap.add_argument('--Re', type=float, default=100.)
     ap.add_argument('--nts', type=int, default=512, help='dt = 1/nts')
     ap.add_argument('--method', default='gmres')
-    ap.add_argument('--cheb', type=int, default=4)
+    ap.add_argument('--cheb', type=int, default=6)
     ap.add_argument('--rtol', type=float, default=1e-10)
     ap.add_argument('--fp32', type=int, default=1,
                     help='store the explicit preconditioner matrices in fp32')
     ap.add_argument('--drop', type=float, default=3e-3,
                     help='relative drop tolerance of the explicit polynomial')
-    ap.add_argument('--reorth', type=int, default=1,
+    ap.add_argument('--reorth', type=int, default=0,
                     help='1: Gram-Schmidt applied twice (CGS2), 0: once')
     ap.add_argument('--fhat', default='auto',
                     help="F^-1 approximation: 'cheb' recurrence, 'explicit' "
@@ -132,7 +145,7 @@ def main():
     ap.add_argument('--check-every', type=int, default=2)
     ap.add_argument('--eager', action='store_true',
                     help='plain launches instead of hipGraph replay')
-    ap.add_argument('--roofline-refine', type=int, default=3,
+    ap.add_argument('--roofline-refine', type=int, default=4,
                     help='red refinements of the mesh for the HBM roofline '
                     'SpMV (0 disables)')
     ap.add_argument('--no-cpu', action='store_true')
@@ -211,19 +224,26 @@ def main():
     if rank == 0:
         value = world*args.steps/wall
         roof = roofline_spmv(saddle, saddle_csr(F, J), 200,
-                             'K at the benchmark size (cache resident)')
+                             'K at the benchmark size (cache resident)',
+                             variants=('vector',))
         roof_hbm = None
         if args.roofline_refine > 0:
             _, smr, _ = build_problem(N=args.level, Re=args.Re,
                                       refine=args.roofline_refine)
             Kr = saddle_csr((smr['M'] + .5*dt*smr['A']).tocsr(), smr['J'])
+            # only the LDS-streaming kernel runs on the refined matrix, so its
+            # rocprofv3 average is this measurement and nothing else
             roof_hbm = roofline_spmv(
                 saddle, Kr, 30, 'K on the mesh refined {0}x (n={1})'.format(
-                    args.roofline_refine, Kr.shape[0]))
+                    args.roofline_refine, Kr.shape[0]), variants=('stream',))
+            traffic = pmc_traffic(Kr)
+        else:
+            traffic = None
         main_roof = roof_hbm if roof_hbm is not None else roof
         roofline = dict(bound='hbm', achieved=main_roof['achieved'],
                         peak=HBM_PEAK_GBS, unit='GB/s',
-                        frac=main_roof['achieved']/HBM_PEAK_GBS, traffic=None,
+                        frac=main_roof['achieved']/HBM_PEAK_GBS,
+                        traffic=traffic,
                         kernel=main_roof['kernel'], detail=main_roof,
                         at_benchmark_size=roof)
         cpu = None

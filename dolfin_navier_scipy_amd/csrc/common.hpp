@@ -91,8 +91,8 @@ struct CsrDev {
     DevBuf<int> rowptr, colidx;
     DevBuf<double> vals;
     // row-block table of the LDS-streaming kernel (built on the host)
-    DevBuf<int> rowblocks;
-    int nrowblocks = 0;
+    DevBuf<int> rowblocks_t[3];   // tiles of 1024 / 2048 / 4096 non-zeros
+    int nrowblocks_t[3] = {0, 0, 0};
 
     int upload(const dns_csr *a, hipStream_t s);
 };

@@ -153,21 +153,32 @@ k_spmv_vec(int nrows, const int *__restrict__ rowptr,
 // with G lanes per row.
 // ---------------------------------------------------------------------------
 constexpr int kStreamNnz = 2048;     // products per LDS tile (16 KiB)
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef int v2i32 __attribute__((ext_vector_type(2)));
 
-template <int G>
+template <int G, int TILE = kStreamNnz, int UNR = 4, int RPS = 0>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
               const int *__restrict__ rowptr, const int *__restrict__ colidx,
               const double *__restrict__ vals, const double *__restrict__ x,
               double *__restrict__ y, double alpha, double beta,
               const double *__restrict__ b) {
-    __shared__ double prod[kStreamNnz];
+    __shared__ double prod[TILE];
     __shared__ double red[4];
-    for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    __shared__ int rps[kBlock + 1];   // RPS: the block's row pointers
+    // XCD-aware start: workgroups b, b+8, b+16, ... land on the same XCD
+    // (round-robin dispatch over the 8 XCDs), so give each residue class a
+    // CONTIGUOUS range of row blocks: the x entries a class gathers then form
+    // one window of ~n/8 entries that fits that XCD's private 4 MiB L2
+    // (speed only -- any placement computes the same result).
+    const int gq = gridDim.x / 8, gr = gridDim.x % 8;
+    const int cls = blockIdx.x % 8;
+    const int vb = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
+    for (int blk = vb; blk < nblocks; blk += gridDim.x) {
         const int r0 = rowblocks[blk], r1 = rowblocks[blk + 1];
         const int k0 = rowptr[r0], k1 = rowptr[r1];
         const int nn = k1 - k0;
-        if (nn > kStreamNnz) {
+        if (nn > TILE) {
             // a single long row: block-wide strided dot product
             double s = 0.0;
             for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
@@ -178,14 +189,26 @@ k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
             continue;
         }
         __syncthreads();             // previous tile fully consumed
-#pragma unroll 4
+        const int nr = r1 - r0;
+        // the block's row pointers ride along with the value stream (one
+        // coalesced load) so that phase 2 starts from LDS, not from a
+        // dependent global load
+        if (RPS) {
+            if (threadIdx.x < nr)
+                rps[threadIdx.x] = rowptr[r0 + threadIdx.x] - k0;
+            if (threadIdx.x == 0) rps[nr] = nn;
+        }
+        // lane-contiguous 8-byte value / 4-byte index loads (measured faster
+        // here than 16-byte pair loads, whose LDS writes conflict 2-way, and
+        // than non-temporal loads, which lose the Infinity Cache at mid sizes)
+#pragma unroll UNR
         for (int k = threadIdx.x; k < nn; k += kBlock)
             prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
         __syncthreads();
-        const int nr = r1 - r0;
         const int g = threadIdx.x % G, rsub = threadIdx.x / G;
         for (int r = rsub; r < nr; r += kBlock / G) {
-            const int a0 = rowptr[r0 + r] - k0, a1 = rowptr[r0 + r + 1] - k0;
+            const int a0 = RPS ? rps[r] : rowptr[r0 + r] - k0;
+            const int a1 = RPS ? rps[r + 1] : rowptr[r0 + r + 1] - k0;
             double s = 0.0;
             for (int k = a0 + g; k < a1; k += G) s += prod[k];
             s = subwave_sum<G>(s);

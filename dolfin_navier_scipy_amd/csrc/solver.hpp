@@ -41,34 +41,72 @@ inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
     nnz = a->nnz;
     lpr = pick_lpr(nrows > 0 ? (double)nnz / nrows : 1.0);
     DNS_TRY(rowptr.alloc((size_t)nrows + 1));
-    DNS_TRY(colidx.alloc((size_t)nnz));
-    DNS_TRY(vals.alloc((size_t)nnz));
+    // two spare entries: k_spmv_stream reads (value, index) PAIRS on the
+    // even-aligned stream and may touch one entry past the last non-zero
+    DNS_TRY(colidx.alloc((size_t)nnz + 2));
+    DNS_TRY(vals.alloc((size_t)nnz + 2));
+    DNS_HIP(hipMemsetAsync(colidx.p + nnz, 0, 2 * sizeof(int), s));
+    DNS_HIP(hipMemsetAsync(vals.p + nnz, 0, 2 * sizeof(double), s));
     DNS_TRY(rowptr.upload(a->rowptr, (size_t)nrows + 1, s));
     DNS_TRY(colidx.upload(a->colidx, (size_t)nnz, s));
     DNS_TRY(vals.upload(a->vals, (size_t)nnz, s));
     // row blocks of the LDS-streaming kernel: consecutive rows with at most
-    // kStreamNnz non-zeros and at most kBlock rows; a longer row stands alone
-    std::vector<int> rb;
-    rb.push_back(0);
-    int start = 0;
-    while (start < nrows) {
-        int end = start;
-        int64_t acc = 0;
-        while (end < nrows && (end - start) < kBlock) {
-            const int64_t len = a->rowptr[end + 1] - a->rowptr[end];
-            if (acc + len > kStreamNnz) break;
-            acc += len;
-            ++end;
+    // TILE non-zeros and at most kBlock rows; a longer row stands alone
+    // (tables for the three tile sizes the tuning variants use)
+    const int tiles[3] = {1024, 2048, 4096};
+    for (int t = 0; t < 3; ++t) {
+        std::vector<int> rb;
+        rb.push_back(0);
+        int start = 0;
+        while (start < nrows) {
+            int end = start;
+            int64_t acc = 0;
+            while (end < nrows && (end - start) < kBlock) {
+                const int64_t len = a->rowptr[end + 1] - a->rowptr[end];
+                if (acc + len > tiles[t]) break;
+                acc += len;
+                ++end;
+            }
+            if (end == start) end = start + 1;   // single long row
+            rb.push_back(end);
+            start = end;
         }
-        if (end == start) end = start + 1;   // single long row
-        rb.push_back(end);
-        start = end;
+        nrowblocks_t[t] = (int)rb.size() - 1;
+        DNS_TRY(rowblocks_t[t].alloc(rb.size()));
+        DNS_TRY(rowblocks_t[t].upload(rb.data(), rb.size(), s));
+        DNS_HIP(hipStreamSynchronize(s));       // `rb` is a loop temporary
     }
-    nrowblocks = (int)rb.size() - 1;
-    DNS_TRY(rowblocks.alloc(rb.size()));
-    DNS_TRY(rowblocks.upload(rb.data(), rb.size(), s));
-    DNS_HIP(hipStreamSynchronize(s));       // `rb` is a stack temporary
     return DNS_OK;
+}
+
+template <int TILE, int UNR, int RPS, int GOVR>
+inline void launch_stream_g(const CsrDev &A, int t, const double *x, double *y,
+                            double alpha, double beta, const double *b,
+                            hipStream_t s) {
+    const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
+    const int nb = A.nrowblocks_t[t];
+    const int grid = std::min(nb, 65535);
+    const int *rbp = A.rowblocks_t[t].p;
+    if (GOVR > 0)
+        hipLaunchKernelGGL((k_spmv_stream<(GOVR > 0 ? GOVR : 4), TILE, UNR, RPS>),
+                           grid, kBlock, 0, s, nb, rbp, A.rowptr.p, A.colidx.p,
+                           A.vals.p, x, y, alpha, beta, b);
+    else if (avg <= 6)
+        hipLaunchKernelGGL((k_spmv_stream<1, TILE, UNR, RPS>), grid, kBlock, 0,
+                           s, nb, rbp, A.rowptr.p, A.colidx.p, A.vals.p, x, y,
+                           alpha, beta, b);
+    else if (avg <= 12)
+        hipLaunchKernelGGL((k_spmv_stream<2, TILE, UNR, RPS>), grid, kBlock, 0,
+                           s, nb, rbp, A.rowptr.p, A.colidx.p, A.vals.p, x, y,
+                           alpha, beta, b);
+    else if (avg <= 48)
+        hipLaunchKernelGGL((k_spmv_stream<4, TILE, UNR, RPS>), grid, kBlock, 0,
+                           s, nb, rbp, A.rowptr.p, A.colidx.p, A.vals.p, x, y,
+                           alpha, beta, b);
+    else
+        hipLaunchKernelGGL((k_spmv_stream<16, TILE, UNR, RPS>), grid, kBlock, 0,
+                           s, nb, rbp, A.rowptr.p, A.colidx.p, A.vals.p, x, y,
+                           alpha, beta, b);
 }
 
 // y = alpha*A*x + beta*b on `s` (device pointers)
@@ -77,24 +115,21 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                        hipStream_t s) {
     if (A.nrows == 0) return DNS_OK;
     if (variant == DNS_SPMV_STREAM) {
-        const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
-        const int grid = std::min(A.nrowblocks, 65535);
-        if (avg <= 6)
-            hipLaunchKernelGGL(k_spmv_stream<1>, grid, kBlock, 0, s,
-                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
-                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
-        else if (avg <= 12)
-            hipLaunchKernelGGL(k_spmv_stream<2>, grid, kBlock, 0, s,
-                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
-                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
-        else if (avg <= 48)
-            hipLaunchKernelGGL(k_spmv_stream<4>, grid, kBlock, 0, s,
-                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
-                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
-        else
-            hipLaunchKernelGGL(k_spmv_stream<16>, grid, kBlock, 0, s,
-                               A.nrowblocks, A.rowblocks.p, A.rowptr.p,
-                               A.colidx.p, A.vals.p, x, y, alpha, beta, b);
+        // tile 2048, 2 loads in flight per lane, row pointers staged in LDS:
+        // the winner of scripts/spmv_tune.py on the 0.98 GB refined matrix
+        launch_stream_g<2048, 2, 1, 0>(A, 1, x, y, alpha, beta, b, s);
+    } else if (variant >= 16 && variant < 32) {
+        // tuning variants (scripts/spmv_tune.py), all on the 2048 tile
+        switch (variant - 16) {
+            case 0: launch_stream_g<2048, 2, 0, 0>(A, 1, x, y, alpha, beta, b, s); break;
+            case 1: launch_stream_g<2048, 2, 1, 0>(A, 1, x, y, alpha, beta, b, s); break;
+            case 2: launch_stream_g<2048, 2, 1, 8>(A, 1, x, y, alpha, beta, b, s); break;
+            case 3: launch_stream_g<2048, 2, 0, 8>(A, 1, x, y, alpha, beta, b, s); break;
+            case 4: launch_stream_g<2048, 1, 1, 0>(A, 1, x, y, alpha, beta, b, s); break;
+            case 5: launch_stream_g<2048, 4, 1, 0>(A, 1, x, y, alpha, beta, b, s); break;
+            case 6: launch_stream_g<2048, 2, 1, 2>(A, 1, x, y, alpha, beta, b, s); break;
+            default: launch_stream_g<4096, 2, 1, 0>(A, 2, x, y, alpha, beta, b, s); break;
+        }
     } else {
         const int grid = grid_for_rows(A.nrows, A.lpr);
         DNS_LPR_SWITCH(A.lpr,

@@ -12,10 +12,12 @@ forms:
  * `N1(u0)` = inner(grad(u)*u0, v) dx, `N2(u0)` = inner(grad(u0)*u, v) dx
                                                  (dts:358-359)
 
-Degrees of freedom: P2 nodes are the mesh vertices followed by the edge
-midpoints; velocity dof `2*node + component`; pressure dof = vertex index.
-The numbering differs from dolfin's -- parity is with the reference
-*algorithm* on identical matrices, not with dolfin's assembly.
+Degrees of freedom: P2 nodes (mesh vertices and edge midpoints) are renumbered
+by reverse Cuthill-McKee, as dolfin's default `reorder_dofs_serial` does for
+the reference's matrices; velocity dof `2*node + component`; pressure dofs
+follow the order of their vertices.  The numbering still differs from
+dolfin's -- parity is with the reference *algorithm* on identical matrices,
+not with dolfin's assembly.
 """
 import numpy as np
 import scipy.sparse as sps
@@ -59,7 +61,7 @@ def _p2_dbasis_dlam(lam):
 class TaylorHood(object):
     """Taylor-Hood spaces on a `Mesh2D` and the forms of the NSE"""
 
-    def __init__(self, mesh):
+    def __init__(self, mesh, reorder=True):
         self.mesh = mesh
         edges, celledges, nadj = mesh.edges()
         self.edges, self.celledges, self.edge_nadj = edges, celledges, nadj
@@ -67,9 +69,33 @@ class TaylorHood(object):
         self.nnodes = nv + edges.shape[0]
         self.vdim = 2*self.nnodes
         self.pdim = nv
-        self.cellnodes = np.hstack([mesh.cells, nv + celledges])  # (nc, 6)
-        self.nodecoords = np.vstack(
+        cellnodes = np.hstack([mesh.cells, nv + celledges])       # (nc, 6)
+        nodecoords = np.vstack(
             [mesh.verts, 0.5*(mesh.verts[edges[:, 0]]+mesh.verts[edges[:, 1]])])
+        # locality-preserving dof numbering (what dolfin's default
+        # `reorder_dofs_serial` gives the reference's matrices): reverse
+        # Cuthill-McKee on the P2 node graph; pressure dofs follow the order
+        # of their vertices in it
+        if reorder:
+            from scipy.sparse.csgraph import reverse_cuthill_mckee
+            nn = self.nnodes
+            r = np.repeat(cellnodes, 6, axis=1).ravel()
+            c = np.tile(cellnodes, (1, 6)).ravel()
+            graph = sps.coo_matrix((np.ones(r.size, dtype=np.int8), (r, c)),
+                                   shape=(nn, nn)).tocsr()
+            order = reverse_cuthill_mckee(graph, symmetric_mode=True)
+            newid = np.empty(nn, dtype=np.int64)
+            newid[order] = np.arange(nn)
+        else:
+            newid = np.arange(self.nnodes, dtype=np.int64)
+        self.node_newid = newid                  # (vertex|edge id) -> P2 node
+        self.cellnodes = newid[cellnodes]
+        self.nodecoords = np.empty_like(nodecoords)
+        self.nodecoords[newid] = nodecoords
+        vorder = np.argsort(newid[:nv])
+        self.vert_pdof = np.empty(nv, dtype=np.int64)
+        self.vert_pdof[vorder] = np.arange(nv)   # vertex -> pressure dof
+        self.cellpdofs = self.vert_pdof[mesh.cells]                 # (nc, 3)
         # geometry: gradients of the barycentric coordinates, (nc, 3, 2)
         p = mesh.verts[mesh.cells]
         self.area = mesh.cell_areas()
@@ -128,12 +154,12 @@ class TaylorHood(object):
         A = self._assemble(rows, cols, np.array(av), (self.vdim, self.vdim))
         # divergence: J[q_a, (b,c)] = int psi_a d_c phi_b
         jloc = np.einsum('cq,qa,cqbd->cabd', w, psi, gphi)      # (nc,3,6,2)
-        jr = np.broadcast_to(self.mesh.cells[:, :, None, None], (nc, 3, 6, 2))
+        jr = np.broadcast_to(self.cellpdofs[:, :, None, None], (nc, 3, 6, 2))
         jc = np.broadcast_to(vd[:, None, :, :], (nc, 3, 6, 2))
         J = self._assemble(jr, jc, jloc, (self.pdim, self.vdim))
         mploc = np.einsum('cq,qa,qb->cab', w, psi, psi)
-        pr = np.broadcast_to(self.mesh.cells[:, :, None], (nc, 3, 3))
-        pc = np.broadcast_to(self.mesh.cells[:, None, :], (nc, 3, 3))
+        pr = np.broadcast_to(self.cellpdofs[:, :, None], (nc, 3, 3))
+        pc = np.broadcast_to(self.cellpdofs[:, None, :], (nc, 3, 3))
         MP = self._assemble(pr, pc, mploc, (self.pdim, self.pdim))
         return dict(M=M, A=A, J=J, JT=sps.csr_matrix(J.T), MP=MP)
 
@@ -183,8 +209,8 @@ class TaylorHood(object):
     def boundary_nodes(self):
         """P2 nodes on the boundary and their coordinates"""
         bedges = np.where(self.edge_nadj == 1)[0]
-        nodes = np.unique(np.concatenate(
-            [self.edges[bedges].ravel(), self.mesh.nverts + bedges]))
+        nodes = np.unique(self.node_newid[np.concatenate(
+            [self.edges[bedges].ravel(), self.mesh.nverts + bedges])])
         return nodes, self.nodecoords[nodes]
 
     def cylinderwake_bcs(self, xmin=0.0, xmax=2.2, ymin=0.0, ymax=0.41,

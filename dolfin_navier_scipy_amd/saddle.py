@@ -275,7 +275,8 @@ def spmv_bench(A, variant='stream', reps=50, warmup=5, device=0):
     """average seconds per `y = A x` on resident data, and `||y||^2`"""
     view = C.CsrView(sps.csr_matrix(A))
     secs, chk = ct.c_double(0.), ct.c_double(0.)
+    vid = _VARIANTS[variant] if isinstance(variant, str) else int(variant)
     C.check(C.load_library().dns_spmv_bench(
-        device, view.byref(), _VARIANTS[variant], int(reps), int(warmup),
+        device, view.byref(), vid, int(reps), int(warmup),
         ct.byref(secs), ct.byref(chk)))
     return secs.value, chk.value
