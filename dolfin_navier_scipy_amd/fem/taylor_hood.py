@@ -116,11 +116,12 @@ class TaylorHood(object):
         """cell velocity dofs `(nc, 6, 2)`"""
         return 2*self.cellnodes[:, :, None] + np.arange(2)[None, None, :]
 
-    def _assemble(self, rows, cols, vals, shape):
+    def _assemble(self, rows, cols, vals, shape, keep_pattern=False):
         mat = sps.coo_matrix((vals.ravel(), (rows.ravel(), cols.ravel())),
                              shape=shape).tocsr()
         mat.sum_duplicates()
-        mat.eliminate_zeros()   # as `mat_dolfin2sparse`, reference dts:80
+        if not keep_pattern:
+            mat.eliminate_zeros()   # as `mat_dolfin2sparse`, reference dts:80
         mat.sort_indices()
         return mat
 
@@ -182,8 +183,12 @@ class TaylorHood(object):
         np.add.at(fvec, self._vdofs().ravel(), floc.ravel())
         return fvec.reshape((-1, 1))
 
-    def convection_mats(self, u0vec):
-        """`N1(u0), N2(u0), N(u0)u0` on the full space (dts:325-376)"""
+    def convection_mats(self, u0vec, keep_pattern=False):
+        """`N1(u0), N2(u0), N(u0)u0` on the full space (dts:325-376)
+
+        `keep_pattern`: keep the structural pattern (explicit zeros) so that
+        `A + N(v)` has ONE sparsity pattern for every `v` -- what lets the
+        device keep the system resident and only re-value it per step"""
         nc = self.mesh.ncells
         uq, guq = self._vel_at_qp(u0vec)
         w = _QW[None, :]*self.area[:, None]
@@ -201,8 +206,10 @@ class TaylorHood(object):
                 v1.append(n1loc if c == d else np.zeros_like(n1loc))
                 v2.append(n2loc[:, :, :, d, c])
         rows, cols = np.array(rows), np.array(cols)
-        N1 = self._assemble(rows, cols, np.array(v1), (self.vdim, self.vdim))
-        N2 = self._assemble(rows, cols, np.array(v2), (self.vdim, self.vdim))
+        N1 = self._assemble(rows, cols, np.array(v1), (self.vdim, self.vdim),
+                            keep_pattern=keep_pattern)
+        N2 = self._assemble(rows, cols, np.array(v2), (self.vdim, self.vdim),
+                            keep_pattern=keep_pattern)
         return N1, N2, self.convection_vec(u0vec)
 
     # -- boundary conditions ---------------------------------------------

@@ -1,0 +1,135 @@
+"""Newton/Picard trapezoidal sweeps (reference snu:1016-1047, 1304-1566).
+
+CPU part: the oracle restatement satisfies its defining equations (the branch
+cannot be executed in the reference -- dolfin + bit rot -- so it is pinned by
+definition, see oracle/newton_picard_oracle.py).  GPU part: the same sweeps
+with every saddle solve going through the drop-in `lin_alg_utils` (re-valued
+`M + dt/2 (A + N(v))`, same pattern every step) reproduce the oracle.
+"""
+import numpy as np
+import pytest
+
+import scenarios
+from oracle import newton_picard_oracle as npo
+from oracle import imex_oracle
+
+
+@pytest.fixture(scope='module')
+def setup(toy_prob):
+    th, smc, rhsd = toy_prob['th'], toy_prob['smc'], toy_prob['rhsd']
+    inv, dbcinds, dbcvals = (toy_prob['invinds'], toy_prob['dbcinds'],
+                             toy_prob['dbcvals'])
+    M, A, J = smc['M'], smc['A'], smc['J']
+    NP, NV = J.shape
+
+    def appnd(vvec):
+        full = np.zeros((th.vdim, 1))
+        full[inv] = vvec
+        full[dbcinds, 0] = dbcvals
+        return full
+
+    bcsv = np.zeros((th.vdim, 1))
+    bcsv[dbcinds, 0] = dbcvals
+
+    def conv(vfull, picard):
+        """algebraic `get_v_conv_conts` (snu:109-133) + `condense_velmatsbybcs`
+        (dts:610-642)"""
+        if vfull.shape[0] == NV:
+            vfull = appnd(vfull)
+        N1, N2, fv3 = th.convection_mats(vfull, keep_pattern=True)
+        Nm = N1 if picard else (N1 + N2)
+        Nc = Nm[inv, :][:, inv].tocsr()
+        rhsbc = -(Nm @ bcsv)[inv, :]
+        return Nc, (0.*fv3[inv, :] if picard else fv3[inv, :]), rhsbc
+
+    kw, rec, aux = scenarios.build(variant='plain', seed=0, Nts=6, tE=0.03,
+                                   prob=toy_prob)
+    imex_oracle.cnab(**kw)          # semi-explicit run = first lin. points
+    times, vels, _ = rec.arrays()
+    lin0 = {t: vels[k].reshape((-1, 1)) for k, t in enumerate(times)}
+    return dict(M=M, A=A, J=J, fv=rhsd['fv'], fp=rhsd['fp'], conv=conv,
+                appnd=appnd, trange=kw['trange'], iniv=kw['inivel'], lin0=lin0,
+                inv=inv, NV=NV, NP=NP)
+
+
+def _sweep_kwargs(s):
+    return dict(M=s['M'], A=s['A'], J=s['J'], fv=s['fv'], fp=s['fp'],
+                conv=s['conv'], appndbcs=s['appnd'])
+
+
+def test_oracle_trapezoidal_residual_and_newton_convergence(setup):
+    s = setup
+    vdict, pdict, hist = npo.newton_picard(
+        s['trange'], s['iniv'], s['lin0'], vel_pcrd_stps=1, vel_nwtn_stps=3,
+        invinds=s['inv'], **_sweep_kwargs(s))
+    kinds = [h[0] for h in hist]
+    assert kinds[0] == 'picard' and 'newton' in kinds
+    upd = [h[1] for h in hist]
+    # Newton updates contract quadratically-ish: each at least 30x smaller
+    assert upd[-1] < upd[0]*1e-3
+    # converged sweep: nonlinear trapezoidal residual of every step
+    M, A, J, conv, appnd = s['M'], s['A'], s['J'], s['conv'], s['appnd']
+    tr = s['trange']
+    for k in range(1, len(tr)):
+        dt = tr[k] - tr[k-1]
+        vn, vc = vdict[tr[k]], vdict[tr[k-1]]
+        # full convection N(v)v at both ends (Newton form evaluated at itself)
+        Nn, rcn, rbn = conv(appnd(vn), False)
+        Nc, rcc, rbc = conv(appnd(vc), False)
+        # N1 v + N2 v - N(v)v = N(v) v  at the linearisation point
+        res = M @ (vn - vc) + .5*dt*((A @ vn) + (Nn @ vn) - rcn - rbn
+                                     + (A @ vc) + (Nc @ vc) - rcc - rbc
+                                     - 2*s['fv']) - dt*(J.T @ pdict[tr[k]])
+        assert np.abs(res).max() <= 5e-8*np.abs(M @ vn).max()
+        assert np.abs(J @ vn - s['fp']).max() <= 1e-10
+
+
+def test_oracle_get_pfromv_consistency(setup):
+    """reference tests/test_units_pfromv.py:45 in algebraic form: the pressure
+    recomputed from a velocity satisfies the momentum equation's projection"""
+    s = setup
+    v = s['iniv']
+    p = npo.get_pfromv(v=v, M=s['M'], A=s['A'], J=s['J'], fv=s['fv'],
+                       conv=s['conv'], appndbcs=s['appnd'])
+    assert p.shape == (s['NP'], 1)
+    # by construction M a + J^T p~ = rhs with J a = 0
+    _, rc, _ = s['conv'](s['appnd'](v), False)
+    rhs = -(s['A'] @ v) - rc + s['fv']
+    from oracle import saddle_oracle
+    ap = saddle_oracle.solve_sadpnt_smw(amat=s['M'], jmat=s['J'], rhsv=rhs)
+    assert np.allclose(-ap[s['NV']:], p)
+    assert np.abs(s['J'] @ ap[:s['NV']]).max() <= 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('krylovini', [None, 'upd'])
+def test_gpu_sweeps_match_oracle(setup, krylovini):
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau, _capi
+    assert _capi.device_count() > 0
+    s = setup
+    ref_v, ref_p, _ = npo.trapezoidal_sweep(
+        s['trange'], s['iniv'], linpoints=s['lin0'], picard=False,
+        **_sweep_kwargs(s))
+    lau.clear_cache()
+    got_v, got_p, _ = npo.trapezoidal_sweep(
+        s['trange'], s['iniv'], linpoints=s['lin0'], picard=False,
+        solve=lau.solve_sadpnt_smw, krylovini=krylovini, **_sweep_kwargs(s))
+    # ONE resident system re-valued every step (same pattern), not one per step
+    assert len(lau._cache) == 1
+    for t in s['trange'][1:]:
+        ev = np.linalg.norm(got_v[t] - ref_v[t])/np.linalg.norm(ref_v[t])
+        ep = np.linalg.norm(got_p[t] - ref_p[t])/np.linalg.norm(ref_p[t])
+        assert ev <= 1e-8 and ep <= 1e-6, (t, ev, ep)
+    lau.clear_cache()
+
+
+@pytest.mark.gpu
+def test_gpu_get_pfromv(setup):
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    s = setup
+    args = dict(v=s['iniv'], M=s['M'], A=s['A'], J=s['J'], fv=s['fv'],
+                conv=s['conv'], appndbcs=s['appnd'])
+    ref = npo.get_pfromv(**args)
+    got = npo.get_pfromv(solve=lau.solve_sadpnt_smw, **args)
+    assert np.linalg.norm(got - ref) <= 1e-7*np.linalg.norm(ref)
+    lau.clear_cache()
