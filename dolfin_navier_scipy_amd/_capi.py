@@ -83,6 +83,10 @@ class dns_imex_coeffs(ct.Structure):
 
 # every symbol include/dns_amd.h declares: name -> (restype, argtypes)
 _VP = ct.c_void_p
+ALLREDUCE_CB = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int32)
+ALLGATHERV_CB = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, c_int32_p,
+                             ct.c_int32)
+UNIQUE_ID_BYTES = 128
 SIGNATURES = {
     'dns_version': (ct.c_int, []),
     'dns_status_string': (ct.c_char_p, [ct.c_int]),
@@ -107,6 +111,20 @@ SIGNATURES = {
     'dns_saddle_cheb_bounds': (ct.c_int, [_VP, c_double_p, c_double_p]),
     'dns_saddle_probe': (ct.c_int, [_VP, ct.c_int32, ct.c_int32, ct.c_int32,
                                     c_double_p]),
+    'dns_comm_unique_id': (ct.c_int, [ct.c_char_p]),
+    'dns_comm_create_rccl': (ct.c_int, [ct.c_int, ct.c_int32, ct.c_int32,
+                                        ct.c_char_p, ct.POINTER(_VP)]),
+    'dns_comm_create_callbacks': (ct.c_int, [ct.c_int, ct.c_int32, ct.c_int32,
+                                             ALLREDUCE_CB, ALLGATHERV_CB, _VP,
+                                             ct.POINTER(_VP)]),
+    'dns_comm_destroy': (None, [_VP]),
+    'dns_comm_stats': (ct.c_int, [_VP, ct.POINTER(ct.c_int64),
+                                  ct.POINTER(ct.c_int64)]),
+    'dns_saddle_set_comm': (ct.c_int, [_VP, _VP]),
+    'dns_partition_range': (ct.c_int, [ct.c_int32, ct.c_int32, ct.c_int32,
+                                       c_int32_p, c_int32_p]),
+    'dns_device_read': (ct.c_int, [ct.c_int, _VP, _VP, ct.c_size_t]),
+    'dns_device_write': (ct.c_int, [ct.c_int, _VP, _VP, ct.c_size_t]),
     'dns_default_precond_opts': (None, [ct.POINTER(dns_precond_opts)]),
     'dns_default_solve_opts': (None, [ct.POINTER(dns_solve_opts)]),
     'dns_imex_create': (ct.c_int, [_VP, ct.POINTER(dns_csr),

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['dns_amd.hip']
 HEADERS = ['common.hpp', 'kernels.hpp', 'bicgstab_kernels.hpp', 'solver.hpp',
-           'hostcsr.hpp', 'gmres_kernels.hpp',
+           'hostcsr.hpp', 'gmres_kernels.hpp', 'comm.hpp',
            'imex.hpp', 'imex_capi.inc',
            os.path.join('..', '..', 'include', 'dns_amd.h')]
 LIB = os.path.join(CSRC, 'libdnsamd.so')
@@ -36,7 +36,8 @@ def build_library(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-           '-shared', '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           '-shared', '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES] \
+        + ['-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

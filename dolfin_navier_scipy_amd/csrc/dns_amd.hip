@@ -149,6 +149,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     DNS_TRY(bctl.alloc(1));
     DNS_TRY(bctl.zero(stream));
     DNS_TRY(scal.alloc(16));
+    DNS_TRY(dsum.alloc(kMaxRestart + 8));
     DNS_TRY(cheb_r.alloc((size_t)nv));
     DNS_TRY(cheb_d0.alloc((size_t)nv));
     DNS_TRY(cheb_d1.alloc((size_t)nv));
@@ -250,19 +251,24 @@ int dns_saddle::estimate_bounds() {
     return DNS_OK;
 }
 
+// Chebyshev recurrence for zv = Fh^-1 (rv - JT zp).  In the row-partitioned
+// solve a rank updates only its velocity rows; the direction vector every
+// rank needs in full for the next F apply is all-gathered after each step.
 static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
                       const int *jsel, const double *zp, double *zv,
                       const int *guard) {
     const int deg = h->popts.cheb_degree;
-    const int gj = grid_for_rows(h->nv, h->JT.lpr);
+    const int v0 = h->v0(), v1 = h->v1();
+    const int gj = grid_for_rows(v1 - v0, h->JT.lpr);
     double *d0 = (deg == 1) ? zv : h->cheb_d0.p;
     DNS_LPR_SWITCH(h->JT.lpr,
                    hipLaunchKernelGGL(k_cheb_init<L>, gj, kBlock, 0, h->stream,
                                       h->nv, h->JT.rowptr.p, h->JT.colidx.p,
                                       h->JT.vals.p, zp, rbase, ldr, jsel,
                                       h->dinv.p, 1.0 / h->theta, h->cheb_r.p,
-                                      d0, guard));
-    const int gf = grid_for_rows(h->nv, h->F.lpr);
+                                      d0, guard, v0, v1));
+    if (h->dist()) DNS_TRY(h->comm->allgatherv(d0, h->st_v, h->stream));
+    const int gf = grid_for_rows(v1 - v0, h->F.lpr);
     double *dbuf[2] = {h->cheb_d0.p, h->cheb_d1.p};
     for (int s = 0; s < deg - 1; ++s) {
         const int first = (s == 0), last = (s == deg - 2);
@@ -272,7 +278,10 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
                                h->F.rowptr.p, h->F.colidx.p, h->F.vals.p,
                                h->dinv.p, dbuf[s & 1], dbuf[(s + 1) & 1],
                                h->cheb_r.p, zv, h->c1[s], h->c2[s], first,
-                               last, guard));
+                               last, guard, v0, v1));
+        if (h->dist())
+            DNS_TRY(h->comm->allgatherv(last ? zv : dbuf[(s + 1) & 1], h->st_v,
+                                        h->stream));
         h->spmv_count++;
     }
     DNS_HIP(hipGetLastError());
@@ -284,27 +293,31 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
 int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
                                 double *zv, const int *guard, double *xacc) {
     if (fhat_explicit) {
-        const int g = grid_for_rows(nv, Gc.lpr);
+        const int r0 = v0(), r1 = v1();
+        const int g = grid_for_rows(r1 - r0, Gc.lpr);
+        // fused correction only on one GPU (every rank needs ALL of x)
+        double *xa = dist() ? nullptr : xacc;
         if (fp32_store) {
             DNS_LPR_SWITCH(
                 Gc.lpr,
                 hipLaunchKernelGGL((k_spmv_split<L, float>), g, kBlock, 0,
                                    stream, nv, Gc.rowptr.p, Gc.colidx.p,
                                    gc32.p, rvec, (size_t)0, zero_ptr(), zp, zv,
-                                   guard, xacc));
+                                   guard, xa, r0, r1));
         } else {
             DNS_LPR_SWITCH(
                 Gc.lpr,
                 hipLaunchKernelGGL((k_spmv_split<L, double>), g, kBlock, 0,
                                    stream, nv, Gc.rowptr.p, Gc.colidx.p,
                                    Gc.vals.p, rvec, (size_t)0, zero_ptr(), zp,
-                                   zv, guard, xacc));
+                                   zv, guard, xa, r0, r1));
         }
         DNS_HIP(hipGetLastError());
-        return DNS_OK;
+        if (dist()) DNS_TRY(comm->allgatherv(zv, st_v, stream));
+    } else {
+        DNS_TRY(apply_fhat(this, rvec, 0, zero_ptr(), zp, zv, guard));
     }
-    DNS_TRY(apply_fhat(this, rvec, 0, zero_ptr(), zp, zv, guard));
-    if (xacc) {
+    if (xacc && (dist() || !fhat_explicit)) {
         hipLaunchKernelGGL(k_axpby, grid_for_elems(nv), kBlock, 0, stream,
                            (int64_t)nv, 1.0, zv, 1.0, xacc);
         DNS_HIP(hipGetLastError());
@@ -317,20 +330,30 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
                               const int *guard, double *xacc) {
     double *zp = zout + nv;
     double *xp = xacc ? xacc + nv : nullptr;
+    double *xpf = dist() ? nullptr : xp;     // fused x_p += z_p on one GPU only
+    const int r0 = p0(), r1 = p1();
     if (popts.schur == DNS_SCHUR_DENSE) {
-        const int g = std::max(1, std::min(np, 2048));
+        const int g = std::max(1, std::min(r1 - r0, 2048));
         if (fp32_store)
             hipLaunchKernelGGL(k_schur_dense<float>, g, kBlock, 0, stream, np,
                                sinv32.p, rvec, (size_t)0, zero_ptr(), nv, zp,
-                               guard, xp);
+                               guard, xpf, r0, r1);
         else
             hipLaunchKernelGGL(k_schur_dense<double>, g, kBlock, 0, stream, np,
                                sinv.p, rvec, (size_t)0, zero_ptr(), nv, zp,
-                               guard, xp);
+                               guard, xpf, r0, r1);
     } else {
-        hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(np), kBlock, 0,
+        hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(r1 - r0), kBlock, 0,
                            stream, np, sinv.p, rvec, (size_t)0, zero_ptr(), nv,
-                           zp, guard, xp);
+                           zp, guard, xpf, r0, r1);
+    }
+    if (dist()) {
+        DNS_TRY(comm->allgatherv(zp, st_p, stream));
+        if (xp) {
+            hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
+                               (int64_t)np, 1.0, zp, 1.0, xp);
+            DNS_HIP(hipGetLastError());
+        }
     }
     return apply_fhat_part(rvec, zp, zout, guard, xacc);
 }
@@ -451,6 +474,9 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
     drop_graphs();   // captured kernel arguments (coefficients, buffers)
+    // the set-up is done redundantly and in full by every rank (identical
+    // preconditioners without any communication); applies are partitioned
+    dist_active = false;
     if (popts.eig_lo > 0.0 && popts.eig_hi > popts.eig_lo) {
         lam_lo = popts.eig_lo;
         lam_hi = popts.eig_hi;
@@ -500,6 +526,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     }
     DNS_HIP(hipStreamSynchronize(stream));
     precond_ready = true;
+    dist_active = (comm != nullptr);
     return DNS_OK;
 }
 
@@ -524,7 +551,8 @@ int dns_saddle::true_residual(const double *b, const double *x, double *out) {
     DNS_LPR_SWITCH(K.lpr,
                    hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x,
-                                      b, r.p, partR.p, (double *)nullptr));
+                                      b, r.p, partR.p, (double *)nullptr, 0,
+                                      n));
     hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, gridS,
                        scal.p);
     DNS_HIP(hipGetLastError());
@@ -588,34 +616,54 @@ static inline uint64_t bits_of(double v) {
 // (ctl->done), so `c` may overshoot.  Nothing here synchronises or allocates.
 int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                               const dns_solve_opts *o) {
-    // r = b - K x, ||r||^2, ||b||^2
+    const bool dd = dist();
+    const int n0 = r0n(), n1 = r1n();
+    // r = b - K x over this rank's rows, ||r||^2, ||b||^2
     DNS_LPR_SWITCH(
         K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream, n,
                                   K.rowptr.p, K.colidx.p, K.vals.p, x, b, r.p,
-                                  partR.p, partB.p));
+                                  partR.p, partB.p, n0, n1));
+    // what the consumers of a reduction read: the per-workgroup partials on
+    // one GPU; the all-reduced sums (one "partial" per scalar) across ranks
+    const double *rr_part = partR.p, *bb_part = partB.p;
+    int rr_np = gridS;
+    if (dd) {
+        DNS_TRY(comm->allgatherv(r.p, st_n, stream));
+        hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, gridS,
+                           dsum.p);
+        hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partB.p, gridS,
+                           dsum.p + 1);
+        DNS_TRY(comm->allreduce(dsum.p, 2, stream));
+        rr_part = dsum.p;
+        bb_part = dsum.p + 1;
+        rr_np = 1;
+    }
     const bool dense = popts.schur == DNS_SCHUR_DENSE;
-    // workgroups of the head kernel: one wavefront per Schur row
-    const int gridA = dense ? std::max(gridD, std::min(np, 2048)) : gridD;
+    const int q0 = p0(), q1 = p1();
+    // workgroups of the head kernel: one workgroup per Schur row
+    const int gridA = dense ? std::max(gridD, std::min(q1 - q0, 2048)) : gridD;
     double *zp = z.p + nv;
+    double *hsum = dsum.p + 2;           // all-reduced Gram-Schmidt dots
     for (int j = 0; j < c; ++j) {
         const double *src = (j == 0) ? r.p : w.p;
-        const double *spart = (j == 0) ? partR.p : partN.p;
-        const int snp = (j == 0) ? gridS : gridD;
+        const double *spart = (j == 0) ? rr_part : partN.p;
+        const int snp = (j == 0) ? rr_np : gridD;
         if (dense && fp32_store)
             hipLaunchKernelGGL(k_arn_head<2>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv32.p, zp, ctl.p, o->rtol,
-                               o->atol, partB.p, gridS, o->maxiter);
+                               o->atol, bb_part, rr_np, o->maxiter, q0, q1);
         else if (dense)
             hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
-                               o->atol, partB.p, gridS, o->maxiter);
+                               o->atol, bb_part, rr_np, o->maxiter, q0, q1);
         else
             hipLaunchKernelGGL(k_arn_head<0>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
-                               o->atol, partB.p, gridS, o->maxiter);
+                               o->atol, bb_part, rr_np, o->maxiter, q0, q1);
+        if (dd) DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, z.p, done_ptr(),
                                 nullptr));
         if (fuse_dots) {
@@ -624,27 +672,40 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 hipLaunchKernelGGL(k_spmv_multidot<L>, gridC, kBlock, 0,
                                    stream, n, K.rowptr.p, K.colidx.p,
                                    K.vals.p, z.p, w.p, V.p, ld, j, partA.p,
-                                   gridC, ctl.p));
+                                   gridC, ctl.p, n0, n1));
         } else {
             DNS_LPR_SWITCH(
                 K.lpr,
-                hipLaunchKernelGGL(k_spmv_guard<L>, grid_for_rows(n, K.lpr),
-                                   kBlock, 0, stream, n, K.rowptr.p,
-                                   K.colidx.p, K.vals.p, z.p, w.p, ctl.p));
+                hipLaunchKernelGGL(k_spmv_guard<L>,
+                                   grid_for_rows(n1 - n0, K.lpr), kBlock, 0,
+                                   stream, n, K.rowptr.p, K.colidx.p, K.vals.p,
+                                   z.p, w.p, ctl.p, n0, n1));
+            if (dd) DNS_TRY(comm->allgatherv(w.p, st_n, stream));
+            // full-vector dots (every rank alike once w is gathered)
             hipLaunchKernelGGL(k_multidot, gridC, kBlock, 0, stream, n, V.p,
                                ld, w.p, partA.p, gridC, j, ctl.p);
         }
+        const double *hpart = partA.p;
+        int hnp = gridC;
+        if (dd && fuse_dots) {
+            // dots were taken over this rank's rows only: gather w, sum the
+            // partials to j+1 scalars and all-reduce those
+            DNS_TRY(comm->allgatherv(w.p, st_n, stream));
+            hipLaunchKernelGGL(k_sum_partials_n, 1, kBlock, 0, stream, partA.p,
+                               gridC, j + 1, hsum);
+            DNS_TRY(comm->allreduce(hsum, j + 1, stream));
+            hpart = hsum;
+            hnp = 1;
+        }
         if (o->reorth) {
             hipLaunchKernelGGL(k_orth<1>, gridD, kBlock, 0, stream, n, V.p, ld,
-                               w.p, partA.p, gridC, j, 0, partE.p, gridD,
-                               ctl.p);
+                               w.p, hpart, hnp, j, 0, partE.p, gridD, ctl.p);
             hipLaunchKernelGGL(k_orth<0>, gridD, kBlock, 0, stream, n, V.p, ld,
                                w.p, partE.p, gridD, j, 1, partN.p, gridD,
                                ctl.p);
         } else {
             hipLaunchKernelGGL(k_orth<0>, gridD, kBlock, 0, stream, n, V.p, ld,
-                               w.p, partA.p, gridC, j, 0, partN.p, gridD,
-                               ctl.p);
+                               w.p, hpart, hnp, j, 0, partN.p, gridD, ctl.p);
         }
     }
     hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
@@ -668,7 +729,8 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
         DNS_TRY(histdev.alloc(need_hist));
     }
     hist_cap = histdev.n;
-    const bool graph = o->use_graph != 0;
+    // RCCL calls are issued eagerly between the kernels (no graph capture)
+    const bool graph = o->use_graph != 0 && !dist();
     // first cycle length: what the previous solve needed plus slack (time
     // stepping repeats itself), rounded to the polling granularity
     const int gran = std::max(1, o->check_every);
@@ -756,7 +818,7 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
     DNS_LPR_SWITCH(K.lpr,
                    hipLaunchKernelGGL(k_resid_norm<L>, nred, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x,
-                                      b, r.p, partR.p, partB.p));
+                                      b, r.p, partR.p, partB.p, 0, n));
     spmv_count++;
     // <rhat, r> = <r, r> at the start: partR doubles as part_rr and part_nn
     hipLaunchKernelGGL(k_bicg_start, nred, kBlock, 0, stream, n, r.p,
@@ -1018,6 +1080,107 @@ int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
     return DNS_OK;
 }
 
+int dns_comm_unique_id(char *out) {
+    if (!out) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    static_assert(sizeof(ncclUniqueId) <= DNS_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId id;
+    ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess)
+        return fail(DNS_ERR_COMM, "ncclGetUniqueId: %s", ncclGetErrorString(r));
+    memset(out, 0, DNS_UNIQUE_ID_BYTES);
+    memcpy(out, &id, sizeof(id));
+    return DNS_OK;
+}
+
+int dns_comm_create_rccl(int device, int32_t nranks, int32_t rank,
+                         const char *uid, dns_comm **out) {
+    if (!out || !uid || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    *out = nullptr;
+    DNS_HIP(hipSetDevice(device));
+    dns_comm *c = new (std::nothrow) dns_comm();
+    if (!c) return fail(DNS_ERR_BAD_ARGUMENT, "out of host memory");
+    c->rank = rank;
+    c->nranks = nranks;
+    c->device = device;
+    ncclUniqueId id;
+    memcpy(&id, uid, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&c->nccl, nranks, id, rank);
+    if (r != ncclSuccess) {
+        c->nccl = nullptr;
+        delete c;
+        return fail(DNS_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
+    }
+    *out = c;
+    return DNS_OK;
+}
+
+int dns_comm_create_callbacks(int device, int32_t nranks, int32_t rank,
+                              dns_allreduce_cb allreduce,
+                              dns_allgatherv_cb allgatherv, void *ctx,
+                              dns_comm **out) {
+    if (!out || !allreduce || !allgatherv || nranks < 1 || rank < 0 ||
+        rank >= nranks)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    dns_comm *c = new (std::nothrow) dns_comm();
+    if (!c) return fail(DNS_ERR_BAD_ARGUMENT, "out of host memory");
+    c->rank = rank;
+    c->nranks = nranks;
+    c->device = device;
+    c->ar_cb = allreduce;
+    c->ag_cb = allgatherv;
+    c->ctx = ctx;
+    *out = c;
+    return DNS_OK;
+}
+
+void dns_comm_destroy(dns_comm *c) { delete c; }
+
+int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather) {
+    if (!c) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    if (n_allreduce) *n_allreduce = c->n_allreduce;
+    if (n_allgather) *n_allgather = c->n_allgather;
+    return DNS_OK;
+}
+
+int dns_saddle_set_comm(dns_saddle *h, dns_comm *c) {
+    if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "null handle");
+    h->drop_graphs();
+    h->comm = c;
+    h->dist_active = false;
+    h->precond_ready = false;          // set up (again) after attaching
+    if (c) {
+        h->st_n = partition_starts(h->n, c->nranks);
+        h->st_v = partition_starts(h->nv, c->nranks);
+        h->st_p = partition_starts(h->np, c->nranks);
+    }
+    return DNS_OK;
+}
+
+int dns_partition_range(int32_t n, int32_t nranks, int32_t rank,
+                        int32_t *start, int32_t *end) {
+    if (!start || !end || n < 0 || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    const std::vector<int> st = partition_starts(n, nranks);
+    *start = st[rank];
+    *end = st[rank + 1];
+    return DNS_OK;
+}
+
+int dns_device_read(int device, const void *dev, void *host, size_t bytes) {
+    if (!dev || !host) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    DNS_HIP(hipSetDevice(device));
+    DNS_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return DNS_OK;
+}
+
+int dns_device_write(int device, void *dev, const void *host, size_t bytes) {
+    if (!dev || !host) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    DNS_HIP(hipSetDevice(device));
+    DNS_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    return DNS_OK;
+}
+
 int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                      int32_t reps, double *us_per_launch) {
     if (!h || !us_per_launch || chain < 1 || reps < 1)
@@ -1055,14 +1218,14 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv32.p, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
-                                           h->gridS, 1 << 30);
+                                           h->gridS, 1 << 30, 0, np);
                     else
                         hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, s, n,
                                            nv, np, j, h->w.p, h->partN.p,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv.p, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
-                                           h->gridS, 1 << 30);
+                                           h->gridS, 1 << 30, 0, np);
                     break;
                 case 1:
                     DNS_TRY(h->apply_fhat_part(h->V.p + (size_t)j * h->ld, zp,
@@ -1075,7 +1238,8 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            0, s, n, h->K.rowptr.p,
                                            h->K.colidx.p, h->K.vals.p, h->z.p,
                                            h->w.p, h->V.p, h->ld, j,
-                                           h->partA.p, h->gridC, h->ctl.p));
+                                           h->partA.p, h->gridC, h->ctl.p, 0,
+                                           n));
                     break;
                 case 3:
                     hipLaunchKernelGGL(k_orth<0>, h->gridD, kBlock, 0, s, n,
@@ -1089,7 +1253,8 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                         hipLaunchKernelGGL(k_resid_norm<L>, h->gridS, kBlock, 0,
                                            s, n, h->K.rowptr.p, h->K.colidx.p,
                                            h->K.vals.p, h->xdev.p, h->bdev.p,
-                                           h->r.p, h->partR.p, h->partB.p));
+                                           h->r.p, h->partR.p, h->partB.p, 0,
+                                           n));
                     break;
                 case 5:
                     hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, s, 0,

@@ -31,13 +31,16 @@ k_resid_norm(int nrows, const int *__restrict__ rowptr,
              const int *__restrict__ colidx, const double *__restrict__ vals,
              const double *__restrict__ x, const double *__restrict__ b,
              double *__restrict__ r, double *__restrict__ part_rr,
-             double *__restrict__ part_bb) {
+             double *__restrict__ part_bb, int row0, int row1) {
+    // rows [row0, row1): the whole matrix on one GPU, this rank's row block in
+    // the row-partitioned solve
     __shared__ double red[4];
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
     double arr = 0.0, abb = 0.0;
-    for (int row = sub; row < nrows; row += nsub) {
+    (void)nrows;
+    for (int row = row0 + sub; row < row1; row += nsub) {
         double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, row, sublane);
         if (sublane == 0) {
             const double bv = b[row];
@@ -53,6 +56,16 @@ k_resid_norm(int nrows, const int *__restrict__ rowptr,
         part_rr[blockIdx.x] = arr;
         if (part_bb) part_bb[blockIdx.x] = abb;
     }
+}
+
+// out[s] = sum of the partials of scalar s (one workgroup): what is all-reduced
+// across ranks in the row-partitioned solve
+__global__ void __launch_bounds__(kBlock)
+k_sum_partials_n(const double *__restrict__ part, int nparts, int nscal,
+                 double *__restrict__ out) {
+    __shared__ double sums[kMaxRestart + 1];
+    reduce_partials(part, nparts, nparts, nscal, sums);
+    if (threadIdx.x < nscal) out[threadIdx.x] = sums[threadIdx.x];
 }
 
 // Givens update of column j (thread 0 of workgroup 0 only)
@@ -102,7 +115,10 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
            const double *__restrict__ src_part, int src_nparts,
            double *__restrict__ V, size_t ld, const void *__restrict__ sinv,
            double *__restrict__ zp, DnsCtl *ctl, double rtol, double atol,
-           const double *__restrict__ bb_part, int bb_nparts, int maxiter) {
+           const double *__restrict__ bb_part, int bb_nparts, int maxiter,
+           int prow0, int prow1) {
+    // [prow0, prow1): the Schur rows this rank computes (all of them on one
+    // GPU); normalisation and the control block are done by every rank alike
     if (j > 0 && ctl->done) return;
     __shared__ double sc[2];
     __shared__ double red4[4];
@@ -126,13 +142,13 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
         const double *sp = src + nv;
         if (SK == 1) {
             dense_rows_block<double>((const double *)sinv, sp, np, -scale, zp,
-                                     nullptr, red4);
+                                     nullptr, red4, prow0, prow1);
         } else if (SK == 2) {
             dense_rows_block<float>((const float *)sinv, sp, np, -scale, zp,
-                                    nullptr, red4);
+                                    nullptr, red4, prow0, prow1);
         } else {
             const double *sd = (const double *)sinv;
-            for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
+            for (int i = prow0 + blockIdx.x * kBlock + threadIdx.x; i < prow1;
                  i += gridDim.x * kBlock)
                 zp[i] = -sd[i] * sp[i] * scale;
         }
@@ -165,8 +181,9 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
                 const double *__restrict__ vals, const double *__restrict__ z,
                 double *__restrict__ w, const double *__restrict__ V, size_t ld,
                 int j, double *__restrict__ part, int nparts,
-                const DnsCtl *ctl) {
+                const DnsCtl *ctl, int row0, int row1) {
     if (ctl->done) return;
+    (void)nrows;
     constexpr int NQ = (kMaxRestart + LPR) / LPR;   // dots per lane
     __shared__ double wred[kBlock / 64][NQ * LPR];
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
@@ -176,7 +193,7 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    for (int row = sub; row < nrows; row += nsub) {
+    for (int row = row0 + sub; row < row1; row += nsub) {
         // basis entries first: their loads overlap the row's own load chain
         double vq[NQ];
 #pragma unroll
@@ -211,12 +228,13 @@ __global__ void __launch_bounds__(kBlock)
 k_spmv_guard(int nrows, const int *__restrict__ rowptr,
              const int *__restrict__ colidx, const double *__restrict__ vals,
              const double *__restrict__ x, double *__restrict__ w,
-             const DnsCtl *ctl) {
+             const DnsCtl *ctl, int row0, int row1) {
     if (ctl->done) return;
+    (void)nrows;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < nrows; row += nsub) {
+    for (int row = row0 + sub; row < row1; row += nsub) {
         double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, row, sublane);
         if (sublane == 0) w[row] = s;
     }

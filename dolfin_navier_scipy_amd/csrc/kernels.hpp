@@ -378,13 +378,14 @@ k_cheb_init(int nv, const int *__restrict__ rowptr,
             size_t ld, const int *__restrict__ jsel,
             const double *__restrict__ dinv, double inv_theta,
             double *__restrict__ r, double *__restrict__ d,
-            const int *__restrict__ guard) {
+            const int *__restrict__ guard, int row0, int row1) {
     if (*guard) return;
+    (void)nv;
     const double *rv = rbase + (size_t)(*jsel) * ld;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < nv; row += nsub) {
+    for (int row = row0 + sub; row < row1; row += nsub) {
         double s = csr_row_dot<LPR>(rowptr, colidx, vals, zp, row, sublane);
         if (sublane == 0) {
             const double rr = dinv[row] * (rv[row] - s);
@@ -404,12 +405,13 @@ k_cheb_step(int nv, const int *__restrict__ rowptr,
             const double *__restrict__ dinv, const double *__restrict__ d_in,
             double *__restrict__ d_out, double *__restrict__ r,
             double *__restrict__ x, double c1, double c2, int first, int last,
-            const int *__restrict__ guard) {
+            const int *__restrict__ guard, int row0, int row1) {
     if (*guard) return;
+    (void)nv;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < nv; row += nsub) {
+    for (int row = row0 + sub; row < row1; row += nsub) {
         double s = csr_row_dot<LPR>(rowptr, colidx, vals, d_in, row, sublane);
         if (sublane == 0) {
             const double di = d_in[row];
@@ -438,13 +440,13 @@ k_spmv_split(int nv, const int *__restrict__ rowptr,
              const double *__restrict__ rbase, size_t ld,
              const int *__restrict__ jsel, const double *__restrict__ zp,
              double *__restrict__ zv, const int *__restrict__ guard,
-             double *__restrict__ xacc) {
+             double *__restrict__ xacc, int row0, int row1) {
     if (*guard) return;
     const double *rv = rbase + (size_t)(*jsel) * ld;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < nv; row += nsub) {
+    for (int row = row0 + sub; row < row1; row += nsub) {
         const int k1 = rowptr[row + 1];
         int k = rowptr[row] + sublane;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -476,10 +478,12 @@ __global__ void __launch_bounds__(kBlock)
 k_schur_jacobi(int np, const double *__restrict__ sdinv,
                const double *__restrict__ rbase, size_t ld,
                const int *__restrict__ jsel, int nv, double *__restrict__ zp,
-               const int *__restrict__ guard, double *__restrict__ xacc) {
+               const int *__restrict__ guard, double *__restrict__ xacc,
+               int row0, int row1) {
     if (*guard) return;
+    (void)np;
     const double *rp = rbase + (size_t)(*jsel) * ld + nv;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
+    for (int i = row0 + blockIdx.x * kBlock + threadIdx.x; i < row1;
          i += gridDim.x * kBlock) {
         const double v = -sdinv[i] * rp[i];
         zp[i] = v;
@@ -497,8 +501,10 @@ __device__ __forceinline__ void dense_rows_block(const VT *__restrict__ a,
                                                  int n, double scale,
                                                  double *__restrict__ out,
                                                  double *__restrict__ xacc,
-                                                 double *red) {
-    for (int row = blockIdx.x; row < n; row += gridDim.x) {
+                                                 double *red, int row0 = 0,
+                                                 int row1 = -1) {
+    if (row1 < 0) row1 = n;
+    for (int row = row0 + blockIdx.x; row < row1; row += gridDim.x) {
         const VT *ar = a + (size_t)row * n;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int c = threadIdx.x;
@@ -533,11 +539,12 @@ __global__ void __launch_bounds__(kBlock)
 k_schur_dense(int np, const VT *__restrict__ sinv,
               const double *__restrict__ rbase, size_t ld,
               const int *__restrict__ jsel, int nv, double *__restrict__ zp,
-              const int *__restrict__ guard, double *__restrict__ xacc) {
+              const int *__restrict__ guard, double *__restrict__ xacc,
+              int row0, int row1) {
     if (*guard) return;
     __shared__ double red[4];
     const double *rp = rbase + (size_t)(*jsel) * ld + nv;
-    dense_rows_block<VT>(sinv, rp, np, -1.0, zp, xacc, red);
+    dense_rows_block<VT>(sinv, rp, np, -1.0, zp, xacc, red, row0, row1);
 }
 
 __global__ void __launch_bounds__(kBlock)

@@ -8,6 +8,7 @@
 #include <functional>
 
 #include "bicgstab_kernels.hpp"
+#include "comm.hpp"
 #include "gmres_kernels.hpp"
 #include "hostcsr.hpp"
 #include "kernels.hpp"
@@ -199,6 +200,19 @@ struct dns_saddle {
     double *scal_host = nullptr;          // pinned
     std::vector<double> history;
     int64_t spmv_count = 0;
+    // row-partitioned solve (comm.hpp): this rank's row blocks of the n rows of
+    // K, the nv velocity rows (Fh^-1) and the np pressure rows (Sh^-1)
+    dns_comm *comm = nullptr;
+    bool dist_active = false;         // false during set-up (done redundantly)
+    std::vector<int> st_n, st_v, st_p;
+    dns::DevBuf<double> dsum;         // all-reduced scalars
+    bool dist() const { return comm != nullptr && dist_active; }
+    int r0n() const { return dist() ? st_n[comm->rank] : 0; }
+    int r1n() const { return dist() ? st_n[comm->rank + 1] : n; }
+    int v0() const { return dist() ? st_v[comm->rank] : 0; }
+    int v1() const { return dist() ? st_v[comm->rank + 1] : nv; }
+    int p0() const { return dist() ? st_p[comm->rank] : 0; }
+    int p1() const { return dist() ? st_p[comm->rank + 1] : np; }
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool want_history = true;         // copy the residual history back

@@ -77,6 +77,14 @@ class SaddleSystem(object):
         except Exception:
             pass
 
+    def set_comm(self, comm):
+        """attach a `comm.Comm` (row-partitioned solve); call before
+        `setup_precond`; `None` detaches"""
+        self._comm = comm
+        C.check(self.lib.dns_saddle_set_comm(
+            self._h, comm._h if comm is not None else None))
+        self.precond_ready = False
+
     def update_values(self, fdata):
         fdata = C.as_f64(fdata, size=self._f.data.size)
         C.check(self.lib.dns_saddle_update_values(self._h, C.dptr(fdata)))

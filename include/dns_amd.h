@@ -157,6 +157,42 @@ int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi);
 void dns_default_precond_opts(dns_precond_opts *o);
 void dns_default_solve_opts(dns_solve_opts *o);
 
+/* ---- row-partitioned solve over several GPUs ------------------------------
+ * One process per GPU.  Every rank creates the same saddle system, attaches
+ * a communicator, and from then on computes only its block of rows of every
+ * operator apply (K, Fh^-1, Sh^-1); vectors are kept in full on every rank:
+ * an in-place all-gather-v of the row blocks follows each apply (the halo
+ * gather) and the Krylov dot products are summed by an all-reduce of a few
+ * fp64 scalars.  Production backend: RCCL over xGMI.  Test backend: host
+ * callbacks (the tests drive them with torch.distributed/gloo so that two
+ * ranks can share one GPU).  The reference has no counterpart.
+ */
+typedef struct dns_comm dns_comm;
+#define DNS_UNIQUE_ID_BYTES 128
+/* in-place sum over ranks of `count` doubles at DEVICE pointer `dev` */
+typedef int (*dns_allreduce_cb)(void *ctx, double *dev, int32_t count);
+/* in-place: rank r owns dev[starts[r] .. starts[r+1]); afterwards every rank
+ * holds every block; `starts` has nranks+1 entries */
+typedef int (*dns_allgatherv_cb)(void *ctx, double *dev, const int32_t *starts,
+                                 int32_t nranks);
+int dns_comm_unique_id(char *out_128_bytes);          /* call on rank 0     */
+int dns_comm_create_rccl(int device, int32_t nranks, int32_t rank,
+                         const char *unique_id_128_bytes, dns_comm **out);
+int dns_comm_create_callbacks(int device, int32_t nranks, int32_t rank,
+                              dns_allreduce_cb allreduce,
+                              dns_allgatherv_cb allgatherv, void *ctx,
+                              dns_comm **out);
+void dns_comm_destroy(dns_comm *c);
+int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather);
+/* attach before dns_saddle_setup_precond; NULL detaches */
+int dns_saddle_set_comm(dns_saddle *h, dns_comm *c);
+/* the block partition used for n rows: [start, end) of `rank` */
+int dns_partition_range(int32_t n, int32_t nranks, int32_t rank,
+                        int32_t *start, int32_t *end);
+/* raw device <-> host copies for the callback backend */
+int dns_device_read(int device, const void *dev, void *host, size_t bytes);
+int dns_device_write(int device, void *dev, const void *host, size_t bytes);
+
 /* ---- device-resident IMEX time loop -------------------------------------
  * Replaces the inner loops of `time_int_utils.cnab` (tiu:104-143) and
  * `time_int_utils.sbdftwo` (tiu:320-353): the state (v, p, history) and the

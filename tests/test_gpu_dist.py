@@ -1,0 +1,135 @@
+"""Row-partitioned solve on the GPU.
+
+ * one rank, RCCL communicator (world size 1): every RCCL call of the
+   distributed code path runs and the answer equals the plain solve;
+ * two ranks sharing ONE GPU through the gloo-staged communicator: the real
+   HIP kernels with rank > 0 row blocks, all-gather-v and all-reduce in
+   between, against the CPU oracle and against the single-rank run.
+(RCCL itself refuses two ranks on one device, and a gpurun box has one GPU.)
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _problem():
+    import scenarios
+    prob = scenarios.toy_problem()
+    M, A, J = (prob['smc'][k] for k in 'MAJ')
+    dt = 5e-3
+    F = (M + .5*dt*A).tocsr()
+    R1 = (M - .5*dt*A).tocsr()
+    rng = np.random.default_rng(11)
+    NP, NV = J.shape
+    rhsv = M @ rng.standard_normal(NV)
+    rhsp = 1e-3*rng.standard_normal(NP)
+    return dict(M=M, A=A, J=J, F=F, R1=R1, rhsv=rhsv, rhsp=rhsp, dt=dt,
+                v0=rng.standard_normal(NV), nfc=M @ rng.standard_normal(NV))
+
+
+def _solve_and_step(sad, comm, fhat, reorth):
+    pr = _problem()
+    system = sad.SaddleSystem(pr['F'], pr['J'])
+    if comm is not None:
+        system.set_comm(comm)
+    system.setup_precond(cheb_degree=4, schur='dense', fhat=fhat)
+    x = system.solve(pr['rhsv'], pr['rhsp'], rtol=1e-12, reorth=reorth)
+    stats = dict(system.last_stats)
+    # a few device-resident CNAB steps through the same communicator
+    stepper = sad.ImexStepper(system, pr['R1'])
+    dt = pr['dt']
+    stepper.set_state(pr['v0'], nfc_c=pr['nfc'], nfc_o=pr['nfc'])
+    stepper.set_rhs(dt*pr['rhsv'], pr['rhsp'])
+    cf = sad.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                pscale=-1./dt)
+    opts = sad.solve_opts(rtol=1e-12, reorth=reorth, use_graph=True)
+    stepper.run(5, cf, opts)
+    v, p = stepper.get_state()
+    stepper.close()
+    system.close()
+    return x, stats, v, p
+
+
+def test_rccl_world_size_one_equals_plain_solve():
+    from dolfin_navier_scipy_amd import saddle, comm as dcomm, _capi
+    assert _capi.device_count() > 0
+    x0, st0, v0, p0 = _solve_and_step(saddle, None, 'explicit', True)
+    cm = dcomm.Comm.rccl(0, 1, 0, dcomm.rccl_unique_id())
+    for fhat in ('explicit', 'cheb'):
+        x1, st1, v1, p1 = _solve_and_step(saddle, cm, fhat, True)
+        assert st1['status'] == 0 and st1['true_relres'] <= 5e-12
+        assert np.linalg.norm(x1 - x0) <= 1e-9*np.linalg.norm(x0)
+        assert np.linalg.norm(v1 - v0) <= 1e-9*np.linalg.norm(v0)
+    calls = cm.stats()
+    assert calls['allreduce'] > 0 and calls['allgatherv'] > 0
+    cm.close()
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+    import faulthandler
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(100, exit=True)   # never hang a GPU box
+    dist.init_process_group('gloo', rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=60))
+    from dolfin_navier_scipy_amd import saddle, comm as dcomm
+    cm = dcomm.Comm.gloo(0)
+    out = {}
+    for fhat, reorth in (('explicit', False), ('cheb', True)):
+        x, st, v, p = _solve_and_step(saddle, cm, fhat, reorth)
+        out[fhat] = (x, v, p, st['iters'], st['true_relres'])
+    np.savez(os.path.join(outdir, 'rank{0}.npz'.format(rank)),
+             **{'{0}_{1}'.format(k, i): np.asarray(val)
+                for k, tup in out.items() for i, val in enumerate(tup)})
+    cm.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_gloo_staged(tmp_path):
+    import torch.multiprocessing as mp
+    from dolfin_navier_scipy_amd import saddle
+    from oracle import saddle_oracle
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / 'rank0.npz')
+    r1 = np.load(tmp_path / 'rank1.npz')
+    pr = _problem()
+    ref = saddle_oracle.solve_sadpnt_smw(amat=pr['F'], jmat=pr['J'],
+                                         rhsv=pr['rhsv'],
+                                         rhsp=pr['rhsp']).reshape(-1)
+    NV = pr['F'].shape[0]
+    xs, sts, vs, ps = _solve_and_step(saddle, None, 'explicit', False)
+    for fhat in ('explicit', 'cheb'):
+        x_a, x_b = r0[fhat + '_0'], r1[fhat + '_0']
+        # both ranks end with the same full iterate ...
+        assert np.array_equal(x_a, x_b)
+        # ... which is the oracle's solution
+        assert float(r0[fhat + '_4']) <= 5e-12
+        assert np.linalg.norm(x_a[:NV] - ref[:NV]) <= 1e-9*np.linalg.norm(ref[:NV])
+        assert np.linalg.norm(x_a[NV:] - ref[NV:]) <= 1e-7*np.linalg.norm(ref[NV:])
+        # time stepping through the communicator == single-rank stepping
+        assert np.array_equal(r0[fhat + '_1'], r1[fhat + '_1'])
+        assert np.linalg.norm(r0[fhat + '_1'] - vs) <= 1e-9*np.linalg.norm(vs)
+        assert np.linalg.norm(r0[fhat + '_2'] - ps) <= 1e-7*np.linalg.norm(ps)
+    assert abs(int(r0['explicit_3']) - sts['iters']) <= 1
