@@ -36,6 +36,21 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+class stdout_to_stderr(object):
+    """RCCL prints a version banner on fd 1 when a communicator is created;
+    the bench contract is ONE JSON line on stdout"""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def spmv_bytes(A):
     """algorithmic bytes of y = A x"""
     r, c = A.shape
@@ -149,6 +164,12 @@ def main():
                     help='red refinements of the mesh for the HBM roofline '
                     'SpMV (0 disables)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--replicas', action='store_true',
+                    help='N>1: independent replicas instead of the '
+                    'row-partitioned solve')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='attach an RCCL communicator even with one rank '
+                    '(self-test of the multi-GPU code path)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -159,7 +180,9 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl')
+        with stdout_to_stderr():
+            dist.init_process_group('nccl')
+            dist.barrier()
     device = local_rank if world > 1 else 0
 
     from dolfin_navier_scipy_amd import saddle, _capi
@@ -186,6 +209,29 @@ def main():
     R1 = (M - .5*dt*A).tocsr()
     t_setup = time.perf_counter()
     system = factory(F, J)
+    # N > 1: ONE simulation, its operator applies row-partitioned over the
+    # ranks (RCCL all-gather-v of the row blocks + all-reduce of the Krylov
+    # dots).  Strong scaling by construction -- and at n ~ 1e4 it is bound by
+    # collective latency, not by compute (SURVEY.md 8e says so up front).
+    mode, scaling, comm_obj = ('single', 'weak', None)
+    if world > 1:
+        mode = 'replicas'
+    if (world > 1 and not args.replicas) or args.force_dist:
+        try:
+            from dolfin_navier_scipy_amd import comm as dcomm
+            with stdout_to_stderr():
+                if dist is not None:
+                    comm_obj = dcomm.Comm.rccl_from_torch(device)
+                else:
+                    comm_obj = dcomm.Comm.rccl(device, 1, 0,
+                                               dcomm.rccl_unique_id())
+            system.set_comm(comm_obj)
+            mode, scaling = 'row-partitioned over RCCL', 'strong'
+        except Exception as exc:       # keep the scaling run alive
+            sys.stderr.write('row-partitioned mode unavailable ({0}); '
+                             'running replicas\n'.format(exc))
+            comm_obj = None
+            mode = 'replicas (partitioned mode failed: {0})'.format(exc)
     system.setup_precond(cheb_degree=args.cheb, schur='dense', fhat=args.fhat,
                          fp32_store=bool(args.fp32), drop_tol=args.drop)
     _capi.device_synchronize(device)
@@ -222,7 +268,8 @@ def main():
 
     out = None
     if rank == 0:
-        value = world*args.steps/wall
+        # replicas: N simulations advance together; partitioned: one does
+        value = (1 if comm_obj is not None else world)*args.steps/wall
         roof = roofline_spmv(saddle, saddle_csr(F, J), 200,
                              'K at the benchmark size (cache resident)',
                              variants=('vector',))
@@ -266,12 +313,14 @@ def main():
                    .format(args.Re),
             value=value, unit='timesteps/s', n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=1e3*wall/args.steps,
-            higher_is_better=True, scaling='weak', vs_baseline=None,
+            higher_is_better=True, scaling=scaling, vs_baseline=None,
             dtype='f64', data='synthetic',
             config=dict(workload='cylinderwake N={0} Re={1:g} CNAB dt=1/{2} '
                         'Taylor-Hood NV={3} NP={4}; convection history frozen'
                         .format(args.level, args.Re, args.nts, NV, NP),
-                        parallelism='replicas' if world > 1 else 'single',
+                        parallelism=mode,
+                        collectives=(comm_obj.stats() if comm_obj is not None
+                                     else None),
                         method=args.method, cheb_degree=args.cheb,
                         schur='dense', rtol=args.rtol,
                         launch='eager' if args.eager else 'hipGraph',
@@ -285,6 +334,8 @@ def main():
         print(json.dumps(out))
     stepper.close()
     system.close()
+    if comm_obj is not None:
+        comm_obj.close()
     lau.clear_cache()
     if dist is not None:
         dist.destroy_process_group()

@@ -22,7 +22,8 @@ def _free_port():
 
 def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      RANK=str(rank), WORLD_SIZE=str(world))
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      GLOO_SOCKET_IFNAME='lo')   # loopback, deterministically
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -95,6 +96,12 @@ def _worker(rank, world, port, outdir):
 
 def test_world2_partition_collectives_and_model(tmp_path):
     import torch.multiprocessing as mp
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for attempt in range(2):         # one retry: a rendezvous port can race
+        try:
+            mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2,
+                     join=True)
+            break
+        except Exception:
+            if attempt == 1:
+                raise
     assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')

@@ -83,7 +83,8 @@ def test_rccl_world_size_one_equals_plain_solve():
 
 def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                      RANK=str(rank), WORLD_SIZE=str(world))
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      GLOO_SOCKET_IFNAME='lo')   # loopback, deterministically
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -110,8 +111,14 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
     import torch.multiprocessing as mp
     from dolfin_navier_scipy_amd import saddle
     from oracle import saddle_oracle
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for attempt in range(2):         # one retry: a rendezvous port can race
+        try:
+            mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2,
+                     join=True)
+            break
+        except Exception:
+            if attempt == 1:
+                raise
     r0 = np.load(tmp_path / 'rank0.npz')
     r1 = np.load(tmp_path / 'rank1.npz')
     pr = _problem()
