@@ -143,6 +143,14 @@ SIGNATURES = {
                                 ct.POINTER(ct.c_int64)]),
     'dns_imex_get_state': (ct.c_int, [_VP, c_double_p, c_double_p]),
     'dns_imex_vnorm': (ct.c_int, [_VP, c_double_p]),
+    'dns_conv_create_p2': (ct.c_int, [ct.c_int, ct.c_int32, c_int32_p,
+                                      c_double_p, c_double_p, ct.c_int32,
+                                      ct.c_int32, c_int32_p, ct.c_int32,
+                                      c_int32_p, c_double_p, ct.POINTER(_VP)]),
+    'dns_conv_destroy': (None, [_VP]),
+    'dns_conv_set_dbcvals': (ct.c_int, [_VP, c_double_p]),
+    'dns_conv_apply': (ct.c_int, [_VP, c_double_p, ct.c_double, c_double_p]),
+    'dns_imex_set_convection': (ct.c_int, [_VP, _VP, ct.c_double]),
     'dns_spmv': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr), c_double_p,
                             c_double_p, ct.c_double, ct.c_double, ct.c_int32]),
     'dns_dot': (ct.c_int, [ct.c_int, ct.c_int64, c_double_p, c_double_p,

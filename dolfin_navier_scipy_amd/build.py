@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['dns_amd.hip']
 HEADERS = ['common.hpp', 'kernels.hpp', 'bicgstab_kernels.hpp', 'solver.hpp',
            'hostcsr.hpp', 'gmres_kernels.hpp', 'comm.hpp',
-           'imex.hpp', 'imex_capi.inc',
+           'imex.hpp', 'imex_capi.inc', 'convection.hpp', 'conv_capi.inc',
            os.path.join('..', '..', 'include', 'dns_amd.h')]
 LIB = os.path.join(CSRC, 'libdnsamd.so')
 

@@ -1,0 +1,76 @@
+"""Device convection `N(u)u` for P2 velocities on triangles (`dns_conv_*`).
+
+Replaces the per-step host callback `f_vdp` of the reference
+(`stokes_navier_utils.py:1136-1140` -> `dolfin_to_sparrays.get_convvec`,
+dts:427-472): with an operator attached (`ImexStepper.set_convection`) the
+CNAB/SBDF2 loop needs no host round trip at all.
+"""
+import ctypes as ct
+
+import numpy as np
+
+from . import _capi as C
+
+__all__ = ['ConvectionP2']
+
+
+def _i32(arr):
+    return np.ascontiguousarray(arr, dtype=np.int32)
+
+
+class ConvectionP2(object):
+    def __init__(self, cell_vdofs, glam, area, vdim, invinds, dbcinds,
+                 dbcvals, device=0):
+        """`cell_vdofs (nc, 6, 2)`, `glam (nc, 3, 2)`, `area (nc,)` -- the
+        element data any P2 FE library has (see include/dns_amd.h)"""
+        self.lib = C.load_library()
+        cv = _i32(np.asarray(cell_vdofs).reshape(-1))
+        gl = np.ascontiguousarray(np.asarray(glam, dtype=np.float64).reshape(-1))
+        ar = C.as_f64(area)
+        self.ncells = ar.size
+        inv, dbi = _i32(invinds), _i32(dbcinds)
+        dbv = C.as_f64(dbcvals, size=dbi.size)
+        self.nv = inv.size
+        self._h = ct.c_void_p()
+        C.check(self.lib.dns_conv_create_p2(
+            device, self.ncells, cv.ctypes.data_as(C.c_int32_p), C.dptr(gl),
+            C.dptr(ar), int(vdim), inv.size, inv.ctypes.data_as(C.c_int32_p),
+            dbi.size, dbi.ctypes.data_as(C.c_int32_p), C.dptr(dbv),
+            ct.byref(self._h)))
+
+    @classmethod
+    def from_taylor_hood(cls, th, invinds, dbcinds, dbcvals, device=0):
+        """element data of the scaffolding assembler (`fem.TaylorHood`)"""
+        return cls(th._vdofs(), th.glam, th.area, th.vdim, invinds, dbcinds,
+                   dbcvals, device=device)
+
+    def set_dbcvals(self, dbcvals):
+        dbv = C.as_f64(dbcvals)
+        C.check(self.lib.dns_conv_set_dbcvals(self._h, C.dptr(dbv)))
+
+    def apply(self, v_inner, scale=1.0):
+        v = C.as_f64(v_inner, size=self.nv)
+        out = np.empty(self.nv)
+        C.check(self.lib.dns_conv_apply(self._h, C.dptr(v), float(scale),
+                                        C.dptr(out)))
+        return out.reshape((-1, 1))
+
+    def host_callback(self, invinds, scale=-1.0):
+        """an `f_vdp(vfull)` callable (reference tiu:113) backed by this
+        operator: the inner part of `vfull` in, `scale*N(v)v` out"""
+        inv = np.asarray(invinds)
+
+        def f_vdp(vfull):
+            return self.apply(np.asarray(vfull).reshape(-1)[inv], scale=scale)
+        return f_vdp
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.dns_conv_destroy(self._h)
+            self._h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,125 @@
+// Convection vector N(u)u = inner(grad(u)*u, v)*dx for P2 velocities on
+// triangles, evaluated on the device (replaces the host
+// FEniCS callback `f_vdp` -> `get_v_conv_conts(semi_explicit=True)` ->
+// `dts.get_convvec`, reference snu:1136-1140, snu:103-107, dts:427-472).
+//
+// Two kernels, no atomics (bitwise reproducible):
+//   k_conv_cells : one thread per cell; gathers the 12 local velocity values
+//                  (inner dofs from the state vector, Dirichlet dofs from the
+//                  boundary-value table: `append_bcs_vec`, dts:49-64, fused),
+//                  7-point degree-5 quadrature, writes 12 local contributions
+//                  cell-contiguously (struct of arrays -> coalesced)
+//   k_conv_gather: one thread per inner dof sums its contributions through an
+//                  inverted index (dof -> list of (local slot, cell)) and
+//                  applies the sign/scale of the caller (`-1`: goes to the rhs)
+#pragma once
+#include "common.hpp"
+
+namespace dns {
+
+struct ConvTables {
+    double phi[7][6];       // P2 shape functions at the quadrature points
+    double dphi[7][6][3];   // d(phi_a)/d(lambda_i)
+    double qw[7];           // weights (sum to 1)
+};
+
+__constant__ ConvTables c_conv;
+
+__global__ void __launch_bounds__(kBlock)
+k_conv_cells(int ncells, const int *__restrict__ cellmap,   // [12][ncells]
+             const double *__restrict__ glam,               // [6][ncells]
+             const double *__restrict__ area,
+             const double *__restrict__ v_inner,
+             const double *__restrict__ dbcvals,
+             double *__restrict__ cellvals) {               // [12][ncells]
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= ncells) return;
+    double ul[6][2];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = cellmap[(size_t)(2 * a + i) * ncells + c];
+            ul[a][i] = (m >= 0) ? v_inner[m] : dbcvals[-m - 1];
+        }
+    double gl[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gl[k][0] = glam[(size_t)(2 * k) * ncells + c];
+        gl[k][1] = glam[(size_t)(2 * k + 1) * ncells + c];
+    }
+    const double ar = area[c];
+    double fl[6][2];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) fl[a][0] = fl[a][1] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        double uq[2] = {0.0, 0.0};
+        double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // g[i][d] = d_d u_i
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double ph = c_conv.phi[q][a];
+            const double gx = c_conv.dphi[q][a][0] * gl[0][0] +
+                              c_conv.dphi[q][a][1] * gl[1][0] +
+                              c_conv.dphi[q][a][2] * gl[2][0];
+            const double gy = c_conv.dphi[q][a][0] * gl[0][1] +
+                              c_conv.dphi[q][a][1] * gl[1][1] +
+                              c_conv.dphi[q][a][2] * gl[2][1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uq[i] = fma(ph, ul[a][i], uq[i]);
+                g[i][0] = fma(gx, ul[a][i], g[i][0]);
+                g[i][1] = fma(gy, ul[a][i], g[i][1]);
+            }
+        }
+        const double wq = c_conv.qw[q] * ar;
+        const double cv0 = wq * (g[0][0] * uq[0] + g[0][1] * uq[1]);
+        const double cv1 = wq * (g[1][0] * uq[0] + g[1][1] * uq[1]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            fl[a][0] = fma(c_conv.phi[q][a], cv0, fl[a][0]);
+            fl[a][1] = fma(c_conv.phi[q][a], cv1, fl[a][1]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            cellvals[(size_t)(2 * a + i) * ncells + c] = fl[a][i];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_conv_gather(int nrows, const int *__restrict__ gptr,
+              const int *__restrict__ gidx,
+              const double *__restrict__ cellvals, double scale,
+              double *__restrict__ out) {
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < nrows;
+         r += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int k = gptr[r]; k < gptr[r + 1]; ++k) s += cellvals[gidx[k]];
+        out[r] = scale * s;
+    }
+}
+
+}  // namespace dns
+
+struct dns_conv {
+    int device = 0;
+    int ncells = 0, nv_inner = 0, ndbc = 0;
+    dns::DevBuf<int> cellmap, gptr, gidx;
+    dns::DevBuf<double> glam, area, dbcvals, cellvals;
+    // enqueue out_dev = scale * N(u)u[inner] for the inner velocity `v_dev`
+    int enqueue(const double *v_dev, double scale, double *out_dev,
+                hipStream_t s) {
+        const int g1 = (ncells + dns::kBlock - 1) / dns::kBlock;
+        hipLaunchKernelGGL(dns::k_conv_cells, g1, dns::kBlock, 0, s, ncells,
+                           cellmap.p, glam.p, area.p, v_dev, dbcvals.p,
+                           cellvals.p);
+        const int g2 = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
+                                                dns::kBlock, 2048));
+        hipLaunchKernelGGL(dns::k_conv_gather, g2, dns::kBlock, 0, s, nv_inner,
+                           gptr.p, gidx.p, cellvals.p, scale, out_dev);
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
+    }
+};

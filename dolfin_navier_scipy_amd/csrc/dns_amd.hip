@@ -1471,3 +1471,4 @@ int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
 }  // extern "C"
 
 #include "imex_capi.inc"
+#include "conv_capi.inc"

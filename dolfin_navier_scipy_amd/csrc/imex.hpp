@@ -1,5 +1,6 @@
 // Device-resident IMEX stepper state (CNAB / SBDF2 inner loops).
 #pragma once
+#include "convection.hpp"
 #include "solver.hpp"
 
 struct dns_imex {
@@ -8,12 +9,15 @@ struct dns_imex {
     // two solution-space vectors [v; p~] (current, previous) + work
     dns::DevBuf<double> xs[3];
     dns::DevBuf<double> ck[2];     // checkpoint of (cur, prev) for a batch
+    dns::DevBuf<double> ckn[2];    // ... and of the convection history
     int cur = 0, prev = 1, work = 2;
     int nsol = 0;                  // how many valid solution vectors (0,1,2)
     dns::DevBuf<double> nfc[2];
     int nc = 0, no = 1;
     dns::DevBuf<double> g, gp, b;
     double last_pscale = 1.0;
+    dns_conv *conv = nullptr;      // device convection: nfc_c = scale*N(v_c)v_c
+    double conv_scale = -1.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ~dns_imex() {
         if (e0) (void)hipEventDestroy(e0);

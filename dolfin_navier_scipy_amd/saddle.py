@@ -188,6 +188,13 @@ class ImexStepper(object):
         C.check(self.lib.dns_imex_set_state(self._h, *[C.dptr(a)
                                                        for a in args]))
 
+    def set_convection(self, conv, scale=-1.0):
+        """attach a `convection.ConvectionP2`: every step then evaluates
+        `nfc_c = scale*N(v_c)v_c` on the device (`None` detaches)"""
+        self._conv = conv
+        C.check(self.lib.dns_imex_set_convection(
+            self._h, conv._h if conv is not None else None, float(scale)))
+
     def set_rhs(self, gvec=None, rhsp=None):
         g = None if gvec is None else C.as_f64(gvec, self.sys.NV)
         gp = None if rhsp is None else C.as_f64(rhsp, self.sys.NP)

@@ -137,16 +137,22 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
          M=None, A=None, J=None, f_vdp=None, f_tdp=None, g_tdp=None,
          f_tvdp=None, scalep=-1., getbcs=None, applybcs=None, appndbcs=None,
          savevp=None, dynamic_rhs=None, dynamic_rhs_memory={},
-         check_ff_maxv=None, ntimeslices=10, verbose=True, solver=None):
+         check_ff_maxv=None, ntimeslices=10, verbose=True, solver=None,
+         device_convection=None, invinds=None):
     """Crank-Nicolson / Adams-Bashforth-2 on the GPU (reference tiu:23-145)
 
     `solver`: optional dict overriding `SOLVER` (method, rtol, cheb_degree...).
+    `device_convection`: a `convection.ConvectionP2` (with `invinds`, the inner
+    dofs of the full velocity vector) -- the loop then evaluates `-N(v)v` on
+    the device and `f_vdp` is not called per step.
     Returns `v_n, p_n, ffflag` like the reference.
     """
     prm = _solver_settings(solver)
     dt, listofts = _inittimegrid(trange, ntimeslices=ntimeslices)
     NP, NV = J.shape
     ffflag = 0
+    if device_convection is not None and f_vdp is None:
+        f_vdp = device_convection.host_callback(invinds)   # Heun start only
     dynamic_rhs, f_vdp = _wrap_callbacks(NV, dynamic_rhs, f_tvdp, f_vdp)
     dfv_c, drm = dynamic_rhs(trange[0], vc=inivel, memory=dynamic_rhs_memory,
                              mode='init')
@@ -166,6 +172,8 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
     cf = ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
                             pscale=scalep/dt, extrapolate=prm['extrapolate'])
     stepper.set_state(v_n, ptilde_c=p_n*dt/scalep, nfc_c=nfc_c)
+    if device_convection is not None:
+        stepper.set_convection(device_convection, scale=-1.0)
     try:
         for kck, ctrange in enumerate(listofts):
             nrmvc = stepper.vnorm()
@@ -180,7 +188,8 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
                 v_c, p_c = v_n, p_n
                 bcs_c, bfv_c, mbc_c = bcs_n, bfv_n, mbc_n
                 fv_c, dfv_c = fv_n, dfv_n
-                nfc_new = f_vdp(appndbcs(v_c, bcs_c))
+                nfc_new = None if device_convection is not None \
+                    else f_vdp(appndbcs(v_c, bcs_c))
                 bcs_n = getbcs(ctime, appndbcs(v_c, bcs_c), p_c, mode='abtwo')
                 bfv_n, bfp_n, mbc_n = applybcs(bcs_n)
                 fv_n, fp_n = f_tdp(ctime), g_tdp(ctime)

@@ -239,6 +239,36 @@ int dns_imex_get_state(dns_imex *st, double *v, double *p);
 /* ||v||_2 of the current velocity (blow-up guard, tiu:94-103) */
 int dns_imex_vnorm(dns_imex *st, double *out);
 
+/* ---- convection on the device --------------------------
+ * N(u)u = inner(grad(u)*u, v)*dx for P2 velocities on triangles: replaces the
+ * host callback `f_vdp` = `get_v_conv_conts(semi_explicit=True)` ->
+ * `dolfin_to_sparrays.get_convvec` (stokes_navier_utils.py:1136-1140,103-107;
+ * dolfin_to_sparrays.py:427-472) including its `append_bcs_vec`
+ * (dolfin_to_sparrays.py:49-64).  Mesh data as the caller's FE library has it:
+ *   cell_vdofs[12*c + 2*a + i] : FULL-space velocity dof of local node a,
+ *        component i; local nodes 0..2 = vertices, 3..5 = midpoints of the
+ *        edges opposite to vertex 0, 1, 2
+ *   glam[6*c + 2*k + d]  : d-th component of grad(lambda_k) on cell c
+ *   area[c]; invinds (inner dofs, order of the condensed vectors);
+ *   dbcinds / dbcvals (Dirichlet dofs and values)
+ */
+typedef struct dns_conv dns_conv;
+int dns_conv_create_p2(int device, int32_t ncells, const int32_t *cell_vdofs,
+                       const double *glam, const double *area, int32_t vdim,
+                       int32_t nv_inner, const int32_t *invinds, int32_t ndbc,
+                       const int32_t *dbcinds, const double *dbcvals,
+                       dns_conv **out);
+void dns_conv_destroy(dns_conv *cv);
+int dns_conv_set_dbcvals(dns_conv *cv, const double *dbcvals);
+/* out = scale * N(u)u restricted to the inner dofs (host in/out; parity) */
+int dns_conv_apply(dns_conv *cv, const double *v_inner, double scale,
+                   double *out);
+/* let the stepper evaluate nfc_c = scale * N(v_c)v_c itself every step
+ * (scale = -1: "goes to the rhs", stokes_navier_utils.py:1128-1140); NULL
+ * detaches.  dns_imex_step then takes nfc_new = NULL and dns_imex_run
+ * advances the convection history instead of freezing it */
+int dns_imex_set_convection(dns_imex *st, dns_conv *cv, double scale);
+
 /* ---- standalone kernels (parity tests, micro-benchmarks) -----------------
  * upload, run the same device kernels the solver uses, download */
 int dns_spmv(int device, const dns_csr *a, const double *x, double *y,
