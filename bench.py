@@ -159,6 +159,8 @@ def main():
     ap.add_argument('--method', default='gmres')
     ap.add_argument('--cheb', type=int, default=6)
     ap.add_argument('--rtol', type=float, default=1e-10)
+    ap.add_argument('--extrap', type=int, default=2,
+                    help='warm start: 0 none, 1 linear, 2 quadratic')
     ap.add_argument('--fp32', type=int, default=1,
                     help='store the explicit preconditioner matrices in fp32')
     ap.add_argument('--drop', type=float, default=3e-3,
@@ -256,7 +258,7 @@ def main():
         return -th.convection_vec(full)[inv, :]          # snu:1136-1140
 
     cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
-                                   pscale=-1./dt, extrapolate=True)
+                                   pscale=-1./dt, extrapolate=args.extrap)
     opts = saddle.solve_opts(method=args.method, rtol=args.rtol, maxiter=400,
                              restart=60, check_every=args.check_every,
                              use_graph=not args.eager,

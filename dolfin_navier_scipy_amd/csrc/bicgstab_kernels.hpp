@@ -240,4 +240,14 @@ k_lincomb2(int n, double e_c, const double *__restrict__ x_c, double e_p,
         out[i] = fma(e_c, x_c[i], e_p * x_p[i]);
 }
 
+// x0 = 3 x_c - 3 x_p + x_pp  (quadratic extrapolation of the last three steps)
+__global__ void __launch_bounds__(kBlock)
+k_lincomb3(int n, const double *__restrict__ x_c,
+           const double *__restrict__ x_p, const double *__restrict__ x_pp,
+           double *__restrict__ out) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock)
+        out[i] = 3.0 * (x_c[i] - x_p[i]) + x_pp[i];
+}
+
 }  // namespace dns

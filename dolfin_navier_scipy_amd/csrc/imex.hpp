@@ -7,11 +7,11 @@ struct dns_imex {
     dns_saddle *sys = nullptr;
     dns::CsrDev R1;
     // two solution-space vectors [v; p~] (current, previous) + work
-    dns::DevBuf<double> xs[3];
-    dns::DevBuf<double> ck[2];     // checkpoint of (cur, prev) for a batch
+    dns::DevBuf<double> xs[4];     // current, previous, pre-previous, work
+    dns::DevBuf<double> ck[3];     // checkpoint of the history for a batch
     dns::DevBuf<double> ckn[2];    // ... and of the convection history
-    int cur = 0, prev = 1, work = 2;
-    int nsol = 0;                  // how many valid solution vectors (0,1,2)
+    int cur = 0, prev = 1, pprev = 2, work = 3;
+    int nsol = 0;                  // how many valid solution vectors (0..3)
     dns::DevBuf<double> nfc[2];
     int nc = 0, no = 1;
     dns::DevBuf<double> g, gp, b;

@@ -204,7 +204,7 @@ class ImexStepper(object):
     def coeffs(a_c=1., a_p=0., cn_c=0., cn_o=0., pscale=1., extrapolate=True):
         return C.dns_imex_coeffs(a_c=a_c, a_p=a_p, cn_c=cn_c, cn_o=cn_o,
                                  pscale=pscale,
-                                 extrapolate_x0=1 if extrapolate else 0, pad=0)
+                                 extrapolate_x0=int(extrapolate), pad=0)
 
     def step(self, cf, nfc_new=None, opts=None, raise_on_fail=True):
         o = solve_opts() if opts is None else opts
