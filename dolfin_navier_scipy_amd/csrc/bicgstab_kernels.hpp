@@ -231,6 +231,99 @@ k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
         b[nv + i] = gp[i];
 }
 
+// ---------------------------------------------------------------------------
+// Whole prologue of a resident IMEX step in ONE launch (row-parallel over the
+// n rows of K; replaces gather + k_imex_rhs + k_lincomb* + k_resid_norm):
+//   nfc_c = scale * (convection gather)            [if a device operator is on]
+//   b_v   = R1 (a_c v_c + a_p v_p) + cn_c nfc_c + cn_o nfc_o + g ;  b_p = gp
+//   x0    = e_c x_c + e_p x_p + e_pp x_pp          (warm start)
+//   r     = b - K x0 ,  partials of ||r||^2 and ||b||^2
+// K x0 is formed from the history vectors directly (x0 of other rows is not
+// available inside the launch): up to three gathers per non-zero.
+// ---------------------------------------------------------------------------
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
+                const int *__restrict__ k_colidx,
+                const double *__restrict__ k_vals,
+                const int *__restrict__ r_rowptr,
+                const int *__restrict__ r_colidx,
+                const double *__restrict__ r_vals,
+                const double *__restrict__ x_c, const double *__restrict__ x_p,
+                const double *__restrict__ x_pp, double e_c, double e_p,
+                double e_pp, double a_c, double a_p,
+                double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
+                double cn_c, double cn_o, const double *__restrict__ g,
+                const double *__restrict__ gp, const int *__restrict__ gptr,
+                const int *__restrict__ gidx,
+                const double *__restrict__ cellvals, double conv_scale,
+                double *__restrict__ b, double *__restrict__ x0,
+                double *__restrict__ r, double *__restrict__ part_rr,
+                double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    double arr = 0.0, abb = 0.0;
+    for (int row = sub; row < n; row += nsub) {
+        // K x0 over the row, x0 assembled from the history on the fly
+        double kx = 0.0;
+        {
+            const int k1 = k_rowptr[row + 1];
+            for (int k = k_rowptr[row] + sublane; k < k1; k += LPR) {
+                const int c = k_colidx[k];
+                double xv = e_c * x_c[c];
+                if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
+                if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
+                kx = fma(k_vals[k], xv, kx);
+            }
+        }
+        double rs = 0.0, cvs = 0.0;
+        if (row < nv) {
+            const int k1 = r_rowptr[row + 1];
+            for (int k = r_rowptr[row] + sublane; k < k1; k += LPR) {
+                const int c = r_colidx[k];
+                double vv = a_c * x_c[c];
+                if (a_p != 0.0) vv = fma(a_p, x_p[c], vv);
+                rs = fma(r_vals[k], vv, rs);
+            }
+            if (gptr) {
+                const int g1 = gptr[row + 1];
+                for (int k = gptr[row] + sublane; k < g1; k += LPR)
+                    cvs += cellvals[gidx[k]];
+            }
+        }
+        kx = subwave_sum<LPR>(kx);
+        rs = subwave_sum<LPR>(rs);
+        if (gptr) cvs = subwave_sum<LPR>(cvs);
+        if (sublane == 0) {
+            double bv;
+            if (row < nv) {
+                double nc = gptr ? conv_scale * cvs : nfc_c[row];
+                if (gptr) nfc_c[row] = nc;
+                bv = rs + cn_c * nc + cn_o * nfc_o[row] + g[row];
+            } else {
+                bv = gp[row - nv];
+            }
+            double xv = e_c * x_c[row];
+            if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
+            if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
+            const double rv = bv - kx;
+            b[row] = bv;
+            x0[row] = xv;
+            r[row] = rv;
+            arr = fma(rv, rv, arr);
+            abb = fma(bv, bv, abb);
+        }
+    }
+    arr = block_sum(arr, red);
+    abb = block_sum(abb, red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = arr;
+        part_bb[blockIdx.x] = abb;
+    }
+}
+
 // x0 = e_c * x_c + e_p * x_p   (warm start, `krylovini='upd'` snu:1496-1501)
 __global__ void __launch_bounds__(kBlock)
 k_lincomb2(int n, double e_c, const double *__restrict__ x_c, double e_p,

@@ -108,13 +108,19 @@ struct dns_conv {
     int ncells = 0, nv_inner = 0, ndbc = 0;
     dns::DevBuf<int> cellmap, gptr, gidx;
     dns::DevBuf<double> glam, area, dbcvals, cellvals;
-    // enqueue out_dev = scale * N(u)u[inner] for the inner velocity `v_dev`
-    int enqueue(const double *v_dev, double scale, double *out_dev,
-                hipStream_t s) {
+    // element kernel alone (the gather is fused into the step prologue)
+    int enqueue_cells(const double *v_dev, hipStream_t s) {
         const int g1 = (ncells + dns::kBlock - 1) / dns::kBlock;
         hipLaunchKernelGGL(dns::k_conv_cells, g1, dns::kBlock, 0, s, ncells,
                            cellmap.p, glam.p, area.p, v_dev, dbcvals.p,
                            cellvals.p);
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
+    }
+    // enqueue out_dev = scale * N(u)u[inner] for the inner velocity `v_dev`
+    int enqueue(const double *v_dev, double scale, double *out_dev,
+                hipStream_t s) {
+        DNS_TRY(enqueue_cells(v_dev, s));
         const int g2 = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
                                                 dns::kBlock, 2048));
         hipLaunchKernelGGL(dns::k_conv_gather, g2, dns::kBlock, 0, s, nv_inner,

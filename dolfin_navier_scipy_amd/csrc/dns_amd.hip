@@ -615,14 +615,18 @@ static inline uint64_t bits_of(double v) {
 // correction x += P^-1 (V y).  Kernels after convergence return at once
 // (ctl->done), so `c` may overshoot.  Nothing here synchronises or allocates.
 int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
-                              const dns_solve_opts *o) {
+                              const dns_solve_opts *o, bool first,
+                              bool have_resid) {
     const bool dd = dist();
     const int n0 = r0n(), n1 = r1n();
-    // r = b - K x over this rank's rows, ||r||^2, ||b||^2
-    DNS_LPR_SWITCH(
-        K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream, n,
-                                  K.rowptr.p, K.colidx.p, K.vals.p, x, b, r.p,
-                                  partR.p, partB.p, n0, n1));
+    // r = b - K x over this rank's rows, ||r||^2, ||b||^2 (unless the caller's
+    // prologue kernel has produced r and the partials already)
+    if (!have_resid) {
+        DNS_LPR_SWITCH(
+            K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
+                                      n, K.rowptr.p, K.colidx.p, K.vals.p, x, b,
+                                      r.p, partR.p, partB.p, n0, n1));
+    }
     // what the consumers of a reduction read: the per-workgroup partials on
     // one GPU; the all-reduced sums (one "partial" per scalar) across ranks
     const double *rr_part = partR.p, *bb_part = partB.p;
@@ -652,17 +656,20 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             hipLaunchKernelGGL(k_arn_head<2>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv32.p, zp, ctl.p, o->rtol,
-                               o->atol, bb_part, rr_np, o->maxiter, q0, q1);
+                               o->atol, bb_part, rr_np, o->maxiter, q0, q1,
+                               (first && j == 0) ? 1 : 0);
         else if (dense)
             hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
-                               o->atol, bb_part, rr_np, o->maxiter, q0, q1);
+                               o->atol, bb_part, rr_np, o->maxiter, q0, q1,
+                               (first && j == 0) ? 1 : 0);
         else
             hipLaunchKernelGGL(k_arn_head<0>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
-                               o->atol, bb_part, rr_np, o->maxiter, q0, q1);
+                               o->atol, bb_part, rr_np, o->maxiter, q0, q1,
+                               (first && j == 0) ? 1 : 0);
         if (dd) DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, z.p, done_ptr(),
                                 nullptr));
@@ -719,7 +726,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
 
 int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
                       dns_solve_stats *st, const std::function<int()> &prologue,
-                      uint64_t prologue_key) {
+                      uint64_t prologue_key, bool prologue_has_resid) {
     const int m = std::max(1, std::min(o->restart, kMaxRestart));
     DNS_TRY(ensure_workspace(m));
     const size_t need_hist = (size_t)o->maxiter + 2 * kMaxRestart + 8;
@@ -749,12 +756,11 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             (uint64_t)popts.cheb_degree, (uint64_t)popts.schur,
             (uint64_t)first, (uint64_t)fhat_explicit, (uint64_t)fuse_dots};
         DNS_TRY(run_cached(key, graph, [&]() -> int {
-            if (first) {
-                if (prologue) DNS_TRY(prologue());
-                // reset total_it, hist_len, conv, status for this solve
-                DNS_HIP(hipMemsetAsync(ctl.p, 0, sizeof(CtlHeader), stream));
-            }
-            return enqueue_cycle(b, x, c, o);
+            if (first && prologue) DNS_TRY(prologue());
+            // (the counters of the previous solve are reset by the head
+            // kernel of the first cycle)
+            return enqueue_cycle(b, x, c, o, first,
+                                 first && prologue_has_resid && !dist());
         }));
         first = false;
         if (pipeline_c > 0) {
@@ -1218,14 +1224,14 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv32.p, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
-                                           h->gridS, 1 << 30, 0, np);
+                                           h->gridS, 1 << 30, 0, np, 0);
                     else
                         hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, s, n,
                                            nv, np, j, h->w.p, h->partN.p,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv.p, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
-                                           h->gridS, 1 << 30, 0, np);
+                                           h->gridS, 1 << 30, 0, np, 0);
                     break;
                 case 1:
                     DNS_TRY(h->apply_fhat_part(h->V.p + (size_t)j * h->ld, zp,

@@ -116,7 +116,9 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
            double *__restrict__ V, size_t ld, const void *__restrict__ sinv,
            double *__restrict__ zp, DnsCtl *ctl, double rtol, double atol,
            const double *__restrict__ bb_part, int bb_nparts, int maxiter,
-           int prow0, int prow1) {
+           int prow0, int prow1, int first) {
+    // `first` (only with j == 0): first cycle of a solve -- the counters of the
+    // previous solve still sit in the control block and are reset here
     // [prow0, prow1): the Schur rows this rank computes (all of them on one
     // GPU); normalisation and the control block are done by every rank alike
     if (j > 0 && ctl->done) return;
@@ -130,8 +132,8 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     if (j == 0) {
         bn = sqrt(sc[1]);
         tol = fmax(rtol * bn, atol);
-        stop = !(hn > tol) || isnan(hn) || ctl->total_it >= maxiter ||
-               ctl->status != DNS_OK;
+        stop = !(hn > tol) || isnan(hn) ||
+               (!first && (ctl->total_it >= maxiter || ctl->status != DNS_OK));
     }
     if (!stop && hn > 0.0) {
         const double scale = 1.0 / hn;
@@ -155,6 +157,12 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (j == 0) {
+            if (first) {
+                ctl->total_it = 0;
+                ctl->hist_len = 0;
+                ctl->conv = 0;
+                ctl->status = DNS_OK;
+            }
             ctl->jdone = 0;
             ctl->zero = 0;
             ctl->beta = hn;

@@ -221,7 +221,7 @@ struct dns_saddle {
     typedef int (*enqueue_fn)(void *ctx);
     // enqueue one GMRES cycle of `c` iterations (capturable: no sync inside)
     int enqueue_cycle(const double *b, double *x, int c,
-                      const dns_solve_opts *o);
+                      const dns_solve_opts *o, bool first, bool have_resid);
     // run `body` eagerly or as a cached graph identified by `key`
     template <typename Body>
     int run_cached(const std::vector<uint64_t> &key, bool use_graph,
@@ -251,7 +251,7 @@ struct dns_saddle {
     int gmres(const double *b, double *x, const dns_solve_opts *o,
               dns_solve_stats *st,
               const std::function<int()> &prologue = nullptr,
-              uint64_t prologue_key = 0);
+              uint64_t prologue_key = 0, bool prologue_has_resid = false);
     int bicgstab(const double *b, double *x, const dns_solve_opts *o,
                  dns_solve_stats *st);
     int true_residual(const double *b, const double *x, double *out);
