@@ -579,7 +579,9 @@ void dns_saddle::drop_graphs() {
 template <typename Body>
 int dns_saddle::run_cached(const std::vector<uint64_t> &key, bool use_graph,
                            Body body) {
-    if (!use_graph) return body();
+    // inside an enclosing capture (several time steps in one graph) the body
+    // is simply enqueued into that capture
+    if (!use_graph || capturing) return body();
     for (auto &g : graphs)
         if (g.key == key) {
             DNS_HIP(hipGraphLaunch(g.exec, stream));
@@ -588,7 +590,9 @@ int dns_saddle::run_cached(const std::vector<uint64_t> &key, bool use_graph,
     GraphEntry ge;
     ge.key = key;
     DNS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    capturing = true;
     const int rc = body();
+    capturing = false;
     hipError_t e = hipStreamEndCapture(stream, &ge.graph);
     if (rc != DNS_OK) {
         if (ge.graph) (void)hipGraphDestroy(ge.graph);

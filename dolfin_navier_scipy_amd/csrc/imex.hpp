@@ -23,6 +23,7 @@ struct dns_imex {
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     }
+    uint64_t step_key(const dns_imex_coeffs *cf) const;
     int step_device(const dns_imex_coeffs *cf, const dns_solve_opts *o,
                     dns_solve_stats *st, bool with_true_residual);
 };

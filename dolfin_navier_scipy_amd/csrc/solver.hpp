@@ -215,6 +215,7 @@ struct dns_saddle {
     int p1() const { return dist() ? st_p[comm->rank + 1] : np; }
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
+    bool capturing = false;           // a run_cached capture is open
     bool want_history = true;         // copy the residual history back
     size_t hist_cap = 0;
     std::vector<dns::GraphEntry> graphs;
