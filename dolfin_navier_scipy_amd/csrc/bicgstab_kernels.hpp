@@ -266,33 +266,62 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
     const int nsub = gridDim.x * (kBlock / LPR);
     double arr = 0.0, abb = 0.0;
     for (int row = sub; row < n; row += nsub) {
-        // K x0 over the row, x0 assembled from the history on the fly
-        double kx = 0.0;
-        {
-            const int k1 = k_rowptr[row + 1];
-            for (int k = k_rowptr[row] + sublane; k < k1; k += LPR) {
-                const int c = k_colidx[k];
-                double xv = e_c * x_c[c];
-                if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
-                if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
-                kx = fma(k_vals[k], xv, kx);
-            }
+        // three independent gather chains (K x0, R1 v, convection list): the
+        // first pass of each is issued level by level -- row pointers, then
+        // indices, then values -- so that the dependent-load latency is paid
+        // three times per row, not nine; longer rows finish in the loops below
+        const bool isv = row < nv;
+        const bool hasg = isv && gptr != nullptr;
+        int kk = k_rowptr[row] + sublane;
+        const int kend = k_rowptr[row + 1];
+        int rk = 0, rend = 0, gk = 0, gend = 0;
+        if (isv) {
+            rk = r_rowptr[row] + sublane;
+            rend = r_rowptr[row + 1];
         }
-        double rs = 0.0, cvs = 0.0;
-        if (row < nv) {
-            const int k1 = r_rowptr[row + 1];
-            for (int k = r_rowptr[row] + sublane; k < k1; k += LPR) {
-                const int c = r_colidx[k];
-                double vv = a_c * x_c[c];
-                if (a_p != 0.0) vv = fma(a_p, x_p[c], vv);
-                rs = fma(r_vals[k], vv, rs);
-            }
-            if (gptr) {
-                const int g1 = gptr[row + 1];
-                for (int k = gptr[row] + sublane; k < g1; k += LPR)
-                    cvs += cellvals[gidx[k]];
-            }
+        if (hasg) {
+            gk = gptr[row] + sublane;
+            gend = gptr[row + 1];
         }
+        const bool k_on = kk < kend, r_on = rk < rend, g_on = gk < gend;
+        int kc = 0, rc = 0, gi = 0;
+        double kval = 0.0, rval = 0.0;
+        if (k_on) {
+            kc = k_colidx[kk];
+            kval = k_vals[kk];
+        }
+        if (r_on) {
+            rc = r_colidx[rk];
+            rval = r_vals[rk];
+        }
+        if (g_on) gi = gidx[gk];
+        double kx = 0.0, rs = 0.0, cvs = 0.0;
+        if (k_on) {
+            double xv = e_c * x_c[kc];
+            if (e_p != 0.0) xv = fma(e_p, x_p[kc], xv);
+            if (e_pp != 0.0) xv = fma(e_pp, x_pp[kc], xv);
+            kx = kval * xv;
+        }
+        if (r_on) {
+            double vv = a_c * x_c[rc];
+            if (a_p != 0.0) vv = fma(a_p, x_p[rc], vv);
+            rs = rval * vv;
+        }
+        if (g_on) cvs = cellvals[gi];
+        for (kk += LPR; kk < kend; kk += LPR) {
+            const int c = k_colidx[kk];
+            double xv = e_c * x_c[c];
+            if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
+            if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
+            kx = fma(k_vals[kk], xv, kx);
+        }
+        for (rk += LPR; rk < rend; rk += LPR) {
+            const int c = r_colidx[rk];
+            double vv = a_c * x_c[c];
+            if (a_p != 0.0) vv = fma(a_p, x_p[c], vv);
+            rs = fma(r_vals[rk], vv, rs);
+        }
+        for (gk += LPR; gk < gend; gk += LPR) cvs += cellvals[gidx[gk]];
         kx = subwave_sum<LPR>(kx);
         rs = subwave_sum<LPR>(rs);
         if (gptr) cvs = subwave_sum<LPR>(cvs);

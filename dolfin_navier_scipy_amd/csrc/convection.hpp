@@ -4,7 +4,8 @@
 // `dts.get_convvec`, reference snu:1136-1140, snu:103-107, dts:427-472).
 //
 // Two kernels, no atomics (bitwise reproducible):
-//   k_conv_cells : one thread per cell; gathers the 12 local velocity values
+//   k_conv_cells : eight lanes per cell (one per quadrature point); gathers the
+//                  12 local velocity values
 //                  (inner dofs from the state vector, Dirichlet dofs from the
 //                  boundary-value table: `append_bcs_vec`, dts:49-64, fused),
 //                  7-point degree-5 quadrature, writes 12 local contributions
@@ -25,6 +26,10 @@ struct ConvTables {
 
 __constant__ ConvTables c_conv;
 
+// eight lanes per cell: lane q < 7 evaluates quadrature point q, lane 7 idles;
+// the twelve local sums are reduced over the eight lanes with xor shuffles and
+// lane l stores slots l and l + 8.  (One thread per cell left the kernel with
+// 18 workgroups and a serial chain of ~700 fp64 operations: ~10 us at N=2.)
 __global__ void __launch_bounds__(kBlock)
 k_conv_cells(int ncells, const int *__restrict__ cellmap,   // [12][ncells]
              const double *__restrict__ glam,               // [6][ncells]
@@ -32,60 +37,63 @@ k_conv_cells(int ncells, const int *__restrict__ cellmap,   // [12][ncells]
              const double *__restrict__ v_inner,
              const double *__restrict__ dbcvals,
              double *__restrict__ cellvals) {               // [12][ncells]
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= ncells) return;
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int c = t >> 3;
+    const int q = t & 7;
+    const bool live = c < ncells;        // whole 8-lane groups are live or not
+    const int cc = live ? c : 0;
+    const int qq = (q < 7) ? q : 0;
     double ul[6][2];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int m = cellmap[(size_t)(2 * a + i) * ncells + c];
+            const int m = cellmap[(size_t)(2 * a + i) * ncells + cc];
             ul[a][i] = (m >= 0) ? v_inner[m] : dbcvals[-m - 1];
         }
     double gl[3][2];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        gl[k][0] = glam[(size_t)(2 * k) * ncells + c];
-        gl[k][1] = glam[(size_t)(2 * k + 1) * ncells + c];
+        gl[k][0] = glam[(size_t)(2 * k) * ncells + cc];
+        gl[k][1] = glam[(size_t)(2 * k + 1) * ncells + cc];
     }
-    const double ar = area[c];
-    double fl[6][2];
+    double uq[2] = {0.0, 0.0};
+    double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // g[i][d] = d_d u_i
+    double ph[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) fl[a][0] = fl[a][1] = 0.0;
+    for (int a = 0; a < 6; ++a) {
+        ph[a] = c_conv.phi[qq][a];
+        const double d0 = c_conv.dphi[qq][a][0], d1 = c_conv.dphi[qq][a][1],
+                     d2 = c_conv.dphi[qq][a][2];
+        const double gx = d0 * gl[0][0] + d1 * gl[1][0] + d2 * gl[2][0];
+        const double gy = d0 * gl[0][1] + d1 * gl[1][1] + d2 * gl[2][1];
 #pragma unroll
-    for (int q = 0; q < 7; ++q) {
-        double uq[2] = {0.0, 0.0};
-        double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // g[i][d] = d_d u_i
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            const double ph = c_conv.phi[q][a];
-            const double gx = c_conv.dphi[q][a][0] * gl[0][0] +
-                              c_conv.dphi[q][a][1] * gl[1][0] +
-                              c_conv.dphi[q][a][2] * gl[2][0];
-            const double gy = c_conv.dphi[q][a][0] * gl[0][1] +
-                              c_conv.dphi[q][a][1] * gl[1][1] +
-                              c_conv.dphi[q][a][2] * gl[2][1];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                uq[i] = fma(ph, ul[a][i], uq[i]);
-                g[i][0] = fma(gx, ul[a][i], g[i][0]);
-                g[i][1] = fma(gy, ul[a][i], g[i][1]);
-            }
-        }
-        const double wq = c_conv.qw[q] * ar;
-        const double cv0 = wq * (g[0][0] * uq[0] + g[0][1] * uq[1]);
-        const double cv1 = wq * (g[1][0] * uq[0] + g[1][1] * uq[1]);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            fl[a][0] = fma(c_conv.phi[q][a], cv0, fl[a][0]);
-            fl[a][1] = fma(c_conv.phi[q][a], cv1, fl[a][1]);
+        for (int i = 0; i < 2; ++i) {
+            uq[i] = fma(ph[a], ul[a][i], uq[i]);
+            g[i][0] = fma(gx, ul[a][i], g[i][0]);
+            g[i][1] = fma(gy, ul[a][i], g[i][1]);
         }
     }
+    const double wq = (q < 7 && live) ? c_conv.qw[qq] * area[cc] : 0.0;
+    const double cv0 = wq * (g[0][0] * uq[0] + g[0][1] * uq[1]);
+    const double cv1 = wq * (g[1][0] * uq[0] + g[1][1] * uq[1]);
+    double mine = 0.0, mine8 = 0.0;     // slots q and q + 8 after the reduction
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            cellvals[(size_t)(2 * a + i) * ncells + c] = fl[a][i];
+    for (int sl = 0; sl < 12; ++sl) {
+        double v = ph[sl >> 1] * ((sl & 1) ? cv1 : cv0);
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        if (sl < 8) {
+            if (q == sl) mine = v;
+        } else {
+            if (q == sl - 8) mine8 = v;
+        }
+    }
+    if (live) {
+        cellvals[(size_t)q * ncells + c] = mine;
+        if (q < 4) cellvals[(size_t)(q + 8) * ncells + c] = mine8;
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -110,7 +118,7 @@ struct dns_conv {
     dns::DevBuf<double> glam, area, dbcvals, cellvals;
     // element kernel alone (the gather is fused into the step prologue)
     int enqueue_cells(const double *v_dev, hipStream_t s) {
-        const int g1 = (ncells + dns::kBlock - 1) / dns::kBlock;
+        const int g1 = (8 * ncells + dns::kBlock - 1) / dns::kBlock;
         hipLaunchKernelGGL(dns::k_conv_cells, g1, dns::kBlock, 0, s, ncells,
                            cellmap.p, glam.p, area.p, v_dev, dbcvals.p,
                            cellvals.p);
