@@ -159,8 +159,8 @@ def main():
     ap.add_argument('--method', default='gmres')
     ap.add_argument('--cheb', type=int, default=6)
     ap.add_argument('--rtol', type=float, default=1e-10)
-    ap.add_argument('--extrap', type=int, default=2,
-                    help='warm start: 0 none, 1 linear, 2 quadratic')
+    ap.add_argument('--extrap', type=int, default=3,
+                    help='warm start: 0 none, 1 linear, 2 quadratic, 3 cubic')
     ap.add_argument('--fp32', type=int, default=1,
                     help='store the explicit preconditioner matrices in fp32')
     ap.add_argument('--drop', type=float, default=3e-3,

@@ -236,7 +236,7 @@ k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
 // n rows of K; replaces gather + k_imex_rhs + k_lincomb* + k_resid_norm):
 //   nfc_c = scale * (convection gather)            [if a device operator is on]
 //   b_v   = R1 (a_c v_c + a_p v_p) + cn_c nfc_c + cn_o nfc_o + g ;  b_p = gp
-//   x0    = e_c x_c + e_p x_p + e_pp x_pp          (warm start)
+//   x0    = e_c x_c + e_p x_p + e_pp x_pp + e_p3 x_p3   (warm start)
 //   r     = b - K x0 ,  partials of ||r||^2 and ||b||^2
 // K x0 is formed from the history vectors directly (x0 of other rows is not
 // available inside the launch): up to three gathers per non-zero.
@@ -250,8 +250,9 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
                 const int *__restrict__ r_colidx,
                 const double *__restrict__ r_vals,
                 const double *__restrict__ x_c, const double *__restrict__ x_p,
-                const double *__restrict__ x_pp, double e_c, double e_p,
-                double e_pp, double a_c, double a_p,
+                const double *__restrict__ x_pp,
+                const double *__restrict__ x_p3, double e_c, double e_p,
+                double e_pp, double e_p3, double a_c, double a_p,
                 double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
                 double cn_c, double cn_o, const double *__restrict__ g,
                 const double *__restrict__ gp, const int *__restrict__ gptr,
@@ -300,6 +301,7 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
             double xv = e_c * x_c[kc];
             if (e_p != 0.0) xv = fma(e_p, x_p[kc], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[kc], xv);
+            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[kc], xv);
             kx = kval * xv;
         }
         if (r_on) {
@@ -313,6 +315,7 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
             double xv = e_c * x_c[c];
             if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
+            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[c], xv);
             kx = fma(k_vals[kk], xv, kx);
         }
         for (rk += LPR; rk < rend; rk += LPR) {
@@ -337,6 +340,7 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
             double xv = e_c * x_c[row];
             if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
+            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[row], xv);
             const double rv = bv - kx;
             b[row] = bv;
             x0[row] = xv;
@@ -360,6 +364,16 @@ k_lincomb2(int n, double e_c, const double *__restrict__ x_c, double e_p,
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
          i += gridDim.x * kBlock)
         out[i] = fma(e_c, x_c[i], e_p * x_p[i]);
+}
+
+// x0 = 4 x_c - 6 x_p + 4 x_pp - x_p3  (cubic extrapolation of the last four)
+__global__ void __launch_bounds__(kBlock)
+k_lincomb4(int n, const double *__restrict__ x_c,
+           const double *__restrict__ x_p, const double *__restrict__ x_pp,
+           const double *__restrict__ x_p3, double *__restrict__ out) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock)
+        out[i] = 4.0 * x_c[i] - 6.0 * x_p[i] + 4.0 * x_pp[i] - x_p3[i];
 }
 
 // x0 = 3 x_c - 3 x_p + x_pp  (quadratic extrapolation of the last three steps)

@@ -7,11 +7,23 @@ struct dns_imex {
     dns_saddle *sys = nullptr;
     dns::CsrDev R1;
     // two solution-space vectors [v; p~] (current, previous) + work
-    dns::DevBuf<double> xs[4];     // current, previous, pre-previous, work
-    dns::DevBuf<double> ck[3];     // checkpoint of the history for a batch
+    // current, previous, pre-previous, pre-pre-previous, work
+    dns::DevBuf<double> xs[5];
+    dns::DevBuf<double> ck[4];     // checkpoint of the history for a batch
     dns::DevBuf<double> ckn[2];    // ... and of the convection history
-    int cur = 0, prev = 1, pprev = 2, work = 3;
-    int nsol = 0;                  // how many valid solution vectors (0..3)
+    int cur = 0, prev = 1, pprev = 2, p3 = 3, work = 4;
+    int nsol = 0;                  // how many valid solution vectors (0..4)
+    long steps_enqueued = 0;       // counts step_device calls (graph replay
+                                   // must advance the host state itself)
+    void rotate_host() {           // p3 <- pprev <- prev <- cur <- new
+        const int old = p3;
+        p3 = pprev;
+        pprev = prev;
+        prev = cur;
+        cur = work;
+        work = old;
+        if (nsol < 4) nsol++;
+    }
     dns::DevBuf<double> nfc[2];
     int nc = 0, no = 1;
     dns::DevBuf<double> g, gp, b;

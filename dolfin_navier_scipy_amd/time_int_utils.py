@@ -28,7 +28,7 @@ __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 
 # solver settings of the time loops; `rtol` is relative to ||rhs||
 SOLVER = dict(method='gmres', rtol=1e-12, maxiter=400, restart=60,
-              cheb_degree=4, schur='auto', extrapolate=2, device=0,
+              cheb_degree=4, schur='auto', extrapolate=3, device=0,
               check_every=2, use_graph=True)
 
 
