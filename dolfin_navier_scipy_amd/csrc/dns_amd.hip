@@ -537,6 +537,11 @@ int dns_saddle::ensure_workspace(int m) {
         drop_graphs();               // graphs hold the old buffer address
         DNS_TRY(V.alloc(need));
     }
+    if (Z.n < (size_t)m * ld) {
+        DNS_HIP(hipStreamSynchronize(stream));
+        drop_graphs();
+        DNS_TRY(Z.alloc((size_t)m * ld));
+    }
     return DNS_OK;
 }
 
@@ -650,9 +655,12 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     const int q0 = p0(), q1 = p1();
     // workgroups of the head kernel: one workgroup per Schur row
     const int gridA = dense ? std::max(gridD, std::min(q1 - q0, 2048)) : gridD;
-    double *zp = z.p + nv;
     double *hsum = dsum.p + 2;           // all-reduced Gram-Schmidt dots
     for (int j = 0; j < c; ++j) {
+        // one GPU: the preconditioned vectors are kept (Z_j) for the
+        // correction behind the cycle
+        double *zj = dd ? z.p : Z.p + (size_t)j * ld;
+        double *zp = zj + nv;
         const double *src = (j == 0) ? r.p : w.p;
         const double *spart = (j == 0) ? rr_part : partN.p;
         const int snp = (j == 0) ? rr_np : gridD;
@@ -675,14 +683,14 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
                                (first && j == 0) ? 1 : 0);
         if (dd) DNS_TRY(comm->allgatherv(zp, st_p, stream));
-        DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, z.p, done_ptr(),
+        DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, zj, done_ptr(),
                                 nullptr));
         if (fuse_dots) {
             DNS_LPR_SWITCH(
                 K.lpr,
                 hipLaunchKernelGGL(k_spmv_multidot<L>, gridC, kBlock, 0,
                                    stream, n, K.rowptr.p, K.colidx.p,
-                                   K.vals.p, z.p, w.p, V.p, ld, j, partA.p,
+                                   K.vals.p, zj, w.p, V.p, ld, j, partA.p,
                                    gridC, ctl.p, n0, n1));
         } else {
             DNS_LPR_SWITCH(
@@ -690,7 +698,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 hipLaunchKernelGGL(k_spmv_guard<L>,
                                    grid_for_rows(n1 - n0, K.lpr), kBlock, 0,
                                    stream, n, K.rowptr.p, K.colidx.p, K.vals.p,
-                                   z.p, w.p, ctl.p, n0, n1));
+                                   zj, w.p, ctl.p, n0, n1));
             if (dd) DNS_TRY(comm->allgatherv(w.p, st_n, stream));
             // full-vector dots (every rank alike once w is gathered)
             hipLaunchKernelGGL(k_multidot, gridC, kBlock, 0, stream, n, V.p,
@@ -721,9 +729,14 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     }
     hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
                        ctl.p, histdev.p, (int)hist_cap, o->maxiter);
-    hipLaunchKernelGGL(k_basis_combine, gridD, kBlock, 0, stream, n, V.p, ld,
-                       ctl.p, u.p);
-    DNS_TRY(apply_precond(u.p, z.p, zero_ptr(), x));
+    if (dd) {
+        hipLaunchKernelGGL(k_basis_combine, gridD, kBlock, 0, stream, n, V.p,
+                           ld, ctl.p, u.p);
+        DNS_TRY(apply_precond(u.p, z.p, zero_ptr(), x));
+    } else {
+        hipLaunchKernelGGL(k_basis_combine_acc, gridD, kBlock, 0, stream, n,
+                           Z.p, ld, ctl.p, x);
+    }
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

@@ -12,8 +12,9 @@
 //  (E  k_orth          second Gram-Schmidt pass + ||w||^2)
 //
 // and per cycle: k_resid_norm (r = b - K x, ||r||^2, ||b||^2) in front,
-// k_arn_tail (last column, y = R^-1 g, history), k_basis_combine and the
-// correction x += P^-1 (V y) behind.  `j` is a plain kernel argument: a cycle
+// k_arn_tail (last column, y = R^-1 g, history) and the correction behind:
+// x += Z y with the kept Z_j = P^-1 V_j on one GPU (k_basis_combine_acc), or
+// k_basis_combine + x += P^-1 (V y) in the row-partitioned solve.  `j` is a plain kernel argument: a cycle
 // is captured as ONE hipGraph, every node has its own arguments, and the
 // device flag `ctl->done` turns the nodes after convergence into no-ops.
 //
@@ -392,6 +393,26 @@ k_basis_combine(int n, const double *__restrict__ V, size_t ld,
         for (int i = 0; i < jcols; ++i)
             s = fma(y[i], V[(size_t)i * ld + e], s);
         u[e] = s;
+    }
+}
+
+// x += sum_{i<jdone} y_i Z_i  with Z_i = P^-1 V_i kept from the Arnoldi steps
+// (the "flexible" form of the correction: no preconditioner apply behind the
+// cycle)
+__global__ void __launch_bounds__(kBlock)
+k_basis_combine_acc(int n, const double *__restrict__ Z, size_t ld,
+                    const DnsCtl *ctl, double *__restrict__ x) {
+    __shared__ double y[kMaxRestart];
+    const int jcols = ctl->jdone;
+    if (jcols == 0) return;
+    if (threadIdx.x < jcols) y[threadIdx.x] = ctl->y[threadIdx.x];
+    __syncthreads();
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+         e += gridDim.x * kBlock) {
+        double s = x[e];
+        for (int i = 0; i < jcols; ++i)
+            s = fma(y[i], Z[(size_t)i * ld + e], s);
+        x[e] = s;
     }
 }
 
