@@ -165,8 +165,9 @@ def main():
                     help='store the explicit preconditioner matrices in fp32')
     ap.add_argument('--drop', type=float, default=3e-3,
                     help='relative drop tolerance of the explicit polynomial')
-    ap.add_argument('--reorth', type=int, default=0,
-                    help='1: Gram-Schmidt applied twice (CGS2), 0: once')
+    ap.add_argument('--reorth', type=int, default=2,
+                    help='1: Gram-Schmidt applied twice (CGS2), 0: once, '
+                    '2: once, folded into the head kernel of the next step')
     ap.add_argument('--fhat', default='auto',
                     help="F^-1 approximation: 'cheb' recurrence, 'explicit' "
                     "polynomial matrix, 'auto'")
@@ -262,7 +263,7 @@ def main():
     opts = saddle.solve_opts(method=args.method, rtol=args.rtol, maxiter=400,
                              restart=60, check_every=args.check_every,
                              use_graph=not args.eager,
-                             reorth=bool(args.reorth))
+                             reorth=args.reorth)
 
     def barrier():
         _capi.device_synchronize(device)

@@ -166,7 +166,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     gridD = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock,
                                                        1024));
     const size_t pmax = (size_t)std::max(std::max(gridS, gridD), nred);
-    DNS_TRY(partA.alloc((size_t)(kMaxRestart + 1) * pmax));
+    DNS_TRY(partA.alloc((size_t)(kMaxRestart + 2) * pmax));
     DNS_TRY(partE.alloc((size_t)(kMaxRestart + 1) * pmax));
     DNS_TRY(partN.alloc(pmax));
     DNS_TRY(partR.alloc(pmax));
@@ -624,8 +624,10 @@ static inline uint64_t bits_of(double v) {
 // correction x += P^-1 (V y).  Kernels after convergence return at once
 // (ctl->done), so `c` may overshoot.  Nothing here synchronises or allocates.
 int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
-                              const dns_solve_opts *o, bool first,
+                              const dns_solve_opts *o, int first,
                               bool have_resid) {
+    // `first`: 1 = the head kernel of this cycle resets the solve's counters,
+    // 2 = only its status (going on after a Gram-Schmidt fallback)
     const bool dd = dist();
     const int n0 = r0n(), n1 = r1n();
     // r = b - K x over this rank's rows, ||r||^2, ||b||^2 (unless the caller's
@@ -656,6 +658,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     // workgroups of the head kernel: one workgroup per Schur row
     const int gridA = dense ? std::max(gridD, std::min(q1 - q0, 2048)) : gridD;
     double *hsum = dsum.p + 2;           // all-reduced Gram-Schmidt dots
+    // reorth == 2: Gram-Schmidt folded into the next head kernel (one GPU)
+    const bool fusedgs = o->reorth == 2 && !dd && fuse_dots;
     for (int j = 0; j < c; ++j) {
         // one GPU: the preconditioned vectors are kept (Z_j) for the
         // correction behind the cycle
@@ -664,24 +668,40 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         const double *src = (j == 0) ? r.p : w.p;
         const double *spart = (j == 0) ? rr_part : partN.p;
         const int snp = (j == 0) ? rr_np : gridD;
-        if (dense && fp32_store)
+        if (fusedgs && j > 0) {
+            if (dense && fp32_store)
+                hipLaunchKernelGGL(k_arn_head_f<2>, gridA, kBlock, 0, stream, n,
+                                   nv, np, j, w.p, partA.p, gridC, V.p, ld,
+                                   Z.p, (const void *)sinv32.p, ctl.p,
+                                   o->maxiter);
+            else if (dense)
+                hipLaunchKernelGGL(k_arn_head_f<1>, gridA, kBlock, 0, stream, n,
+                                   nv, np, j, w.p, partA.p, gridC, V.p, ld,
+                                   Z.p, (const void *)sinv.p, ctl.p,
+                                   o->maxiter);
+            else
+                hipLaunchKernelGGL(k_arn_head_f<0>, gridA, kBlock, 0, stream, n,
+                                   nv, np, j, w.p, partA.p, gridC, V.p, ld,
+                                   Z.p, (const void *)sinv.p, ctl.p,
+                                   o->maxiter);
+        } else if (dense && fp32_store)
             hipLaunchKernelGGL(k_arn_head<2>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv32.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (first && j == 0) ? 1 : 0);
+                               (j == 0) ? first : 0);
         else if (dense)
             hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (first && j == 0) ? 1 : 0);
+                               (j == 0) ? first : 0);
         else
             hipLaunchKernelGGL(k_arn_head<0>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (first && j == 0) ? 1 : 0);
+                               (j == 0) ? first : 0);
         if (dd) DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, zj, done_ptr(),
                                 nullptr));
@@ -691,7 +711,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 hipLaunchKernelGGL(k_spmv_multidot<L>, gridC, kBlock, 0,
                                    stream, n, K.rowptr.p, K.colidx.p,
                                    K.vals.p, zj, w.p, V.p, ld, j, partA.p,
-                                   gridC, ctl.p, n0, n1));
+                                   gridC, ctl.p, n0, n1, fusedgs ? 1 : 0));
+            if (fusedgs) continue;       // no Gram-Schmidt kernel
         } else {
             DNS_LPR_SWITCH(
                 K.lpr,
@@ -716,7 +737,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             hpart = hsum;
             hnp = 1;
         }
-        if (o->reorth) {
+        if (o->reorth == 1) {
             hipLaunchKernelGGL(k_orth<1>, gridD, kBlock, 0, stream, n, V.p, ld,
                                w.p, hpart, hnp, j, 0, partE.p, gridD, ctl.p);
             hipLaunchKernelGGL(k_orth<0>, gridD, kBlock, 0, stream, n, V.p, ld,
@@ -727,8 +748,12 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                w.p, hpart, hnp, j, 0, partN.p, gridD, ctl.p);
         }
     }
-    hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
-                       ctl.p, histdev.p, (int)hist_cap, o->maxiter);
+    if (fusedgs)
+        hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partA.p, gridC,
+                           ctl.p, histdev.p, (int)hist_cap, o->maxiter, 1);
+    else
+        hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
+                           ctl.p, histdev.p, (int)hist_cap, o->maxiter, 0);
     if (dd) {
         hipLaunchKernelGGL(k_basis_combine, gridD, kBlock, 0, stream, n, V.p,
                            ld, ctl.p, u.p);
@@ -764,22 +789,26 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     // dots fused into the K apply while the system is launch-latency bound
     fuse_dots = n <= 400000;
     int restarts = 0;
-    bool first = true;
+    bool first = true;          // prologue + first cycle of the solve
+    int reset = 1;              // what the head kernel resets (k_arn_head)
+    dns_solve_opts oo = *o;
+    // (eight solves in a row that fell back: stop trying on this system)
+    if (gs_fallbacks >= 8 && oo.reorth == 2) oo.reorth = 0;
     while (true) {
         std::vector<uint64_t> key = {
             1u, (uint64_t)(uintptr_t)b, (uint64_t)(uintptr_t)x, (uint64_t)c,
-            (uint64_t)o->reorth, (uint64_t)o->maxiter, bits_of(o->rtol),
-            bits_of(o->atol), first ? prologue_key : 0u,
+            (uint64_t)oo.reorth, (uint64_t)oo.maxiter, bits_of(oo.rtol),
+            bits_of(oo.atol), first ? prologue_key : 0u,
             (uint64_t)popts.cheb_degree, (uint64_t)popts.schur,
-            (uint64_t)first, (uint64_t)fhat_explicit, (uint64_t)fuse_dots};
+            (uint64_t)first + 2u * (uint64_t)reset, (uint64_t)fhat_explicit,
+            (uint64_t)fuse_dots};
         DNS_TRY(run_cached(key, graph, [&]() -> int {
             if (first && prologue) DNS_TRY(prologue());
-            // (the counters of the previous solve are reset by the head
-            // kernel of the first cycle)
-            return enqueue_cycle(b, x, c, o, first,
+            return enqueue_cycle(b, x, c, &oo, reset,
                                  first && prologue_has_resid && !dist());
         }));
         first = false;
+        reset = 0;
         if (pipeline_c > 0) {
             // pipelined time stepping: one cycle, nobody waits; the device
             // accumulates iterations / failures for the batch (k_arn_tail)
@@ -788,12 +817,22 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             return DNS_OK;
         }
         DNS_TRY(read_header());
+        if (hdr_host->status == kGsFallback) {
+            // the fused Gram-Schmidt gave up on its norm: go on from the
+            // current iterate with the explicit kernel
+            gs_fallbacks++;
+            oo.reorth = 0;
+            reset = 2;
+            restarts++;
+            continue;
+        }
         if (hdr_host->status != DNS_OK || hdr_host->conv ||
-            hdr_host->total_it >= o->maxiter || std::isnan(hdr_host->resnorm))
+            hdr_host->total_it >= oo.maxiter || std::isnan(hdr_host->resnorm))
             break;
         restarts++;
         c = std::min(m, std::max(2 * c, 8));
     }
+    if (o->reorth == 2 && oo.reorth == 2) gs_fallbacks = 0;   // clean fused solve
     const int total = hdr_host->total_it;
     last_iters = total;
     history.assign((size_t)std::max(1, hdr_host->hist_len), hdr_host->resnorm);
@@ -1262,7 +1301,7 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            h->K.colidx.p, h->K.vals.p, h->z.p,
                                            h->w.p, h->V.p, h->ld, j,
                                            h->partA.p, h->gridC, h->ctl.p, 0,
-                                           n));
+                                           n, 0));
                     break;
                 case 3:
                     hipLaunchKernelGGL(k_orth<0>, h->gridD, kBlock, 0, s, n,
@@ -1282,7 +1321,7 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                 case 5:
                     hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, s, 0,
                                        h->partN.p, h->gridD, h->ctl.p,
-                                       h->histdev.p, 0, 1 << 30);
+                                       h->histdev.p, 0, 1 << 30, 0);
                     break;
                 case 6:
                     hipLaunchKernelGGL(k_basis_combine, h->gridD, kBlock, 0, s,

@@ -118,8 +118,10 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
            double *__restrict__ zp, DnsCtl *ctl, double rtol, double atol,
            const double *__restrict__ bb_part, int bb_nparts, int maxiter,
            int prow0, int prow1, int first) {
-    // `first` (only with j == 0): first cycle of a solve -- the counters of the
-    // previous solve still sit in the control block and are reset here
+    // `first` (only with j == 0): 1 = first cycle of a solve -- the counters of
+    // the previous solve still sit in the control block and are reset here;
+    // 2 = the solve goes on after a Gram-Schmidt fallback: only the status is
+    // cleared
     // [prow0, prow1): the Schur rows this rank computes (all of them on one
     // GPU); normalisation and the control block are done by every rank alike
     if (j > 0 && ctl->done) return;
@@ -134,7 +136,8 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
         bn = sqrt(sc[1]);
         tol = fmax(rtol * bn, atol);
         stop = !(hn > tol) || isnan(hn) ||
-               (!first && (ctl->total_it >= maxiter || ctl->status != DNS_OK));
+               (first != 1 && ctl->total_it >= maxiter) ||
+               (first == 0 && ctl->status != DNS_OK);
     }
     if (!stop && hn > 0.0) {
         const double scale = 1.0 / hn;
@@ -158,12 +161,12 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (j == 0) {
-            if (first) {
+            if (first == 1) {
                 ctl->total_it = 0;
                 ctl->hist_len = 0;
                 ctl->conv = 0;
-                ctl->status = DNS_OK;
             }
+            if (first) ctl->status = DNS_OK;
             ctl->jdone = 0;
             ctl->zero = 0;
             ctl->beta = hn;
@@ -190,10 +193,12 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
                 const double *__restrict__ vals, const double *__restrict__ z,
                 double *__restrict__ w, const double *__restrict__ V, size_t ld,
                 int j, double *__restrict__ part, int nparts,
-                const DnsCtl *ctl, int row0, int row1) {
+                const DnsCtl *ctl, int row0, int row1, int with_ww) {
+    // with_ww: one more scalar, part[(j+1)*nparts + wg] = <w, w> (the norm of
+    // the orthogonalised vector then follows from Pythagoras, k_arn_head_f)
     if (ctl->done) return;
     (void)nrows;
-    constexpr int NQ = (kMaxRestart + LPR) / LPR;   // dots per lane
+    constexpr int NQ = (kMaxRestart + 1 + LPR) / LPR;   // dots per lane
     __shared__ double wred[kBlock / 64][NQ * LPR];
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
@@ -213,7 +218,11 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
         const double s = csr_row_dot<LPR>(rowptr, colidx, vals, z, row, sublane);
         if (sublane == 0) w[row] = s;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) acc[q] = fma(vq[q], s, acc[q]);
+        for (int q = 0; q < NQ; ++q) {
+            const double vv =
+                (with_ww && q * LPR + sublane == nvec) ? s : vq[q];
+            acc[q] = fma(vv, s, acc[q]);
+        }
     }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -224,10 +233,114 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
         if (lane < LPR) wred[wave][q * LPR + lane] = v;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nvec; i += kBlock) {
+    for (int i = threadIdx.x; i < nvec + (with_ww ? 1 : 0); i += kBlock) {
         double s = 0.0;
         for (int ww = 0; ww < kBlock / 64; ++ww) s += wred[ww][i];
         part[(size_t)i * nparts + blockIdx.x] = s;
+    }
+}
+
+// h_{j,j-1} of classical Gram-Schmidt without forming w - V h first:
+// ||w - V h||^2 = <w,w> - sum h_i^2 (V orthonormal).  hs = [h_0..h_{j-1}, <w,w>]
+// Cancellation: the relative error of the result is ~ eps <w,w> / (2 d), so
+// below d = 1e-8 <w,w> (error 1e-8) the value is not trusted (returns -1) and
+// the solve falls back to the explicit Gram-Schmidt kernel (kGsFallback); a
+// basis that has lost its orthogonality shows up the same way (d <= 0).
+__device__ __forceinline__ double pythagoras_norm(const double *hs, int j) {
+    double ss = 0.0;
+    for (int i = 0; i < j; ++i) ss = fma(hs[i], hs[i], ss);
+    const double d = hs[j] - ss;
+    if (!(d > 1e-8 * hs[j])) return -1.0;
+    return sqrt(d);
+}
+
+// head of Arnoldi step j >= 1 with the Gram-Schmidt update folded in ("fused"
+// orthogonalisation, one launch less per step): `w` is the RAW K z_{j-1},
+// `hpart` holds the partials of h_i = <V_i, w> (i < j) and of <w, w>.
+//   V_j  = (w - sum h_i V_i) / hn
+//   zp_j = -Sinv V_j,p = (-Sinv w_p - sum h_i zp_i) / hn    (zp_i kept in Z_i)
+template <int SK>
+__global__ void __launch_bounds__(kBlock)
+k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
+             const double *__restrict__ hpart, int hnparts,
+             double *__restrict__ V, size_t ld, double *__restrict__ Z,
+             const void *__restrict__ sinv, DnsCtl *ctl, int maxiter) {
+    if (ctl->done) return;
+    __shared__ double h[kMaxRestart + 2];
+    __shared__ double red4[4];
+    reduce_partials(hpart, hnparts, hnparts, j + 1, h);
+    const double hn = pythagoras_norm(h, j);
+    if (hn < 0.0) {
+        // column j-1 stays open: the cycle ends with the columns before it
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+#ifdef DNS_TRACE_GS
+            double ss = 0.0;
+            for (int i = 0; i < j; ++i) ss += h[i] * h[i];
+            printf("[gs] j=%d FALLBACK d/ww=%.3e\n", j, (h[j] - ss) / h[j]);
+#endif
+            ctl->status = kGsFallback;
+            ctl->done = 1;
+        }
+        return;
+    }
+    if (hn > 0.0) {
+        const double scale = 1.0 / hn;
+        double *vj = V + (size_t)j * ld;
+        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+             e += gridDim.x * kBlock) {
+            double we = w[e];
+            for (int i = 0; i < j; ++i)
+                we = fma(-h[i], V[(size_t)i * ld + e], we);
+            vj[e] = we * scale;
+        }
+        const double *wp = w + nv;
+        double *zp = Z + (size_t)j * ld + nv;
+        if (SK == 0) {
+            const double *sd = (const double *)sinv;
+            for (int r = blockIdx.x * kBlock + threadIdx.x; r < np;
+                 r += gridDim.x * kBlock) {
+                double we = wp[r];
+                for (int i = 0; i < j; ++i)
+                    we = fma(-h[i], V[(size_t)i * ld + nv + r], we);
+                zp[r] = -sd[r] * we * scale;
+            }
+        } else {
+            for (int row = blockIdx.x; row < np; row += gridDim.x) {
+                // the kept zp_i first: their loads overlap the dense row's
+                double corr = 0.0;
+                if (threadIdx.x == 0)
+                    for (int i = 0; i < j; ++i)
+                        corr = fma(h[i], Z[(size_t)i * ld + nv + row], corr);
+                double s0 = 0.0, s1 = 0.0;
+                if (SK == 1) {
+                    const double *ar = (const double *)sinv + (size_t)row * np;
+                    int c = threadIdx.x;
+                    for (; c + kBlock < np; c += 2 * kBlock) {
+                        s0 = fma(ar[c], wp[c], s0);
+                        s1 = fma(ar[c + kBlock], wp[c + kBlock], s1);
+                    }
+                    if (c < np) s0 = fma(ar[c], wp[c], s0);
+                } else {
+                    const float *ar = (const float *)sinv + (size_t)row * np;
+                    int c = threadIdx.x;
+                    for (; c + kBlock < np; c += 2 * kBlock) {
+                        s0 = fma((double)ar[c], wp[c], s0);
+                        s1 = fma((double)ar[c + kBlock], wp[c + kBlock], s1);
+                    }
+                    if (c < np) s0 = fma((double)ar[c], wp[c], s0);
+                }
+                const double s = block_sum(s0 + s1, red4);
+                if (threadIdx.x == 0) zp[row] = (-s - corr) * scale;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (int i = 0; i < j; ++i) ctl->hcol[i] = h[i];
+        givens_close(ctl, j - 1, hn, maxiter);
+#ifdef DNS_TRACE_GS
+        printf("[gs] j=%d hn/|w|=%.3e res=%.3e\n", j, hn / sqrt(h[j]),
+               ctl->resnorm);
+#endif
     }
 }
 
@@ -354,11 +467,27 @@ k_orth(int n, const double *__restrict__ V, size_t ld, double *__restrict__ w,
 __global__ void __launch_bounds__(kBlock)
 k_arn_tail(int c, const double *__restrict__ norm_part, int nparts,
            DnsCtl *ctl, double *__restrict__ histbuf, int hist_cap,
-           int maxiter) {
-    __shared__ double sc[1];
-    reduce_partials(norm_part, nparts, nparts, 1, sc);
+           int maxiter, int fused) {
+    // fused: `norm_part` holds the partials of h_0..h_{c-1} and <w, w> of the
+    // last step (no Gram-Schmidt kernel ran), else those of ||w||^2
+    __shared__ double sc[kMaxRestart + 2];
+    reduce_partials(norm_part, nparts, nparts, fused ? c + 1 : 1, sc);
     if (threadIdx.x != 0) return;
-    if (!ctl->done && c > 0) givens_close(ctl, c - 1, sqrt(sc[0]), maxiter);
+    if (!ctl->done && c > 0) {
+        double hn;
+        if (fused) {
+            hn = pythagoras_norm(sc, c);
+            for (int i = 0; i < c; ++i) ctl->hcol[i] = sc[i];
+        } else {
+            hn = sqrt(sc[0]);
+        }
+        if (hn < 0.0) {
+            ctl->status = kGsFallback;
+            ctl->done = 1;
+        } else {
+            givens_close(ctl, c - 1, hn, maxiter);
+        }
+    }
     const int jcols = ctl->jdone;
     for (int i = jcols - 1; i >= 0; --i) {
         double s = ctl->g[i];

@@ -14,6 +14,11 @@ namespace dns {
 // Krylov control block, lives in HBM; written only by workgroup 0 of the
 // kernels that close an iteration, read (never written) by everyone else.
 // ---------------------------------------------------------------------------
+// internal status (never leaves the library): the fused Gram-Schmidt could not
+// trust its norm; the host repeats from the current iterate with the explicit
+// kernel
+constexpr int kGsFallback = 100;
+
 struct DnsCtl {
     int jdone;       // completed Arnoldi columns of the current cycle
     int jpad;

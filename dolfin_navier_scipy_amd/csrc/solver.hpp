@@ -216,13 +216,15 @@ struct dns_saddle {
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open
+    int gs_fallbacks = 0;             // solves in a row whose fused Gram-Schmidt
+                                      // fell back (>= 8: not tried any more)
     bool want_history = true;         // copy the residual history back
     size_t hist_cap = 0;
     std::vector<dns::GraphEntry> graphs;
     typedef int (*enqueue_fn)(void *ctx);
     // enqueue one GMRES cycle of `c` iterations (capturable: no sync inside)
     int enqueue_cycle(const double *b, double *x, int c,
-                      const dns_solve_opts *o, bool first, bool have_resid);
+                      const dns_solve_opts *o, int first, bool have_resid);
     // run `body` eagerly or as a cached graph identified by `key`
     template <typename Body>
     int run_cached(const std::vector<uint64_t> &key, bool use_graph,

@@ -22,7 +22,8 @@ def solve_opts(method='gmres', restart=60, maxiter=400, reorth=True,
     C.load_library().dns_default_solve_opts(ct.byref(o))
     o.method = _METHODS[method.lower()] if isinstance(method, str) else method
     o.restart, o.maxiter = int(restart), int(maxiter)
-    o.reorth = 1 if reorth else 0
+    # True/1: CGS2, False/0: CGS once, 2: CGS once fused into the head kernel
+    o.reorth = 2 if (reorth == 2 and reorth is not True) else (1 if reorth else 0)
     o.rtol, o.atol = float(rtol), float(atol)
     o.check_every = int(check_every)
     o.use_graph = 1 if use_graph else 0

@@ -81,7 +81,9 @@ typedef struct dns_solve_opts {
     int32_t method;              /* DNS_METHOD_*                             */
     int32_t restart;             /* GMRES cycle length (<= 64)               */
     int32_t maxiter;             /* total inner iterations                   */
-    int32_t reorth;              /* 1: twice-applied Gram-Schmidt            */
+    int32_t reorth;              /* 0: classical Gram-Schmidt once, 1: twice,
+                                    2: once, folded into the next step's head
+                                       kernel (norm by Pythagoras; one GPU) */
     double  rtol;                /* stop at ||r|| <= max(rtol*||b||, atol)   */
     double  atol;
     int32_t check_every;         /* host polls the device flag every k its   */
