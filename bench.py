@@ -324,11 +324,21 @@ def main():
         else:
             traffic = None
         main_roof = roof_hbm if roof_hbm is not None else roof
+        # what plain streaming kernels get out of this HBM (2 GiB, fp64)
+        attain = None
+        if args.roofline_refine > 0:
+            attain = {k: saddle.hbm_probe(2 << 30, k, reps=20, device=device)
+                      for k in ('read', 'read8c', 'copy', 'triad')}
+            attain['read'] = max(attain['read'], attain.pop('read8c'))
         roofline = dict(bound='hbm', achieved=main_roof['achieved'],
                         peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=main_roof['achieved']/HBM_PEAK_GBS,
                         traffic=traffic,
                         kernel=main_roof['kernel'], detail=main_roof,
+                        attainable_GBs=attain,
+                        frac_of_attainable_read=(
+                            main_roof['achieved']/attain['read']
+                            if attain else None),
                         at_benchmark_size=roof)
         cpu = None
         parity = None

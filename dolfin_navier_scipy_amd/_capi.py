@@ -163,6 +163,8 @@ SIGNATURES = {
     'dns_spmv_bench': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr), ct.c_int32,
                                   ct.c_int32, ct.c_int32, c_double_p,
                                   c_double_p]),
+    'dns_hbm_probe': (ct.c_int, [ct.c_int, ct.c_int64, ct.c_int32, ct.c_int32,
+                                 c_double_p]),
 }
 
 _lib = None

@@ -1530,6 +1530,58 @@ int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
     return DNS_OK;
 }
 
+int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
+                  double *gbytes_per_s) {
+    if (!gbytes_per_s || reps < 1 || bytes < 4096 || kind < 0 || kind > 5)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    DNS_HIP(hipSetDevice(device));
+    ScopedStream ss;
+    DNS_HIP(hipStreamCreate(&ss.s));
+    // kinds 3..5: read with 8 loads in flight on grids of 8/16/32 blocks/CU
+    const int narr = (kind == 0 || kind >= 3) ? 1 : (kind == 1 ? 2 : 3);
+    const int64_t n2 = bytes / (16 * narr);       // double2 elements per array
+    DevBuf<double> a, b, c, part;
+    DNS_TRY(a.alloc((size_t)(2 * n2)));
+    if (narr > 1) DNS_TRY(b.alloc((size_t)(2 * n2)));
+    if (narr > 2) DNS_TRY(c.alloc((size_t)(2 * n2)));
+    const int grid = 256 * (kind == 3 ? 8 : (kind == 5 ? 32 : 16));
+    DNS_TRY(part.alloc((size_t)grid));
+    hipLaunchKernelGGL(k_fill_wave, 2048, kBlock, 0, ss.s, (int)std::min<int64_t>(2 * n2, 1 << 30), a.p, 0.37, 1.0, 0);
+    if (narr > 1) DNS_TRY(b.zero(ss.s));
+    if (narr > 2) DNS_TRY(c.zero(ss.s));
+    auto launch = [&]() {
+        if (kind >= 3)
+            hipLaunchKernelGGL(k_stream_read8, grid, kBlock, 0, ss.s, n2,
+                               (const dns_double2 *)a.p, part.p);
+        else if (kind == 0)
+            hipLaunchKernelGGL(k_stream_read, grid, kBlock, 0, ss.s, n2,
+                               (const dns_double2 *)a.p, part.p);
+        else if (kind == 1)
+            hipLaunchKernelGGL(k_stream_copy, grid, kBlock, 0, ss.s, n2,
+                               (const dns_double2 *)a.p, (dns_double2 *)b.p);
+        else
+            hipLaunchKernelGGL(k_stream_triad, grid, kBlock, 0, ss.s, n2,
+                               (const dns_double2 *)a.p,
+                               (const dns_double2 *)b.p, 0.5,
+                               (dns_double2 *)c.p);
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    hipEvent_t e0, e1;
+    DNS_HIP(hipEventCreate(&e0));
+    DNS_HIP(hipEventCreate(&e1));
+    DNS_HIP(hipEventRecord(e0, ss.s));
+    for (int i = 0; i < reps; ++i) launch();
+    DNS_HIP(hipEventRecord(e1, ss.s));
+    DNS_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DNS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    DNS_HIP(hipGetLastError());
+    *gbytes_per_s = (double)(16 * n2 * narr) * reps / (1e-3 * ms) * 1e-9;
+    return DNS_OK;
+}
+
 }  // extern "C"
 
 #include "imex_capi.inc"

@@ -552,6 +552,80 @@ k_schur_dense(int np, const VT *__restrict__ sinv,
     dense_rows_block<VT>(sinv, rp, np, -1.0, zp, xacc, red, row0, row1);
 }
 
+// plain streaming kernels: what the HBM delivers to a kernel of this library
+// (dns_hbm_probe); 16-byte accesses, grid-stride, fully coalesced
+typedef double dns_double2 __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(kBlock)
+k_stream_read(int64_t n2, const dns_double2 *__restrict__ a,
+              double *__restrict__ part) {
+    __shared__ double red[4];
+    double s0 = 0.0, s1 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + stride < n2; i += 2 * stride) {
+        const dns_double2 u = a[i], v = a[i + stride];
+        s0 += u.x + u.y;
+        s1 += v.x + v.y;
+    }
+    if (i < n2) {
+        const dns_double2 u = a[i];
+        s0 += u.x + u.y;
+    }
+    const double s = block_sum(s0 + s1, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// the same with eight 16-byte loads in flight per lane
+__global__ void __launch_bounds__(kBlock)
+k_stream_read8(int64_t n2, const dns_double2 *__restrict__ a,
+               double *__restrict__ part) {
+    __shared__ double red[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 7 * stride < n2; i += 8 * stride) {
+        const dns_double2 u0 = a[i], u1 = a[i + stride];
+        const dns_double2 u2 = a[i + 2 * stride], u3 = a[i + 3 * stride];
+        const dns_double2 u4 = a[i + 4 * stride], u5 = a[i + 5 * stride];
+        const dns_double2 u6 = a[i + 6 * stride], u7 = a[i + 7 * stride];
+        s0 += (u0.x + u0.y) + (u4.x + u4.y);
+        s1 += (u1.x + u1.y) + (u5.x + u5.y);
+        s2 += (u2.x + u2.y) + (u6.x + u6.y);
+        s3 += (u3.x + u3.y) + (u7.x + u7.y);
+    }
+    for (; i < n2; i += stride) {
+        const dns_double2 u = a[i];
+        s0 += u.x + u.y;
+    }
+    const double s = block_sum((s0 + s1) + (s2 + s3), red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_stream_copy(int64_t n2, const dns_double2 *__restrict__ a,
+              dns_double2 *__restrict__ b) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride)
+        b[i] = a[i];
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_stream_triad(int64_t n2, const dns_double2 *__restrict__ a,
+               const dns_double2 *__restrict__ b, double sc,
+               dns_double2 *__restrict__ c) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2;
+         i += stride) {
+        const dns_double2 u = a[i], v = b[i];
+        dns_double2 r;
+        r.x = fma(sc, v.x, u.x);
+        r.y = fma(sc, v.y, u.y);
+        c[i] = r;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_to_f32(int64_t n, const double *__restrict__ in, float *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;

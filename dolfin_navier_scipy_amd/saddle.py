@@ -296,3 +296,15 @@ def spmv_bench(A, variant='stream', reps=50, warmup=5, device=0):
         device, view.byref(), vid, int(reps), int(warmup),
         ct.byref(secs), ct.byref(chk)))
     return secs.value, chk.value
+
+
+def hbm_probe(nbytes=2 << 30, kind='read', reps=20, device=0):
+    """attainable HBM bandwidth [GB/s] of plain streaming kernels over
+    `nbytes` (`kind`: 'read' | 'copy' | 'triad')"""
+    out = ct.c_double(0.)
+    C.check(C.load_library().dns_hbm_probe(
+        int(device), int(nbytes),
+        {'read': 0, 'copy': 1, 'triad': 2, 'read8a': 3, 'read8b': 4,
+         'read8c': 5}[kind],
+        int(reps), ct.byref(out)))
+    return out.value

@@ -290,6 +290,13 @@ int dns_dense_inverse(int device, int32_t n, double *a_rowmajor);
 int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
                    int32_t warmup, double *avg_seconds, double *checksum);
 
+/* attainable HBM bandwidth of the device, measured with plain streaming
+ * kernels over `bytes` of fp64 data (kind 0: read + reduce, 1: copy,
+ * 2: triad a = b + s c); reports GB/s of the bytes the kernel moves.  The SpMV
+ * roofline fraction is quoted against the 8 TB/s peak AND against this. */
+int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
+                  double *gbytes_per_s);
+
 #ifdef __cplusplus
 }
 #endif
