@@ -163,6 +163,25 @@ SIGNATURES = {
     'dns_spmv_bench': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr), ct.c_int32,
                                   ct.c_int32, ct.c_int32, c_double_p,
                                   c_double_p]),
+    'dns_conv_bind_pattern': (ct.c_int, [ct.c_void_p, ct.POINTER(dns_csr)]),
+    'dns_conv_assemble': (ct.c_int, [ct.c_void_p, c_double_p, ct.c_int32,
+                                     c_double_p, c_double_p, c_double_p]),
+    'dns_trap_create': (ct.c_int, [ct.c_void_p, ct.c_void_p, c_double_p,
+                                   c_double_p, ct.c_int32,
+                                   ct.POINTER(ct.c_void_p)]),
+    'dns_trap_destroy': (None, [ct.c_void_p]),
+    'dns_trap_set_rhs': (ct.c_int, [ct.c_void_p, c_double_p, c_double_p]),
+    'dns_trap_traj_write': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32,
+                                       c_double_p]),
+    'dns_trap_traj_read': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32,
+                                      c_double_p]),
+    'dns_trap_start': (ct.c_int, [ct.c_void_p, c_double_p, ct.c_int32]),
+    'dns_trap_step': (ct.c_int, [ct.c_void_p, ct.c_double, ct.c_int32,
+                                 ct.c_int32, ct.c_int32, ct.c_int32,
+                                 ct.c_int32, ct.POINTER(dns_solve_opts),
+                                 ct.POINTER(dns_solve_stats)]),
+    'dns_trap_get_state': (ct.c_int, [ct.c_void_p, c_double_p, c_double_p]),
+    'dns_trap_update_norm': (ct.c_int, [ct.c_void_p, c_double_p]),
     'dns_hbm_probe': (ct.c_int, [ct.c_int, ct.c_int64, ct.c_int32, ct.c_int32,
                                  c_double_p]),
 }

@@ -28,7 +28,10 @@ class ConvectionP2(object):
         gl = np.ascontiguousarray(np.asarray(glam, dtype=np.float64).reshape(-1))
         ar = C.as_f64(area)
         self.ncells = ar.size
+        self._cell_vdofs = cv.reshape((-1, 12))
+        self._vdim = int(vdim)
         inv, dbi = _i32(invinds), _i32(dbcinds)
+        self._invinds = inv
         dbv = C.as_f64(dbcvals, size=dbi.size)
         self.nv = inv.size
         self._h = ct.c_void_p()
@@ -54,6 +57,47 @@ class ConvectionP2(object):
         C.check(self.lib.dns_conv_apply(self._h, C.dptr(v), float(scale),
                                         C.dptr(out)))
         return out.reshape((-1, 1))
+
+    # -- linearised convection matrices (Newton/Picard sweeps) ---------------
+    def connectivity(self):
+        """CSR of ones: all pairs of inner velocity dofs sharing a cell -- the
+        pattern of the condensed `N1(u) + N2(u)` for any `u`"""
+        import scipy.sparse as sps
+        code = np.full(self._vdim, -1, dtype=np.int64)
+        code[self._invinds] = np.arange(self.nv)
+        loc = code[self._cell_vdofs]                      # (nc, 12)
+        rows = np.repeat(loc[:, :, None], 12, axis=2).reshape(-1)
+        cols = np.repeat(loc[:, None, :], 12, axis=1).reshape(-1)
+        keep = (rows >= 0) & (cols >= 0)
+        pat = sps.coo_matrix((np.ones(int(keep.sum())),
+                              (rows[keep], cols[keep])),
+                             shape=(self.nv, self.nv)).tocsr()
+        pat.sum_duplicates()
+        pat.sort_indices()
+        pat.data[:] = 1.
+        return pat
+
+    def bind_pattern(self, pattern):
+        """the CSR pattern `assemble` (and the trapezoidal stepper) fill; it
+        must contain `connectivity()`"""
+        view = C.CsrView(pattern)
+        C.check(self.lib.dns_conv_bind_pattern(self._h, view.byref()))
+        self._pattern = view
+
+    def assemble(self, u_inner, newton=False):
+        """`(N, rhsbc, rhscon)`: `N1(u)` (Picard) or `N1(u) + N2(u)` (Newton)
+        condensed, in the bound pattern; `-N[:, bc] bcvals`; `N(u)u`
+        (reference `get_v_conv_conts`, snu:109-133)"""
+        import scipy.sparse as sps
+        u = C.as_f64(u_inner, size=self.nv)
+        pv = self._pattern
+        nvals = np.empty(pv.data.size)
+        rhsbc, rhscon = np.empty(self.nv), np.empty(self.nv)
+        C.check(self.lib.dns_conv_assemble(
+            self._h, C.dptr(u), int(bool(newton)), C.dptr(nvals),
+            C.dptr(rhsbc), C.dptr(rhscon)))
+        N = sps.csr_matrix((nvals, pv.indices, pv.indptr), shape=pv.shape)
+        return N, rhsbc.reshape((-1, 1)), rhscon.reshape((-1, 1))
 
     def host_callback(self, invinds, scale=-1.0):
         """an `f_vdp(vfull)` callable (reference tiu:113) backed by this

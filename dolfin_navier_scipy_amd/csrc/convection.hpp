@@ -116,6 +116,16 @@ struct dns_conv {
     int ncells = 0, nv_inner = 0, ndbc = 0;
     dns::DevBuf<int> cellmap, gptr, gidx;
     dns::DevBuf<double> glam, area, dbcvals, cellvals;
+    std::vector<int> cmap_host;            // [12][ncells], as on the device
+    struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
+    ~dns_conv();
+    // local matrices of N1(u) (+ N2(u)) -> mat->L
+    int enqueue_mat_cells(const double *v_dev, int newton, hipStream_t s);
+    // nvals (and F = M + tdt (A + N) if fvals) in the bound pattern
+    int enqueue_mat_gather(double *nvals, const double *mvals,
+                           const double *avals, double tdt, double *fvals,
+                           hipStream_t s);
+    int enqueue_bc_gather(double *rhsbc, hipStream_t s);
     // element kernel alone (the gather is fused into the step prologue)
     int enqueue_cells(const double *v_dev, hipStream_t s) {
         const int g1 = (8 * ncells + dns::kBlock - 1) / dns::kBlock;
@@ -137,3 +147,175 @@ struct dns_conv {
         return DNS_OK;
     }
 };
+
+// ---------------------------------------------------------------------------
+// Linearised convection MATRICES on the device (what
+// `get_v_conv_conts` -> `dts.get_convmats` + `condense_velmatsbybcs` assemble
+// with FEniCS for every time step of the Newton/Picard sweeps, snu:109-133,
+// snu:1443-1448, snu:1529-1534, dts:325-376, dts:610-642):
+//   N1(u)[(a,i),(b,k)] = delta_ik int (u . grad phi_b) phi_a        (Picard)
+//   N2(u)[(a,i),(b,k)] = int phi_b d_k u_i phi_a                    (+ Newton)
+// k_conv_mat_cells : local 12x12 matrices, 8 lanes per cell, lane a < 6 owns
+//                    the rows of test function a; slot-major layout
+//                    L[(a,i)*12 + (b,k)][cell] (coalesced stores)
+// k_conv_mat_gather: one thread per non-zero of the bound CSR pattern sums its
+//                    contributions through an inverted index (fixed order, no
+//                    atomics) and, fused, forms  F = M + tdt (A + N)
+// k_conv_bc_gather : rhsbc = -N[:, Dirichlet columns] * Dirichlet values
+// ---------------------------------------------------------------------------
+namespace dns {
+
+__global__ void __launch_bounds__(kBlock)
+k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
+                 const double *__restrict__ glam,
+                 const double *__restrict__ area,
+                 const double *__restrict__ v_inner,
+                 const double *__restrict__ dbcvals, int newton,
+                 double *__restrict__ L) {                  // [144][ncells]
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int c = t >> 3;
+    const int a = t & 7;
+    if (c >= ncells || a >= 6) return;
+    double ul[6][2];
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = cellmap[(size_t)(2 * b + i) * ncells + c];
+            ul[b][i] = (m >= 0) ? v_inner[m] : dbcvals[-m - 1];
+        }
+    double gl[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gl[k][0] = glam[(size_t)(2 * k) * ncells + c];
+        gl[k][1] = glam[(size_t)(2 * k + 1) * ncells + c];
+    }
+    const double ar = area[c];
+    double n1[6];
+    double n2[6][2][2];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        n1[b] = 0.0;
+        n2[b][0][0] = n2[b][0][1] = n2[b][1][0] = n2[b][1][1] = 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        double uq[2] = {0.0, 0.0};
+        double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // g[i][k] = d_k u_i
+        double gp[6][2];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const double d0 = c_conv.dphi[q][b][0], d1 = c_conv.dphi[q][b][1],
+                         d2 = c_conv.dphi[q][b][2];
+            gp[b][0] = d0 * gl[0][0] + d1 * gl[1][0] + d2 * gl[2][0];
+            gp[b][1] = d0 * gl[0][1] + d1 * gl[1][1] + d2 * gl[2][1];
+            const double ph = c_conv.phi[q][b];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uq[i] = fma(ph, ul[b][i], uq[i]);
+                g[i][0] = fma(gp[b][0], ul[b][i], g[i][0]);
+                g[i][1] = fma(gp[b][1], ul[b][i], g[i][1]);
+            }
+        }
+        const double wa = c_conv.qw[q] * ar * c_conv.phi[q][a];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            n1[b] = fma(wa, uq[0] * gp[b][0] + uq[1] * gp[b][1], n1[b]);
+            if (newton) {
+                const double wb = wa * c_conv.phi[q][b];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    n2[b][i][0] = fma(wb, g[i][0], n2[b][i][0]);
+                    n2[b][i][1] = fma(wb, g[i][1], n2[b][i][1]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int slot = (2 * a + i) * 12 + (2 * b + k);
+                const double v =
+                    ((i == k) ? n1[b] : 0.0) + (newton ? n2[b][i][k] : 0.0);
+                L[(size_t)slot * ncells + c] = v;
+            }
+}
+
+// nvals[z] = sum of the local contributions of non-zero z;  if fvals:
+// fvals[z] = mvals[z] + tdt * (avals[z] + nvals[z])
+__global__ void __launch_bounds__(kBlock)
+k_conv_mat_gather(int nnz, const int *__restrict__ mptr,
+                  const int *__restrict__ midx, const double *__restrict__ L,
+                  double *__restrict__ nvals, const double *__restrict__ mvals,
+                  const double *__restrict__ avals, double tdt,
+                  double *__restrict__ fvals) {
+    for (int z = blockIdx.x * kBlock + threadIdx.x; z < nnz;
+         z += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int k = mptr[z]; k < mptr[z + 1]; ++k) s += L[midx[k]];
+        nvals[z] = s;
+        if (fvals) fvals[z] = mvals[z] + tdt * (avals[z] + s);
+    }
+}
+
+// rhsbc[r] = - sum over (local entry, Dirichlet value) pairs of row r
+__global__ void __launch_bounds__(kBlock)
+k_conv_bc_gather(int nrows, const int *__restrict__ bptr,
+                 const int *__restrict__ bidx, const int *__restrict__ bbc,
+                 const double *__restrict__ L,
+                 const double *__restrict__ dbcvals,
+                 double *__restrict__ rhsbc) {
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < nrows;
+         r += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int k = bptr[r]; k < bptr[r + 1]; ++k)
+            s = fma(L[bidx[k]], dbcvals[bbc[k]], s);
+        rhsbc[r] = -s;
+    }
+}
+
+}  // namespace dns
+
+// the matrix side of dns_conv: tables bound to ONE CSR pattern
+struct dns_conv_mat {
+    int nnz = 0;
+    dns::DevBuf<int> mptr, midx, bptr, bidx, bbc;
+    dns::DevBuf<double> L;            // [144][ncells] local matrices
+};
+
+inline dns_conv::~dns_conv() { delete mat; }
+
+inline int dns_conv::enqueue_mat_cells(const double *v_dev, int newton,
+                                       hipStream_t s) {
+    const int g = (8 * ncells + dns::kBlock - 1) / dns::kBlock;
+    hipLaunchKernelGGL(dns::k_conv_mat_cells, g, dns::kBlock, 0, s, ncells,
+                       cellmap.p, glam.p, area.p, v_dev, dbcvals.p, newton,
+                       mat->L.p);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+inline int dns_conv::enqueue_mat_gather(double *nvals, const double *mvals,
+                                        const double *avals, double tdt,
+                                        double *fvals, hipStream_t s) {
+    const int g = std::max(1, std::min((mat->nnz + dns::kBlock - 1) /
+                                           dns::kBlock, 4096));
+    hipLaunchKernelGGL(dns::k_conv_mat_gather, g, dns::kBlock, 0, s, mat->nnz,
+                       mat->mptr.p, mat->midx.p, mat->L.p, nvals, mvals, avals,
+                       tdt, fvals);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+inline int dns_conv::enqueue_bc_gather(double *rhsbc, hipStream_t s) {
+    const int g = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
+                                           dns::kBlock, 2048));
+    hipLaunchKernelGGL(dns::k_conv_bc_gather, g, dns::kBlock, 0, s, nv_inner,
+                       mat->bptr.p, mat->bidx.p, mat->bbc.p, mat->L.p,
+                       dbcvals.p, rhsbc);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}

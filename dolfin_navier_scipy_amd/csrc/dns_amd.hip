@@ -181,6 +181,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
 int dns_saddle::update_values(const double *fvals) {
     DNS_HIP(hipSetDevice(device));
     Fh.vals.assign(fvals, fvals + F.nnz);
+    fh_stale = false;
     DNS_TRY(F.vals.upload(fvals, (size_t)F.nnz, stream));
     hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
                        stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p, K.vals.p);
@@ -188,6 +189,18 @@ int dns_saddle::update_values(const double *fvals) {
                        F.rowptr.p, F.colidx.p, F.vals.p, dinv.p);
     DNS_HIP(hipGetLastError());
     DNS_HIP(hipStreamSynchronize(stream));   // fvals is borrowed
+    return DNS_OK;
+}
+
+// F.vals was re-valued by a device kernel (trapezoidal stepper): bring K and
+// D^-1 along; the host copy is fetched lazily before the next set-up
+int dns_saddle::device_values_changed() {
+    hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
+                       stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p, K.vals.p);
+    hipLaunchKernelGGL(k_diag_inv, grid_for_elems(nv), kBlock, 0, stream, nv,
+                       F.rowptr.p, F.colidx.p, F.vals.p, dinv.p);
+    DNS_HIP(hipGetLastError());
+    fh_stale = true;
     return DNS_OK;
 }
 
@@ -474,6 +487,11 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
     drop_graphs();   // captured kernel arguments (coefficients, buffers)
+    if (fh_stale) {
+        DNS_TRY(F.vals.download(Fh.vals.data(), (size_t)F.nnz, stream));
+        DNS_HIP(hipStreamSynchronize(stream));
+        fh_stale = false;
+    }
     // the set-up is done redundantly and in full by every rank (identical
     // preconditioners without any communication); applies are partitioned
     dist_active = false;
@@ -1585,4 +1603,5 @@ int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
 }  // extern "C"
 
 #include "imex_capi.inc"
+#include "trap_capi.inc"
 #include "conv_capi.inc"

@@ -2,6 +2,7 @@
 #pragma once
 #include "convection.hpp"
 #include "solver.hpp"
+#include "trap.hpp"
 
 struct dns_imex {
     dns_saddle *sys = nullptr;

@@ -216,6 +216,8 @@ struct dns_saddle {
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open
+    bool fh_stale = false;            // F.vals changed on the device
+    int device_values_changed();
     int gs_fallbacks = 0;             // solves in a row whose fused Gram-Schmidt
                                       // fell back (>= 8: not tried any more)
     bool want_history = true;         // copy the residual history back

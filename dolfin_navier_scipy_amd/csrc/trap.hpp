@@ -1,0 +1,80 @@
+// Device-resident trapezoidal-rule stepper with the convection linearised
+// about a stored trajectory: the Newton/Picard time sweeps of the reference
+// (`solve_nse` with `treat_nonl_explicit=False`, snu:1402-1566, and
+// `_get_mats_rhs_ts`, snu:1016-1047).  Per step, all on the device:
+//   N_n = N1(v_lin) [+ N2(v_lin)]            element kernels + gather
+//   F   = M + dt/2 (A + N_n)                 fused into the gather; K, D^-1
+//   rhs = M v_c + dt/2 (f_n + f_c - (A + N_c) v_c)
+//   K [v_n; p~] = [rhs; fp]                  preconditioned GMRES, warm start
+//   N_c = N(v_n), f_c;  update norm dt ||v_n - v_lin||_M^2;  p = -p~/dt
+// The linearisation points of a sweep and the velocities it produces live in
+// two trajectory buffers (nslots x NV each) in HBM -- they replace the
+// per-time-step .npy files of the reference (snu:1012-1014, 1424-1431).
+#pragma once
+#include "convection.hpp"
+#include "solver.hpp"
+
+namespace dns {
+
+// out = fv + rhsbc (+ rhscon)
+__global__ void __launch_bounds__(kBlock)
+k_trap_fvn(int nv, const double *__restrict__ fv,
+           const double *__restrict__ rhsbc,
+           const double *__restrict__ rhscon, double *__restrict__ out) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nv;
+         i += gridDim.x * kBlock)
+        out[i] = fv[i] + rhsbc[i] + (rhscon ? rhscon[i] : 0.0);
+}
+
+// b_v = (M - hdt (A + N_c)) v_c + hdt (f_n + f_c);  b_p = fp.  The three value
+// arrays share ONE pattern (that of F), so the row is walked once.
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_trap_rhs(int nv, int np, const int *__restrict__ rowptr,
+           const int *__restrict__ colidx, const double *__restrict__ mvals,
+           const double *__restrict__ avals, const double *__restrict__ ncvals,
+           const double *__restrict__ v_c, double hdt,
+           const double *__restrict__ fvn_n, const double *__restrict__ fvn_c,
+           const double *__restrict__ fp, double *__restrict__ b) {
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    for (int row = sub; row < nv; row += nsub) {
+        double s = 0.0;
+        const int k1 = rowptr[row + 1];
+        for (int k = rowptr[row] + sublane; k < k1; k += LPR)
+            s = fma(mvals[k] - hdt * (avals[k] + ncvals[k]), v_c[colidx[k]], s);
+        s = subwave_sum<LPR>(s);
+        if (sublane == 0) b[row] = s + hdt * (fvn_n[row] + fvn_c[row]);
+    }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
+         i += gridDim.x * kBlock)
+        b[nv + i] = fp[i];
+}
+
+// d = x - y
+__global__ void __launch_bounds__(kBlock)
+k_trap_diff(int n, const double *__restrict__ x, const double *__restrict__ y,
+            double *__restrict__ d) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock)
+        d[i] = x[i] - y[i];
+}
+
+}  // namespace dns
+
+struct dns_trap {
+    dns_saddle *sys = nullptr;
+    dns_conv *conv = nullptr;
+    int nslots = 0;
+    dns::DevBuf<double> mvals, avals, nc_vals, nn_vals;
+    dns::DevBuf<double> xs[4];                 // ring of [v; p~] solutions
+    int cur = 0, prev = 1, pprev = 2, work = 3;
+    int nsol = 0;
+    dns::DevBuf<double> fv, fp, fvn_c, fvn_n, rhsbc, rhscon, b, dtmp, mtmp;
+    dns::DevBuf<double> traj[2];
+    double updnorm = 0.0;                      // sum dt ||v_n - v_lin||_M^2
+    double last_dt = 0.0;
+    // N_c, f_c at the current velocity
+    int assemble_current(int newton);
+};

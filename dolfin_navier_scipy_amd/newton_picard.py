@@ -1,0 +1,203 @@
+"""Newton/Picard trapezoidal time sweeps, device resident (`dns_trap_*`).
+
+What the reference does in `solve_nse(..., treat_nonl_explicit=False)`
+(stokes_navier_utils.py:1304-1334, 1402-1587) with FEniCS assemblies, sparse
+matrix sums and one saddle-point solve per time step:
+
+ * `get_v_conv_conts` (snu:109-133): `N1(v_lin)` (Picard) or `N1 + N2` (Newton)
+   condensed to the inner dofs, the Dirichlet-column rhs and `N(v)v`
+   -> `ConvectionP2.bind_pattern` + the element kernels of `csrc/convection.hpp`
+ * `_get_mats_rhs_ts` (snu:1016-1047): `M + dt/2 C_n`, `M v + dt/2 (f_n + f_c -
+   C_c v)` -> formed on the device in the ONE resident system (same pattern,
+   new values every step)
+ * the per-step `.npy` linearisation points (snu:1012-1014, 1424-1431)
+   -> two trajectory buffers in HBM
+
+Host code only drives the loop (`TrapezoidalStepper.sweep`, `newton_picard`).
+"""
+import ctypes as ct
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import _capi as C
+from .saddle import SaddleSystem, solve_opts
+
+__all__ = ['TrapezoidalStepper', 'newton_picard', 'union_pattern',
+           'values_in_pattern']
+
+
+def union_pattern(*mats):
+    """CSR matrix of ones on the union of the patterns (explicit zeros of the
+    inputs count), canonical format"""
+    acc = None
+    for m in mats:
+        m = sps.csr_matrix(m)
+        one = sps.csr_matrix((np.ones(m.indices.size), m.indices, m.indptr),
+                             shape=m.shape)
+        acc = one if acc is None else acc + one
+    acc = sps.csr_matrix(acc)
+    acc.sum_duplicates()
+    acc.sort_indices()
+    acc.data[:] = 1.
+    return acc
+
+
+def values_in_pattern(mat, pattern):
+    """the values of `mat` laid out in `pattern` (a superset of its pattern);
+    entries of the pattern `mat` lacks are explicit zeros"""
+    mat = sps.csr_matrix(mat)
+    mat.sum_duplicates()
+    ncols = pattern.shape[1]
+    prow = np.repeat(np.arange(pattern.shape[0]), np.diff(pattern.indptr))
+    pkeys = prow.astype(np.int64)*ncols + pattern.indices
+    mrow = np.repeat(np.arange(mat.shape[0]), np.diff(mat.indptr))
+    mkeys = mrow.astype(np.int64)*ncols + mat.indices
+    pos = np.searchsorted(pkeys, mkeys)
+    if pos.size and (pos.max() >= pkeys.size or
+                     not np.array_equal(pkeys[pos], mkeys)):
+        raise ValueError('matrix has entries outside the pattern')
+    out = np.zeros(pkeys.size)
+    out[pos] = mat.data
+    return out
+
+
+class TrapezoidalStepper(object):
+    """`M, A, J` condensed (inner dofs), `conv` a `ConvectionP2` of the same
+    space; `dt` is the step size the preconditioner is set up for (other
+    step sizes still converge, with more iterations)"""
+
+    def __init__(self, M, A, J, conv, nslots, dt, device=0, precond=None,
+                 JT=None):
+        self.lib = C.load_library()
+        self.conv = conv
+        self.M, self.A, self.J = (sps.csr_matrix(M), sps.csr_matrix(A),
+                                  sps.csr_matrix(J))
+        self.NP, self.NV = self.J.shape
+        self.pattern = union_pattern(self.M, self.A, conv.connectivity())
+        self.mvals = values_in_pattern(self.M, self.pattern)
+        self.avals = values_in_pattern(self.A, self.pattern)
+        F0 = sps.csr_matrix((self.mvals + .5*dt*self.avals,
+                             self.pattern.indices, self.pattern.indptr),
+                            shape=self.pattern.shape)
+        self.system = SaddleSystem(F0, self.J, JT=JT, device=device)
+        pkw = dict(cheb_degree=6, schur='auto', fhat='auto', fp32_store=True,
+                   drop_tol=3e-3)
+        pkw.update(precond or {})
+        if pkw['schur'] == 'auto':
+            pkw['schur'] = 'dense' if self.NP <= 6000 else 'jacobi'
+        self.system.setup_precond(**pkw)
+        conv.bind_pattern(self.pattern)
+        self.nslots = int(nslots)
+        self._h = ct.c_void_p()
+        C.check(self.lib.dns_trap_create(
+            self.system._h, conv._h, C.dptr(self.mvals), C.dptr(self.avals),
+            self.nslots, ct.byref(self._h)))
+        self.last_stats = None
+
+    def close(self):
+        if getattr(self, '_h', None) is not None and self._h:
+            self.lib.dns_trap_destroy(self._h)
+            self._h = ct.c_void_p()
+            self.system.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_rhs(self, fv=None, fp=None):
+        fv = None if fv is None else C.as_f64(fv, self.NV)
+        fp = None if fp is None else C.as_f64(fp, self.NP)
+        C.check(self.lib.dns_trap_set_rhs(self._h, C.dptr(fv), C.dptr(fp)))
+
+    def write_linpoint(self, which, slot, v):
+        v = C.as_f64(v, self.NV)
+        C.check(self.lib.dns_trap_traj_write(self._h, which, slot, C.dptr(v)))
+
+    def read_traj(self, which, slot):
+        out = np.empty(self.NV)
+        C.check(self.lib.dns_trap_traj_read(self._h, which, slot, C.dptr(out)))
+        return out.reshape((-1, 1))
+
+    def start(self, iniv, newton):
+        v = C.as_f64(iniv, self.NV)
+        C.check(self.lib.dns_trap_start(self._h, C.dptr(v), int(bool(newton))))
+
+    def step(self, dt, lin_which, lin_slot, out_slot, newton, opts=None,
+             extrapolate=2, raise_on_fail=True):
+        o = solve_opts() if opts is None else opts
+        st = C.dns_solve_stats()
+        C.check(self.lib.dns_trap_step(
+            self._h, float(dt), int(lin_which), int(lin_slot), int(out_slot),
+            int(bool(newton)), int(extrapolate), ct.byref(o), ct.byref(st)))
+        self.last_stats = st.asdict()
+        if raise_on_fail and st.status != C.DNS_OK:
+            raise C.NotConverged(st.status, 'time step solve failed: '
+                                 '{0}'.format(self.last_stats))
+        return self.last_stats
+
+    def state(self):
+        v, p = np.empty(self.NV), np.empty(self.NP)
+        C.check(self.lib.dns_trap_get_state(self._h, C.dptr(v), C.dptr(p)))
+        return v.reshape((-1, 1)), p.reshape((-1, 1))
+
+    def update_norm(self):
+        out = ct.c_double(0.)
+        C.check(self.lib.dns_trap_update_norm(self._h, ct.byref(out)))
+        return out.value
+
+    def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=2,
+              record=True):
+        """one sweep over `trange` linearised about trajectory `lin_which`
+        (slot k <-> trange[k]); the new velocities go to the other trajectory.
+        Returns `(vdict, pdict, norm_nwtnupd, stats)` (dicts empty unless
+        `record`)"""
+        trange = np.asarray(trange, dtype=np.float64)
+        if trange.size > self.nslots:
+            raise ValueError('trajectory buffers hold {0} slots'.format(
+                self.nslots))
+        newton = not picard
+        self.start(iniv, newton)
+        self.write_linpoint(1 - lin_which, 0, iniv)
+        vdict, pdict = {}, {}
+        if record:
+            vdict[trange[0]] = np.asarray(iniv, dtype=float).reshape((-1, 1))
+        iters, secs = 0, 0.
+        for k in range(1, trange.size):
+            st = self.step(trange[k] - trange[k-1], lin_which, k, k, newton,
+                           opts=opts, extrapolate=extrapolate)
+            iters += st['iters']
+            secs += st['device_seconds']
+            if record:
+                vdict[trange[k]], pdict[trange[k]] = self.state()
+        return vdict, pdict, self.update_norm(), dict(iters=iters,
+                                                      device_seconds=secs)
+
+
+def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
+                  vel_nwtn_stps=2, vel_nwtn_tol=1e-14, opts=None,
+                  extrapolate=2):
+    """Picard sweeps first, then Newton sweeps, each linearised about the
+    previous sweep's trajectory (snu:1304-1334, 1562-1587).  `linpoints0`:
+    `{t: v_inner}` for the first sweep.  Returns `(vdict, pdict, hist)`."""
+    trange = np.asarray(trange, dtype=np.float64)
+    which = 0
+    for k, t in enumerate(trange):
+        stepper.write_linpoint(which, k, linpoints0[t])
+    newtk, norm_nwtnupd = 0, 1.
+    hist = []
+    vdict = pdict = None
+    while newtk < vel_nwtn_stps and norm_nwtnupd > vel_nwtn_tol:
+        if vel_pcrd_stps > 0:
+            vel_pcrd_stps -= 1
+            picard = True
+        else:
+            picard = False
+            newtk += 1
+        vdict, pdict, norm_nwtnupd, _ = stepper.sweep(
+            trange, iniv, which, picard, opts=opts, extrapolate=extrapolate)
+        hist.append(('picard' if picard else 'newton', norm_nwtnupd))
+        which = 1 - which           # the new trajectory = next lin. points
+    return vdict, pdict, hist

@@ -290,6 +290,50 @@ int dns_dense_inverse(int device, int32_t n, double *a_rowmajor);
 int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
                    int32_t warmup, double *avg_seconds, double *checksum);
 
+/* ---- linearised convection matrices + Newton/Picard trapezoidal sweeps ------
+ * (reference: `get_v_conv_conts` snu:109-133 with `get_convmats` dts:325-376
+ * and `condense_velmatsbybcs` dts:610-642; `_get_mats_rhs_ts` snu:1016-1047;
+ * the time loop snu:1402-1566)
+ *
+ * dns_conv_bind_pattern: the CSR pattern (values ignored) the condensed
+ *   N1(u) (+ N2(u)) are assembled into -- it must contain theirs, e.g. the
+ *   pattern of A (symmetric-gradient form) or of M + A kept with its zeros.
+ * dns_conv_assemble (host pointers; the parity-test entry): values of
+ *   N1(u) [newton = 0] or N1(u) + N2(u) [newton = 1] in that pattern,
+ *   rhsbc = -N[:, Dirichlet cols] * Dirichlet values (may be NULL) and
+ *   rhscon = N(u)u (may be NULL).
+ */
+int dns_conv_bind_pattern(dns_conv *cv, const dns_csr *pattern);
+int dns_conv_assemble(dns_conv *cv, const double *u_inner, int32_t newton,
+                      double *nvals, double *rhsbc, double *rhscon);
+
+/* Trapezoidal stepper: M, A given as value arrays in the pattern of `sys`'s F
+ * block (to which `conv` must be bound); two trajectory buffers of `nslots`
+ * velocities each hold the linearisation points of the running sweep
+ * (`which`) and the velocities it produces (`1 - which`).
+ *   start : v_c = iniv, N_c and f_c assembled there, update norm reset
+ *   step  : one step of size dt linearised about traj[lin_which][lin_slot];
+ *           F = M + dt/2 (A + N_n) is formed on the device inside `sys`
+ *           (same pattern, preconditioner kept); result -> traj[1-lin_which]
+ *           [out_slot] (out_slot < 0: not stored)
+ *   get_state: v_c and p = -p~/dt (snu:1542)
+ *   update_norm: sum of dt ||v_n - v_lin||_M^2 since `start` (snu:1557-1560)
+ */
+typedef struct dns_trap dns_trap;
+int dns_trap_create(dns_saddle *sys, dns_conv *conv, const double *m_vals,
+                    const double *a_vals, int32_t nslots, dns_trap **out);
+void dns_trap_destroy(dns_trap *t);
+int dns_trap_set_rhs(dns_trap *t, const double *fv, const double *fp);
+int dns_trap_traj_write(dns_trap *t, int32_t which, int32_t slot,
+                        const double *v);
+int dns_trap_traj_read(dns_trap *t, int32_t which, int32_t slot, double *v);
+int dns_trap_start(dns_trap *t, const double *iniv, int32_t newton);
+int dns_trap_step(dns_trap *t, double dt, int32_t lin_which, int32_t lin_slot,
+                  int32_t out_slot, int32_t newton, int32_t extrapolate_x0,
+                  const dns_solve_opts *opts, dns_solve_stats *stats);
+int dns_trap_get_state(dns_trap *t, double *v, double *p);
+int dns_trap_update_norm(dns_trap *t, double *out);
+
 /* attainable HBM bandwidth of the device, measured with plain streaming
  * kernels over `bytes` of fp64 data (kind 0: read + reduce, 1: copy,
  * 2: triad a = b + s c); reports GB/s of the bytes the kernel moves.  The SpMV

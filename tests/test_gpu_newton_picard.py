@@ -1,0 +1,163 @@
+"""Device-resident Newton/Picard trapezoidal sweeps (`dns_trap_*`,
+`dns_conv_assemble`) against the host assembler and the oracle restatement of
+snu:1016-1047 / snu:1402-1566."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+
+import scenarios
+from oracle import imex_oracle
+from oracle import newton_picard_oracle as npo
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(prob, Nts=6, tE=0.03):
+    th, smc, rhsd = prob['th'], prob['smc'], prob['rhsd']
+    inv, dbcinds, dbcvals = prob['invinds'], prob['dbcinds'], prob['dbcvals']
+    M, A, J = smc['M'], smc['A'], smc['J']
+    NP, NV = J.shape
+
+    def appnd(vvec):
+        full = np.zeros((th.vdim, 1))
+        full[inv] = vvec
+        full[dbcinds, 0] = dbcvals
+        return full
+
+    bcsv = np.zeros((th.vdim, 1))
+    bcsv[dbcinds, 0] = dbcvals
+
+    def conv(vfull, picard):
+        # algebraic `get_v_conv_conts` (snu:109-133), as in test_newton_picard
+        if vfull.shape[0] == NV:
+            vfull = appnd(vfull)
+        N1, N2, fv3 = th.convection_mats(vfull, keep_pattern=True)
+        Nm = N1 if picard else (N1 + N2)
+        Nc = Nm[inv, :][:, inv].tocsr()
+        rhsbc = -(Nm @ bcsv)[inv, :]
+        return Nc, (0.*fv3[inv, :] if picard else fv3[inv, :]), rhsbc
+
+    kw, rec, aux = scenarios.build(variant='plain', seed=0, Nts=Nts, tE=tE,
+                                   prob=prob)
+    imex_oracle.cnab(**kw)          # semi-explicit run = first lin. points
+    times, vels, _ = rec.arrays()
+    lin0 = {t: vels[k].reshape((-1, 1))[inv] for k, t in enumerate(times)}
+    return dict(M=M, A=A, J=J, fv=rhsd['fv'], fp=rhsd['fp'], conv=conv,
+                appnd=appnd, trange=kw['trange'], iniv=kw['inivel'], lin0=lin0,
+                inv=inv, NV=NV, NP=NP, th=th, dbcinds=dbcinds, dbcvals=dbcvals)
+
+
+@pytest.fixture(scope='module')
+def setup(toy_prob):
+    from dolfin_navier_scipy_amd import _capi
+    assert _capi.device_count() > 0
+    return _setup(toy_prob)
+
+
+@pytest.fixture()
+def cvop(setup):
+    from dolfin_navier_scipy_amd import convection
+    s = setup
+    cv = convection.ConvectionP2.from_taylor_hood(s['th'], s['inv'],
+                                                  s['dbcinds'], s['dbcvals'])
+    yield cv
+    cv.close()
+
+
+@pytest.mark.parametrize('newton', [False, True])
+def test_device_convection_matrices_match_host_assembly(setup, cvop, newton):
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    s = setup
+    pattern = dnp.union_pattern(s['M'], s['A'], cvop.connectivity())
+    cvop.bind_pattern(pattern)
+    rng = np.random.default_rng(4)
+    for _ in range(2):
+        u = rng.standard_normal((s['NV'], 1))
+        N, rhsbc, rhscon = cvop.assemble(u, newton=newton)
+        Nref, rcref, rbref = s['conv'](u, not newton)
+        scale = abs(Nref).max()
+        assert abs(N - Nref).max() <= 1e-13*scale
+        assert np.abs(rhsbc - rbref).max() <= 1e-13*max(np.abs(rbref).max(), 1)
+        # rhscon is N(u)u whatever the linearisation
+        _, fv3, _ = s['conv'](u, False)
+        assert np.abs(rhscon - fv3).max() <= 1e-13*np.abs(fv3).max()
+
+
+def test_conv_equals_N1u_equals_N2u(setup, cvop):
+    """the reference's own known-answer test for its convection matrices,
+    tests/test_units_fenicsci.py:84-85: `N(u)u == N1(u) u == N2(u) u` -- on the
+    full space, i.e. with homogeneous Dirichlet data after condensation"""
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    s = setup
+    cvop.set_dbcvals(0*s['dbcvals'])
+    cvop.bind_pattern(dnp.union_pattern(cvop.connectivity()))
+    u = np.random.default_rng(9).standard_normal((s['NV'], 1))
+    N1, _, nuu = cvop.assemble(u, newton=False)
+    N12, _, _ = cvop.assemble(u, newton=True)
+    N2 = N12 - N1
+    ref = np.abs(nuu).max()
+    assert np.abs(N1 @ u - nuu).max() <= 1e-12*ref
+    assert np.abs(N2 @ u - nuu).max() <= 1e-12*ref
+    cvop.set_dbcvals(s['dbcvals'])
+
+
+def test_bind_pattern_rejects_a_pattern_that_is_too_small(setup, cvop):
+    from dolfin_navier_scipy_amd import _capi
+    s = setup
+    with pytest.raises(_capi.DnsError):
+        cvop.bind_pattern(sps.identity(s['NV'], format='csr'))
+    with pytest.raises(_capi.DnsError):
+        cvop.bind_pattern(sps.identity(s['NV'] + 1, format='csr'))
+
+
+@pytest.mark.parametrize('picard', [True, False])
+def test_device_sweep_matches_oracle(setup, cvop, picard):
+    from dolfin_navier_scipy_amd import newton_picard as dnp, saddle
+    s = setup
+    tr = s['trange']
+    lin_full = {t: s['appnd'](v) for t, v in s['lin0'].items()}
+    ref_v, ref_p, ref_upd = npo.trapezoidal_sweep(
+        tr, s['iniv'], M=s['M'], A=s['A'], J=s['J'], fv=s['fv'], fp=s['fp'],
+        conv=s['conv'], appndbcs=s['appnd'], linpoints=s['lin0'],
+        picard=picard)
+    stp = dnp.TrapezoidalStepper(s['M'], s['A'], s['J'], cvop, nslots=tr.size,
+                                 dt=tr[1] - tr[0], precond=dict(cheb_degree=4))
+    stp.set_rhs(s['fv'], s['fp'])
+    for k, t in enumerate(tr):
+        stp.write_linpoint(0, k, s['lin0'][t])
+    opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True)
+    got_v, got_p, upd, st = stp.sweep(tr, s['iniv'], 0, picard, opts=opts)
+    for t in tr[1:]:
+        ev = np.linalg.norm(got_v[t] - ref_v[t])/np.linalg.norm(ref_v[t])
+        ep = np.linalg.norm(got_p[t] - ref_p[t])/np.linalg.norm(ref_p[t])
+        assert ev <= 1e-8 and ep <= 1e-6, (t, ev, ep)
+    assert abs(upd - ref_upd) <= 1e-6*abs(ref_upd) + 1e-18
+    # the sweep's velocities sit in the other trajectory buffer
+    assert np.allclose(stp.read_traj(1, tr.size - 1), got_v[tr[-1]])
+    stp.close()
+
+
+def test_device_newton_picard_driver_matches_oracle(setup, cvop):
+    from dolfin_navier_scipy_amd import newton_picard as dnp, saddle
+    s = setup
+    tr = s['trange']
+    lin_full = {t: s['appnd'](v) for t, v in s['lin0'].items()}
+    ref_v, ref_p, ref_hist = npo.newton_picard(
+        tr, s['iniv'], lin_full, vel_pcrd_stps=1, vel_nwtn_stps=2,
+        invinds=s['inv'], M=s['M'], A=s['A'], J=s['J'], fv=s['fv'],
+        fp=s['fp'], conv=s['conv'], appndbcs=s['appnd'])
+    stp = dnp.TrapezoidalStepper(s['M'], s['A'], s['J'], cvop, nslots=tr.size,
+                                 dt=tr[1] - tr[0], precond=dict(cheb_degree=4))
+    stp.set_rhs(s['fv'], s['fp'])
+    opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True)
+    got_v, got_p, hist = dnp.newton_picard(
+        stp, tr, s['iniv'], s['lin0'], vel_pcrd_stps=1, vel_nwtn_stps=2,
+        opts=opts)
+    assert [h[0] for h in hist] == [h[0] for h in ref_hist]
+    for (_, a), (_, b) in zip(hist, ref_hist):
+        assert abs(a - b) <= 1e-5*abs(b) + 1e-16
+    for t in tr[1:]:
+        ev = np.linalg.norm(got_v[t] - ref_v[t])/np.linalg.norm(ref_v[t])
+        ep = np.linalg.norm(got_p[t] - ref_p[t])/np.linalg.norm(ref_p[t])
+        assert ev <= 1e-8 and ep <= 1e-6, (t, ev, ep)
+    stp.close()
