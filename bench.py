@@ -121,6 +121,56 @@ def cpu_baseline(sm, rhsd, v0, nfc0, dt, conv_host, nsteps):
                 'timed'.format(nsteps, tfac)), v, p
 
 
+def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64):
+    """secondary workload (BASELINE config 3): one Picard
+    and one Newton trapezoidal sweep over `nsteps` steps, everything on the
+    device (convection matrices, F = M + dt/2 (A + N), solve); beside it what
+    the reference pays per step on the CPU: a fresh SuperLU factorisation +
+    solve of the re-valued saddle matrix (FEniCS assembly not counted)"""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spsla
+    from dolfin_navier_scipy_amd import saddle, convection
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    th, inv = femp['V'], femp['invinds']
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
+    trange = dt*np.arange(nsteps + 1)
+    ts = dnp.TrapezoidalStepper(M, A, J, cvop, nslots=nsteps + 1, dt=dt,
+                                device=device, precond=dict(cheb_degree=6))
+    ts.set_rhs(rhsd['fv'], rhsd['fp'])
+    for k in range(nsteps + 1):       # first linearisation: the initial state
+        ts.write_linpoint(0, k, v0)
+    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=0)
+    out = {}
+    which = 0
+    for name, picard in (('picard', True), ('newton', False)):
+        t0 = time.perf_counter()
+        _, _, upd, st = ts.sweep(trange, v0, which, picard, opts=opts,
+                                 record=False)
+        wl = time.perf_counter() - t0
+        out[name] = dict(steps_per_s=nsteps/wl,
+                         krylov_iters_per_step=st['iters']/float(nsteps),
+                         update_norm=upd)
+        which = 1 - which
+    Nc, _, _ = cvop.assemble(v0, newton=False)
+    Fm = sps.csr_matrix((ts.mvals + .5*dt*(ts.avals + Nc.data),
+                         ts.pattern.indices, ts.pattern.indptr), shape=(NV, NV))
+    K = sps.bmat([[Fm, J.T], [J, None]], format='csc')
+    rhs = np.ones(NV + NP)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        spsla.splu(K).solve(rhs)
+    out['cpu_splu_factor_solve_ms_per_step'] = \
+        1e3*(time.perf_counter() - t0)/reps
+    out['steps'] = nsteps
+    ts.close()
+    cvop.close()
+    return out
+
+
 def pmc_traffic(Kmat):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes
     (profiles/spmv_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
@@ -178,6 +228,8 @@ def main():
                     help='red refinements of the mesh for the HBM roofline '
                     'SpMV (0 disables)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-picard', action='store_true',
+                    help='skip the secondary Newton/Picard sweep figures')
     ap.add_argument('--replicas', action='store_true',
                     help='N>1: independent replicas instead of the '
                     'row-partitioned solve')
@@ -340,6 +392,9 @@ def main():
                             main_roof['achieved']/attain['read']
                             if attain else None),
                         at_benchmark_size=roof)
+        picard = None
+        if world == 1 and not args.eager and not args.no_picard:
+            picard = picard_sweep_figures(femp, sm, rhsd, v0, dt, device)
         cpu = None
         parity = None
         if not args.no_cpu:
@@ -378,6 +433,7 @@ def main():
                         krylov_iters_per_step_frozen=(
                             iters_fr/float(args.steps)),
                         true_relres_last=last['true_relres'],
+                        newton_picard_sweeps=picard,
                         device_ms_per_step=1e3*dev_s/args.steps,
                         precond_setup_s=t_setup,
                         initial_stokes=st0,
