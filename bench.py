@@ -13,9 +13,14 @@ excluded") is timed as well and reported in `config`.
 
 Workload at N=1: Schaefer-Turek cylinder wake, mesh level N=2 (NV=9356,
 NP=1289), Re=100, dt=1/512, Taylor-Hood, CNAB -- the configuration
-BASELINE.json quotes the metric on.  For N>1 every rank runs an independent
-replica of that workload (weak scaling, no data-path collective): the
-row-partitioned solve over RCCL is not built yet (DESIGN.md, row e).
+BASELINE.json quotes the metric on.  For N>1 the headline is an ENSEMBLE:
+every rank advances its own simulation of that workload on its own GPU (weak
+scaling, no data-path collective) -- at n ~ 1e4 a time step is ~100 us of
+launch-bound work and a single RCCL collective costs 10-20 us, so partitioning
+ONE simulation of this size cannot pay.  The row-partitioned solve over RCCL
+(all-gather-v halo + all-reduce of the Krylov dots) is
+then timed on the same ranks as a secondary figure, `config.row_partitioned`
+(strong scaling of one simulation), so that both numbers are on record.
 
 The JSON line also carries
   roofline     : CSR SpMV `y = K x` (the kernel family that dominates the
@@ -231,8 +236,7 @@ def main():
     ap.add_argument('--no-picard', action='store_true',
                     help='skip the secondary Newton/Picard sweep figures')
     ap.add_argument('--replicas', action='store_true',
-                    help='N>1: independent replicas instead of the '
-                    'row-partitioned solve')
+                    help='N>1: skip the secondary row-partitioned leg')
     ap.add_argument('--force-dist', action='store_true',
                     help='attach an RCCL communicator even with one rank '
                     '(self-test of the multi-GPU code path)')
@@ -275,29 +279,10 @@ def main():
     R1 = (M - .5*dt*A).tocsr()
     t_setup = time.perf_counter()
     system = factory(F, J)
-    # N > 1: ONE simulation, its operator applies row-partitioned over the
-    # ranks (RCCL all-gather-v of the row blocks + all-reduce of the Krylov
-    # dots).  Strong scaling by construction -- and at n ~ 1e4 it is bound by
-    # collective latency, not by compute (SURVEY.md 8e says so up front).
     mode, scaling, comm_obj = ('single', 'weak', None)
     if world > 1:
-        mode = 'replicas'
-    if (world > 1 and not args.replicas) or args.force_dist:
-        try:
-            from dolfin_navier_scipy_amd import comm as dcomm
-            with stdout_to_stderr():
-                if dist is not None:
-                    comm_obj = dcomm.Comm.rccl_from_torch(device)
-                else:
-                    comm_obj = dcomm.Comm.rccl(device, 1, 0,
-                                               dcomm.rccl_unique_id())
-            system.set_comm(comm_obj)
-            mode, scaling = 'row-partitioned over RCCL', 'strong'
-        except Exception as exc:       # keep the scaling run alive
-            sys.stderr.write('row-partitioned mode unavailable ({0}); '
-                             'running replicas\n'.format(exc))
-            comm_obj = None
-            mode = 'replicas (partitioned mode failed: {0})'.format(exc)
+        mode = ('ensemble: {0} independent simulations, one per GPU, no '
+                'data-path collective'.format(world))
     system.setup_precond(cheb_degree=args.cheb, schur='dense', fhat=args.fhat,
                          fp32_store=bool(args.fp32), drop_tol=args.drop)
     _capi.device_synchronize(device)
@@ -324,7 +309,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_run(with_convection):
+    def timed_run(with_convection, nsteps=None, nwarm=None):
+        nsteps = args.steps if nsteps is None else nsteps
+        nwarm = args.warmup if nwarm is None else nwarm
         stp = saddle.ImexStepper(system, R1)
         stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
         stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
@@ -333,10 +320,10 @@ def main():
             cvop = convection.ConvectionP2.from_taylor_hood(
                 th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
             stp.set_convection(cvop, scale=-1.0)
-        stp.run(args.warmup, cf, opts)
+        stp.run(nwarm, cf, opts)
         barrier()
         t0 = time.perf_counter()
-        dev_s, its, lst = stp.run(args.steps, cf, opts)
+        dev_s, its, lst = stp.run(nsteps, cf, opts)
         barrier()
         wl = time.perf_counter() - t0
         if dist is not None:
@@ -355,10 +342,41 @@ def main():
     # secondary: convection history frozen (the linear algebra alone)
     wall_fr, _, iters_fr, _, _, _ = timed_run(False)
 
+    # secondary (N > 1, or --force-dist): ONE simulation whose operator applies
+    # are row-partitioned over the ranks -- RCCL all-gather-v of the row blocks
+    # + all-reduce of the Krylov dots (strong scaling by construction)
+    partitioned = None
+    if (world > 1 and not args.replicas) or args.force_dist:
+        try:
+            from dolfin_navier_scipy_amd import comm as dcomm
+            with stdout_to_stderr():
+                if dist is not None:
+                    comm_obj = dcomm.Comm.rccl_from_torch(device)
+                else:
+                    comm_obj = dcomm.Comm.rccl(device, 1, 0,
+                                               dcomm.rccl_unique_id())
+            system.set_comm(comm_obj)
+            system.setup_precond(cheb_degree=args.cheb, schur='dense',
+                                 fhat=args.fhat, fp32_store=bool(args.fp32),
+                                 drop_tol=args.drop)
+            psteps = min(args.steps, 200)
+            pwall, _, piters, plast, _, _ = timed_run(
+                True, nsteps=psteps, nwarm=min(args.warmup, 20))
+            partitioned = dict(
+                steps_per_s=psteps/pwall, steps=psteps, scaling='strong',
+                krylov_iters_per_step=piters/float(psteps),
+                true_relres_last=plast['true_relres'],
+                collectives=comm_obj.stats(),
+                what='one simulation, rows of every operator apply '
+                     'partitioned over {0} rank(s); RCCL all-gather-v + '
+                     'all-reduce per Arnoldi step'.format(world))
+        except Exception as exc:       # keep the headline alive
+            sys.stderr.write('row-partitioned leg failed: {0}\n'.format(exc))
+            partitioned = dict(error=str(exc))
+
     out = None
     if rank == 0:
-        # replicas: N simulations advance together; partitioned: one does
-        value = (1 if comm_obj is not None else world)*args.steps/wall
+        value = world*args.steps/wall
         roof = roofline_spmv(saddle, saddle_csr(F, J), 200,
                              'K at the benchmark size (cache resident)',
                              variants=('vector',))
@@ -397,7 +415,7 @@ def main():
             picard = picard_sweep_figures(femp, sm, rhsd, v0, dt, device)
         cpu = None
         parity = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:     # rank 0 at N=1 only
             cpu, v_cpu, p_cpu = cpu_baseline(
                 sm, rhsd, v0, nfc, dt, conv_host, args.warmup + args.steps)
             # same steps, same nonlinear trajectory on both sides
@@ -420,16 +438,14 @@ def main():
                         'Taylor-Hood NV={3} NP={4}; convection N(v)v '
                         'evaluated on the device every step'
                         .format(args.level, args.Re, args.nts, NV, NP),
-                        parallelism=mode,
-                        collectives=(comm_obj.stats() if comm_obj is not None
-                                     else None),
+                        parallelism=mode, collectives=None,
+                        row_partitioned=partitioned,
                         method=args.method, cheb_degree=args.cheb,
                         schur='dense', rtol=args.rtol,
                         launch='eager' if args.eager else 'hipGraph',
                         krylov_iters_per_step=iters/float(args.steps),
                         steps_per_s_convection_frozen=(
-                            (1 if comm_obj is not None else world)
-                            * args.steps/wall_fr),
+                            world*args.steps/wall_fr),
                         krylov_iters_per_step_frozen=(
                             iters_fr/float(args.steps)),
                         true_relres_last=last['true_relres'],
