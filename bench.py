@@ -385,11 +385,12 @@ def main():
             _, smr, _ = build_problem(N=args.level, Re=args.Re,
                                       refine=args.roofline_refine)
             Kr = saddle_csr((smr['M'] + .5*dt*smr['A']).tocsr(), smr['J'])
-            # only the LDS-streaming kernel runs on the refined matrix, so its
-            # rocprofv3 average is this measurement and nothing else
+            # only the LDS-streaming kernel (16-bit column offsets) runs on the
+            # refined matrix, so its rocprofv3 average is this measurement and
+            # nothing else
             roof_hbm = roofline_spmv(
                 saddle, Kr, 30, 'K on the mesh refined {0}x (n={1})'.format(
-                    args.roofline_refine, Kr.shape[0]), variants=('stream',))
+                    args.roofline_refine, Kr.shape[0]), variants=('stream16',))
             traffic = pmc_traffic(Kr)
         else:
             traffic = None

@@ -93,6 +93,12 @@ struct CsrDev {
     // row-block table of the LDS-streaming kernel (built on the host)
     DevBuf<int> rowblocks_t[3];   // tiles of 1024 / 2048 / 4096 non-zeros
     int nrowblocks_t[3] = {0, 0, 0};
+    // 16-bit column indices for the 2048 tile: entry = 15-bit offset from one
+    // of two bases of its row block (bit 15 selects); c16base[2b] < 0 marks a
+    // block whose columns do not fit two 32768-wide windows (read raw)
+    DevBuf<unsigned short> c16;
+    DevBuf<int> c16base;
+    int c16_rawblocks = 0;
 
     int upload(const dns_csr *a, hipStream_t s);
 };

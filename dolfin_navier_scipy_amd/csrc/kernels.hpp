@@ -225,6 +225,71 @@ k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
     }
 }
 
+// The same kernel reading 16-bit column offsets (CsrDev::c16): per row block
+// two window bases, bit 15 of an entry selects the window.  HBM traffic per
+// non-zero drops from 12 to 10 bytes; blocks whose columns do not fit the two
+// windows (bases < 0) read the plain 32-bit indices.
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
+                const int *__restrict__ rowptr, const int *__restrict__ colidx,
+                const unsigned short *__restrict__ c16,
+                const int *__restrict__ c16base,
+                const double *__restrict__ vals, const double *__restrict__ x,
+                double *__restrict__ y, double alpha, double beta,
+                const double *__restrict__ b) {
+    constexpr int TILE = kStreamNnz;
+    __shared__ double prod[TILE];
+    __shared__ double red[4];
+    __shared__ int rps[kBlock + 1];
+    const int gq = gridDim.x / 8, gr = gridDim.x % 8;
+    const int cls = blockIdx.x % 8;
+    const int vb = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
+    for (int blk = vb; blk < nblocks; blk += gridDim.x) {
+        const int r0 = rowblocks[blk], r1 = rowblocks[blk + 1];
+        const int k0 = rowptr[r0], k1 = rowptr[r1];
+        const int nn = k1 - k0;
+        const int blo = c16base[2 * blk], bhi = c16base[2 * blk + 1];
+        if (nn > TILE) {
+            double s = 0.0;
+            for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
+                s = fma(vals[k], x[colidx[k]], s);
+            s = block_sum(s, red);
+            if (threadIdx.x == 0)
+                y[r0] = b ? fma(alpha, s, beta * b[r0]) : alpha * s;
+            continue;
+        }
+        __syncthreads();             // previous tile fully consumed
+        const int nr = r1 - r0;
+        if (threadIdx.x < nr) rps[threadIdx.x] = rowptr[r0 + threadIdx.x] - k0;
+        if (threadIdx.x == 0) rps[nr] = nn;
+        if (blo >= 0) {
+#pragma unroll 2
+            for (int k = threadIdx.x; k < nn; k += kBlock) {
+                const int e = c16[k0 + k];
+                const int col = ((e & 0x8000) ? bhi : blo) + (e & 0x7fff);
+                prod[k] = vals[k0 + k] * x[col];
+            }
+        } else {
+#pragma unroll 2
+            for (int k = threadIdx.x; k < nn; k += kBlock)
+                prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
+        }
+        __syncthreads();
+        const int g = threadIdx.x % G, rsub = threadIdx.x / G;
+        for (int r = rsub; r < nr; r += kBlock / G) {
+            const int a0 = rps[r], a1 = rps[r + 1];
+            double s = 0.0;
+            for (int k = a0 + g; k < a1; k += G) s += prod[k];
+            s = subwave_sum<G>(s);
+            if (g == 0) {
+                const int row = r0 + r;
+                y[row] = b ? fma(alpha, s, beta * b[row]) : alpha * s;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // vector kernels
 // ---------------------------------------------------------------------------

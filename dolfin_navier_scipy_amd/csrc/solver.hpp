@@ -75,6 +75,45 @@ inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
         nrowblocks_t[t] = (int)rb.size() - 1;
         DNS_TRY(rowblocks_t[t].alloc(rb.size()));
         DNS_TRY(rowblocks_t[t].upload(rb.data(), rb.size(), s));
+        if (t == 1 && nnz > 0) {
+            // compressed column indices of the 2048 tile (one pass, no sort):
+            // window 1 starts at the block's smallest column, window 2 at the
+            // smallest column beyond window 1
+            const int nb = nrowblocks_t[t];
+            std::vector<unsigned short> cc((size_t)nnz + 2, 0);
+            std::vector<int> bases((size_t)2 * nb, 0);
+            c16_rawblocks = 0;
+            for (int b = 0; b < nb; ++b) {
+                const int64_t k0 = a->rowptr[rb[b]], k1 = a->rowptr[rb[b + 1]];
+                int lo = INT32_MAX, hi = INT32_MAX, mx = -1;
+                for (int64_t k = k0; k < k1; ++k) lo = std::min(lo, a->colidx[k]);
+                for (int64_t k = k0; k < k1; ++k) {
+                    const int c = a->colidx[k];
+                    mx = std::max(mx, c);
+                    if (c - lo > 32767) hi = std::min(hi, c);
+                }
+                if (k1 == k0) lo = 0;
+                if (hi == INT32_MAX) hi = lo;
+                if (mx - hi > 32767 && mx - lo > 32767) {
+                    bases[2 * b] = -1;           // raw block
+                    bases[2 * b + 1] = -1;
+                    c16_rawblocks++;
+                    continue;
+                }
+                bases[2 * b] = lo;
+                bases[2 * b + 1] = hi;
+                for (int64_t k = k0; k < k1; ++k) {
+                    const int c = a->colidx[k];
+                    cc[k] = (c - lo <= 32767)
+                                ? (unsigned short)(c - lo)
+                                : (unsigned short)(0x8000 | (c - hi));
+                }
+            }
+            DNS_TRY(c16.alloc(cc.size()));
+            DNS_TRY(c16base.alloc(bases.size()));
+            DNS_TRY(c16.upload(cc.data(), cc.size(), s));
+            DNS_TRY(c16base.upload(bases.data(), bases.size(), s));
+        }
         DNS_HIP(hipStreamSynchronize(s));       // `rb` is a loop temporary
     }
     return DNS_OK;
@@ -115,7 +154,30 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                        double alpha, double beta, const double *b, int variant,
                        hipStream_t s) {
     if (A.nrows == 0) return DNS_OK;
-    if (variant == DNS_SPMV_STREAM) {
+    if (variant == DNS_SPMV_STREAM16 && A.c16.p) {
+        // the same with 16-bit column offsets: 10 instead of 12 bytes per
+        // non-zero cross the HBM
+        const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
+        const int nb = A.nrowblocks_t[1];
+        const int grid = std::min(nb, 65535);
+        const int *rbp = A.rowblocks_t[1].p;
+        if (avg <= 6)
+            hipLaunchKernelGGL((k_spmv_stream16<1>), grid, kBlock, 0, s, nb, rbp,
+                               A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
+                               A.vals.p, x, y, alpha, beta, b);
+        else if (avg <= 12)
+            hipLaunchKernelGGL((k_spmv_stream16<2>), grid, kBlock, 0, s, nb, rbp,
+                               A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
+                               A.vals.p, x, y, alpha, beta, b);
+        else if (avg <= 48)
+            hipLaunchKernelGGL((k_spmv_stream16<4>), grid, kBlock, 0, s, nb, rbp,
+                               A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
+                               A.vals.p, x, y, alpha, beta, b);
+        else
+            hipLaunchKernelGGL((k_spmv_stream16<16>), grid, kBlock, 0, s, nb,
+                               rbp, A.rowptr.p, A.colidx.p, A.c16.p,
+                               A.c16base.p, A.vals.p, x, y, alpha, beta, b);
+    } else if (variant == DNS_SPMV_STREAM || variant == DNS_SPMV_STREAM16) {
         // tile 2048, 2 loads in flight per lane, row pointers staged in LDS:
         // the winner of scripts/spmv_tune.py on the 0.98 GB refined matrix
         launch_stream_g<2048, 2, 1, 0>(A, 1, x, y, alpha, beta, b, s);

@@ -11,7 +11,8 @@ __all__ = ['SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
 
 _METHODS = {'gmres': C.DNS_METHOD_GMRES, 'bicgstab': C.DNS_METHOD_BICGSTAB}
 _SCHUR = {'dense': C.DNS_SCHUR_DENSE, 'jacobi': C.DNS_SCHUR_JACOBI}
-_VARIANTS = {'vector': C.DNS_SPMV_VECTOR, 'stream': C.DNS_SPMV_STREAM}
+_VARIANTS = {'vector': C.DNS_SPMV_VECTOR, 'stream': C.DNS_SPMV_STREAM,
+             'stream16': 2}
 _FHAT = {'cheb': C.DNS_FHAT_CHEB, 'explicit': C.DNS_FHAT_EXPLICIT,
          'auto': C.DNS_FHAT_AUTO}
 

@@ -47,6 +47,7 @@ extern "C" {
 
 #define DNS_SPMV_VECTOR      0   /* sub-wave per row, shuffle reduction      */
 #define DNS_SPMV_STREAM      1   /* row blocks streamed through LDS          */
+#define DNS_SPMV_STREAM16    2   /* the same, 16-bit column offsets per block */
 
 typedef struct dns_saddle dns_saddle;   /* opaque: one saddle-point system  */
 typedef struct dns_imex dns_imex;       /* opaque: device-resident stepper  */

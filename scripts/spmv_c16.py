@@ -1,0 +1,26 @@
+"""A/B of the LDS-streaming SpMV with 32-bit and 16-bit column indices in ONE
+process (interleaved rounds), on the refined benchmark matrix"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import bench
+from dolfin_navier_scipy_amd import saddle
+
+refine = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+_, sm, _ = bench.build_problem(N=2, Re=100., refine=refine)
+K = bench.saddle_csr((sm['M'] + .5/512*sm['A']).tocsr(), sm['J'])
+nb = bench.spmv_bytes(K)
+names = {1: 'stream (int32 cols)', 2: 'stream16 (u16 offsets)'}
+res = {k: [] for k in names}
+for rnd in range(4):
+    for k in names:
+        secs, _ = saddle.spmv_bench(K, variant=k, reps=15, warmup=2)
+        res[k].append(nb/secs/1e9)
+for k in sorted(names):
+    v = np.array(res[k])
+    print('%-24s median %7.0f GB/s (algorithmic)  min %7.0f max %7.0f' % (
+        names[k], np.median(v), v.min(), v.max()))
+x = np.random.default_rng(0).standard_normal(K.shape[1])
+y1 = saddle.spmv(K, x, variant='stream')
+y2 = saddle.spmv(K, x, variant='stream16')
+print('max |y16 - y32| =', np.abs(y1 - y2).max())

@@ -15,7 +15,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 _, sm, _ = bench.build_problem(N=2, Re=100., refine=refine)
 K = bench.saddle_csr((sm['M'] + .5/512*sm['A']).tocsr(), sm['J'])
 out = {}
-for variant in ('stream', 'vector'):
+for variant in ('stream16', 'stream', 'vector'):
     secs, chk = saddle.spmv_bench(K, variant=variant, reps=reps, warmup=3)
     out[variant] = dict(avg_us=secs*1e6, GBs=bench.spmv_bytes(K)/secs/1e9)
 out.update(bytes=bench.spmv_bytes(K), nnz=int(K.nnz), rows=int(K.shape[0]))

@@ -20,7 +20,7 @@ def _rand_csr(rng, nrows, ncols, density):
     return mat
 
 
-@pytest.mark.parametrize('variant', ['vector', 'stream'])
+@pytest.mark.parametrize('variant', ['vector', 'stream', 'stream16'])
 @pytest.mark.parametrize('shape,density', [((1, 1), 1.0), ((7, 5), 0.5),
                                            ((300, 300), 0.02),
                                            ((1000, 1300), 0.03),
@@ -36,7 +36,7 @@ def test_spmv_random(sad, variant, shape, density):
     assert np.abs(y - ref).max() <= 1e-13*scale
 
 
-@pytest.mark.parametrize('variant', ['vector', 'stream'])
+@pytest.mark.parametrize('variant', ['vector', 'stream', 'stream16'])
 def test_spmv_alpha_beta_and_fem_matrix(sad, variant, toy_prob):
     rng = np.random.default_rng(1)
     A = toy_prob['smc']['A']
@@ -49,7 +49,7 @@ def test_spmv_alpha_beta_and_fem_matrix(sad, variant, toy_prob):
 
 def test_spmv_empty_matrix(sad):
     A = sps.csr_matrix((10, 12))
-    for variant in ('vector', 'stream'):
+    for variant in ('vector', 'stream', 'stream16'):
         y = sad.spmv(A, np.ones(12), variant=variant)
         assert np.array_equal(y, np.zeros(10))
 
@@ -61,7 +61,7 @@ def test_spmv_linearity_full_size(sad):
     A = (sm['M'] + 1e-3*sm['A']).tocsr()
     rng = np.random.default_rng(2)
     x1, x2 = rng.standard_normal((2, A.shape[1]))
-    for variant in ('vector', 'stream'):
+    for variant in ('vector', 'stream', 'stream16'):
         y1 = sad.spmv(A, x1, variant=variant)
         y2 = sad.spmv(A, x2, variant=variant)
         y12 = sad.spmv(A, 2*x1 - 3*x2, variant=variant)
@@ -96,3 +96,31 @@ def test_dense_inverse_zero_pivot_raises(sad):
     A = np.zeros((4, 4))
     with pytest.raises(_capi.Breakdown):
         sad.dense_inverse(A)
+
+
+def test_spmv_stream16_windows_and_raw_blocks(sad):
+    """16-bit column offsets: a saddle-type matrix whose rows reach two far
+    apart column windows (second base), and a matrix with columns scattered
+    over more than two 32768-wide windows (blocks fall back to the raw 32-bit
+    indices)"""
+    rng = np.random.default_rng(5)
+    n = 150000
+    rows = np.repeat(np.arange(n), 6)
+    near = (rows + rng.integers(-40, 41, rows.size)) % n
+    far = 100000 + (rows // 3 + rng.integers(0, 30, rows.size)) % 40000
+    cols = np.where(rng.random(rows.size) < 0.7, near, far)
+    A = sps.csr_matrix((rng.standard_normal(rows.size), (rows, cols)),
+                       shape=(n, n))
+    A.sum_duplicates()
+    rb, cb = rng.integers(0, 40000, 1600000), rng.integers(0, 200000, 1600000)
+    B = sps.csr_matrix((rng.standard_normal(rb.size), (rb, cb)),
+                       shape=(40000, 200000))
+    B.sum_duplicates()
+    for mat in (A, B):
+        x = rng.standard_normal(mat.shape[1])
+        ref = mat @ x
+        got = sad.spmv(mat, x, variant='stream16')
+        assert np.abs(got - ref).max() <= 1e-12*np.abs(ref).max()
+        got = sad.spmv(mat, x, y=np.ones(mat.shape[0]), alpha=0.5, beta=-2.0,
+                       variant='stream16')
+        assert np.abs(got - (0.5*ref - 2.0)).max() <= 1e-12*np.abs(ref).max()
