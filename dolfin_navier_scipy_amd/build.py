@@ -37,7 +37,8 @@ def build_library(force=False, verbose=True):
         return LIB
     cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
            '-shared', '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES] \
-        + ['-L/opt/rocm/lib', '-lrccl', '-Wl,-rpath,/opt/rocm/lib']
+        + ['-L/opt/rocm/lib', '-lrccl', '-lpthread',
+           '-Wl,-rpath,/opt/rocm/lib']
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -383,7 +383,21 @@ int dns_saddle::to_f32(const double *in, DevBuf<float> &out, size_t count) {
 //   G = p(D^-1 F) D^-1 with p the degree-(k-1) Chebyshev polynomial of
 //   k_cheb_init/k_cheb_step (so G b == the recurrence applied to b),
 //   Gc = [G, -G JT],  S = J G JT (dense Schur complement of the SAME Fh).
+static double wall_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int dns_saddle::build_explicit(bool dense_schur) {
+    const bool dbg = getenv("DNS_DEBUG") != nullptr;
+    double t0 = wall_now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const double t1 = wall_now();
+        fprintf(stderr, "[dns] setup %-28s %8.1f ms\n", what, 1e3 * (t1 - t0));
+        t0 = t1;
+    };
     std::vector<double> dv((size_t)nv, 1.0);
     for (int i = 0; i < nv; ++i) {
         double d = 0.0;
@@ -393,31 +407,24 @@ int dns_saddle::build_explicit(bool dense_schur) {
     }
     HostCsr DF = Fh;
     host_scale_rows(dv, DF);
-    HostCsr R = host_diag(dv);
-    HostCsr Dm = R;
-    for (auto &v : Dm.vals) v /= theta;
-    HostCsr X;
-    X.nrows = X.ncols = nv;
-    X.rowptr.assign((size_t)nv + 1, 0);
-    for (size_t s = 0; s < c1.size(); ++s) {
-        X = host_add(1.0, X, 1.0, Dm);
-        R = host_add(1.0, R, -1.0, host_spgemm(DF, Dm));
-        Dm = host_add(c1[s], Dm, c2[s], R);
-    }
-    HostCsr G = host_add(1.0, X, 1.0, Dm);
-    // the polynomial's entries decay quickly away from the diagonal: drop what
-    // is below drop_tol * (row maximum); S below is built from the SAME
-    // dropped G, so P stays an exact block factorisation of its own [[Fh,JT],..]
-    if (popts.drop_tol > 0.0) host_drop_small(G, popts.drop_tol);
+    // (with drop_tol == 0 the zero entries of the pattern of F^(k-1) stay)
+    HostCsr G = host_cheb_poly(DF, dv, theta, c1, c2, popts.drop_tol);
+    lap("polynomial G (row recurrences)");
     HostCsr GJT = host_spgemm(G, JTh);
+    lap("G*JT");
     HostCsr negGJT = GJT;
     for (auto &v : negGJT.vals) v = -v;
     HostCsr Gch = host_hstack(G, negGJT);
     dns_csr gv = Gch.view();
     DNS_TRY(Gc.upload(&gv, stream));
     if (fp32_store) DNS_TRY(to_f32(Gc.vals.p, gc32, (size_t)Gc.nnz));
+    lap("hstack + upload Gc");
+    if (dbg)
+        fprintf(stderr, "[dns] setup nnz(G) = %ld, nnz(Gc) = %ld\n",
+                (long)G.vals.size(), (long)Gc.nnz);
     if (dense_schur) {
         HostCsr S = host_spgemm(Jh, GJT);
+        lap("S = J*(G*JT)");
         std::vector<double> sd((size_t)np * np, 0.0);
         for (int i = 0; i < np; ++i)
             for (int k = S.rowptr[i]; k < S.rowptr[i + 1]; ++k)
@@ -425,7 +432,9 @@ int dns_saddle::build_explicit(bool dense_schur) {
         DNS_TRY(sinv.alloc((size_t)np * np));
         DNS_TRY(sinv.upload(sd.data(), sd.size(), stream));
         DNS_HIP(hipStreamSynchronize(stream));
+        lap("densify + upload S");
         DNS_TRY(invert_dense(sinv.p, np));
+        lap("Gauss-Jordan inverse");
     }
     return DNS_OK;
 }
