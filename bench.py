@@ -218,7 +218,7 @@ def main():
                     help='warm start: 0 none, 1 linear, 2 quadratic, 3 cubic')
     ap.add_argument('--fp32', type=int, default=1,
                     help='store the explicit preconditioner matrices in fp32')
-    ap.add_argument('--drop', type=float, default=3e-3,
+    ap.add_argument('--drop', type=float, default=1e-3,
                     help='relative drop tolerance of the explicit polynomial')
     ap.add_argument('--reorth', type=int, default=2,
                     help='1: Gram-Schmidt applied twice (CGS2), 0: once, '
@@ -237,11 +237,17 @@ def main():
                     help='skip the secondary Newton/Picard sweep figures')
     ap.add_argument('--replicas', action='store_true',
                     help='N>1: skip the secondary row-partitioned leg')
+    ap.add_argument('--partitioned-only', action='store_true',
+                    help='(internal) run only the row-partitioned leg and '
+                    'print its figures')
+    ap.add_argument('--partitioned-timeout', type=float, default=150.,
+                    help='time limit [s] of the row-partitioned child run')
     ap.add_argument('--force-dist', action='store_true',
                     help='attach an RCCL communicator even with one rank '
                     '(self-test of the multi-GPU code path)')
     args = ap.parse_args()
 
+    one_gpu = False
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -249,9 +255,15 @@ def main():
     if world > 1:
         import torch
         import torch.distributed as dist
+        # rehearsal of the N > 1 code path on a ONE-GPU box (gloo, every rank
+        # on device 0; RCCL itself refuses two ranks per device, so the
+        # partitioned child then reports an error -- which is the point)
+        one_gpu = os.environ.get('DNS_BENCH_REHEARSE_ONE_GPU') == '1'
+        if one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         with stdout_to_stderr():
-            dist.init_process_group('nccl')
+            dist.init_process_group('gloo' if one_gpu else 'nccl')
             dist.barrier()
     device = local_rank if world > 1 else 0
 
@@ -328,7 +340,8 @@ def main():
         wl = time.perf_counter() - t0
         if dist is not None:
             import torch
-            tw = torch.tensor([wl], dtype=torch.float64, device='cuda')
+            tw = torch.tensor([wl], dtype=torch.float64,
+                              device='cpu' if one_gpu else 'cuda')
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             wl = float(tw.item())
         vv, pp = stp.get_state()
@@ -337,16 +350,8 @@ def main():
             cvop.close()
         return wl, dev_s, its, lst, vv, pp
 
-    # headline: the complete time step, convection evaluated on the device
-    wall, dev_s, iters, last, v_gpu, p_gpu = timed_run(True)
-    # secondary: convection history frozen (the linear algebra alone)
-    wall_fr, _, iters_fr, _, _, _ = timed_run(False)
-
-    # secondary (N > 1, or --force-dist): ONE simulation whose operator applies
-    # are row-partitioned over the ranks -- RCCL all-gather-v of the row blocks
-    # + all-reduce of the Krylov dots (strong scaling by construction)
-    partitioned = None
-    if (world > 1 and not args.replicas) or args.force_dist:
+    def partitioned_leg():
+        comm_obj = None
         try:
             from dolfin_navier_scipy_amd import comm as dcomm
             with stdout_to_stderr():
@@ -362,7 +367,7 @@ def main():
             psteps = min(args.steps, 200)
             pwall, _, piters, plast, _, _ = timed_run(
                 True, nsteps=psteps, nwarm=min(args.warmup, 20))
-            partitioned = dict(
+            res = dict(
                 steps_per_s=psteps/pwall, steps=psteps, scaling='strong',
                 krylov_iters_per_step=piters/float(psteps),
                 true_relres_last=plast['true_relres'],
@@ -372,7 +377,68 @@ def main():
                      'all-reduce per Arnoldi step'.format(world))
         except Exception as exc:       # keep the headline alive
             sys.stderr.write('row-partitioned leg failed: {0}\n'.format(exc))
+            res = dict(error=str(exc))
+        system.set_comm(None)
+        if comm_obj is not None:
+            comm_obj.close()
+        return res
+
+    if args.partitioned_only:
+        res = partitioned_leg()
+        if rank == 0:
+            print(json.dumps(res))
+        system.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return res
+
+    # headline: the complete time step, convection evaluated on the device
+    wall, dev_s, iters, last, v_gpu, p_gpu = timed_run(True)
+    # secondary: convection history frozen (the linear algebra alone)
+    wall_fr, _, iters_fr, _, _, _ = timed_run(False)
+
+    # secondary (N > 1, or --force-dist): ONE simulation whose operator applies
+    # are row-partitioned over the ranks -- RCCL all-gather-v of the row blocks
+    # + all-reduce of the Krylov dots (strong scaling by construction).  With
+    # N > 1 it runs in CHILD processes (one per rank, their own rendezvous) under
+    # a time limit: a collective that never completes must not take the
+    # headline measurement with it.
+    partitioned = None
+    if args.force_dist and world == 1:
+        partitioned = partitioned_leg()
+    elif world > 1 and not args.replicas:
+        import subprocess
+        env = dict(os.environ)
+        env['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500'))
+                                 + 17)
+        cmd = [sys.executable, os.path.abspath(__file__), '--partitioned-only',
+               '--gpus', str(world), '--steps', str(args.steps), '--warmup',
+               str(args.warmup), '--level', str(args.level), '--Re',
+               str(args.Re), '--nts', str(args.nts), '--cheb', str(args.cheb),
+               '--rtol', str(args.rtol), '--extrap', str(args.extrap),
+               '--fp32', str(args.fp32), '--drop', str(args.drop),
+               '--fhat', args.fhat]
+        barrier()
+        try:
+            child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
+                                     stderr=subprocess.DEVNULL,
+                                     start_new_session=True)
+            try:
+                cout, _ = child.communicate(timeout=args.partitioned_timeout)
+                lines = [ln for ln in cout.decode().splitlines()
+                         if ln.startswith('{')]
+                if rank == 0:
+                    partitioned = (json.loads(lines[-1]) if lines else
+                                   dict(error='child exited with code {0} and '
+                                        'no result'.format(child.returncode)))
+            except subprocess.TimeoutExpired:
+                os.killpg(child.pid, 9)
+                child.wait()
+                partitioned = dict(error='no result within {0} s (killed)'
+                                   .format(args.partitioned_timeout))
+        except Exception as exc:
             partitioned = dict(error=str(exc))
+        barrier()
 
     out = None
     if rank == 0:
@@ -458,8 +524,6 @@ def main():
             roofline=roofline, cpu_baseline=cpu, parity=parity)
         print(json.dumps(out))
     system.close()
-    if comm_obj is not None:
-        comm_obj.close()
     lau.clear_cache()
     if dist is not None:
         dist.destroy_process_group()
