@@ -108,3 +108,26 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, fn)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src
                 assert 'krylov_model' not in src
+
+
+def test_pattern_helpers_of_the_newton_picard_module():
+    """host logic of `newton_picard`: union pattern with explicit zeros kept,
+    values laid out in a super-pattern"""
+    import scipy.sparse as sps
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    rng = np.random.default_rng(0)
+    A = sps.random(40, 40, density=0.1, format='csr', random_state=rng)
+    B = sps.random(40, 40, density=0.1, format='csr', random_state=rng)
+    B.data[::3] = 0.                      # explicit zeros must stay
+    P = dnp.union_pattern(A, B)
+    assert P.has_canonical_format and np.all(P.data == 1.)
+    want = set(zip(*A.nonzero())) | set(
+        zip(np.repeat(np.arange(40), np.diff(B.indptr)), B.indices))
+    got = set(zip(np.repeat(np.arange(40), np.diff(P.indptr)), P.indices))
+    assert got == want
+    va, vb = dnp.values_in_pattern(A, P), dnp.values_in_pattern(B, P)
+    rebuilt = sps.csr_matrix((va + 2*vb, P.indices, P.indptr), shape=P.shape)
+    assert abs(rebuilt - (A + 2*B)).max() <= 1e-15
+    with pytest.raises(ValueError):
+        dnp.values_in_pattern(sps.identity(40, format='csr') + A,
+                              dnp.union_pattern(A))
