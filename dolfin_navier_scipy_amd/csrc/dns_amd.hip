@@ -1559,25 +1559,34 @@ int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
 
 int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
                   double *gbytes_per_s) {
-    if (!gbytes_per_s || reps < 1 || bytes < 4096 || kind < 0 || kind > 5)
+    if (!gbytes_per_s || reps < 1 || bytes < 4096 || kind < 0 || kind > 8)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
     DNS_HIP(hipSetDevice(device));
     ScopedStream ss;
     DNS_HIP(hipStreamCreate(&ss.s));
     // kinds 3..5: read with 8 loads in flight on grids of 8/16/32 blocks/CU
+    // 6: 8-byte lane loads, 7/8: tile-contiguous 8-byte loads (8 wg/CU, 1 tile/wg)
     const int narr = (kind == 0 || kind >= 3) ? 1 : (kind == 1 ? 2 : 3);
     const int64_t n2 = bytes / (16 * narr);       // double2 elements per array
     DevBuf<double> a, b, c, part;
     DNS_TRY(a.alloc((size_t)(2 * n2)));
     if (narr > 1) DNS_TRY(b.alloc((size_t)(2 * n2)));
     if (narr > 2) DNS_TRY(c.alloc((size_t)(2 * n2)));
-    const int grid = 256 * (kind == 3 ? 8 : (kind == 5 ? 32 : 16));
+    int grid = 256 * (kind == 3 ? 8 : (kind == 5 ? 32 : 16));
+    if (kind == 7) grid = 256 * 8;
+    if (kind == 8) grid = (int)std::min<int64_t>(65535, 2 * n2 / 2048);
     DNS_TRY(part.alloc((size_t)grid));
     hipLaunchKernelGGL(k_fill_wave, 2048, kBlock, 0, ss.s, (int)std::min<int64_t>(2 * n2, 1 << 30), a.p, 0.37, 1.0, 0);
     if (narr > 1) DNS_TRY(b.zero(ss.s));
     if (narr > 2) DNS_TRY(c.zero(ss.s));
     auto launch = [&]() {
-        if (kind >= 3)
+        if (kind == 6)
+            hipLaunchKernelGGL(k_stream_read_b64, grid, kBlock, 0, ss.s,
+                               2 * n2, a.p, part.p);
+        else if (kind >= 7)
+            hipLaunchKernelGGL(k_stream_read_tiles, grid, kBlock, 0, ss.s,
+                               2 * n2, a.p, part.p);
+        else if (kind >= 3)
             hipLaunchKernelGGL(k_stream_read8, grid, kBlock, 0, ss.s, n2,
                                (const dns_double2 *)a.p, part.p);
         else if (kind == 0)

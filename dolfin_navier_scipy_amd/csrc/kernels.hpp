@@ -229,7 +229,10 @@ k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
 // two window bases, bit 15 of an entry selects the window.  HBM traffic per
 // non-zero drops from 12 to 10 bytes; blocks whose columns do not fit the two
 // windows (bases < 0) read the plain 32-bit indices.
-template <int G>
+// DIAG != 0 are diagnostic variants (scripts/spmv_c16.py; wrong results by
+// design): 1 = x read at the stream position instead of the column (no
+// gather), 2 = additionally no LDS reduction phase
+template <int G, int DIAG = 0>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
                 const int *__restrict__ rowptr, const int *__restrict__ colidx,
@@ -263,13 +266,31 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
         const int nr = r1 - r0;
         if (threadIdx.x < nr) rps[threadIdx.x] = rowptr[r0 + threadIdx.x] - k0;
         if (threadIdx.x == 0) rps[nr] = nn;
-        if (blo >= 0) {
-#pragma unroll 2
-            for (int k = threadIdx.x; k < nn; k += kBlock) {
-                const int e = c16[k0 + k];
-                const int col = ((e & 0x8000) ? bhi : blo) + (e & 0x7fff);
-                prod[k] = vals[k0 + k] * x[col];
+        if (blo >= 0 && nn > 0) {
+            // branch-free: every lane issues its TILE/kBlock value and index
+            // loads back to back (positions past the end are clamped to the
+            // last entry; their products land in LDS slots nobody reads), then
+            // the gathers, then the LDS stores -- the whole 20 KB tile is in
+            // flight at once instead of two loads per lane
+            constexpr int NI = TILE / kBlock;
+            double v[NI];
+            int e[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int kk = k0 + min((int)threadIdx.x + i * kBlock, nn - 1);
+                v[i] = vals[kk];
+                e[i] = c16[kk];
             }
+            double xv[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                int col = ((e[i] & 0x8000) ? bhi : blo) + (e[i] & 0x7fff);
+                if (DIAG) col = r0 + (i & 7);
+                xv[i] = x[col];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                prod[threadIdx.x + i * kBlock] = v[i] * xv[i];
         } else {
 #pragma unroll 2
             for (int k = threadIdx.x; k < nn; k += kBlock)
@@ -278,7 +299,7 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
         __syncthreads();
         const int g = threadIdx.x % G, rsub = threadIdx.x / G;
         for (int r = rsub; r < nr; r += kBlock / G) {
-            const int a0 = rps[r], a1 = rps[r + 1];
+            const int a0 = rps[r], a1 = (DIAG == 2) ? a0 + 1 : rps[r + 1];
             double s = 0.0;
             for (int k = a0 + g; k < a1; k += G) s += prod[k];
             s = subwave_sum<G>(s);
@@ -287,6 +308,94 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
                 y[row] = b ? fma(alpha, s, beta * b[row]) : alpha * s;
             }
         }
+    }
+}
+
+// Persistent form of k_spmv_stream16: a workgroup owns a CONTIGUOUS run of row
+// blocks (grid = a few workgroups per CU) and fetches the next block's
+// descriptors (row range, bases) while it streams the current one, so the
+// dependent chain rowblocks -> rowptr -> stream is paid once per workgroup and
+// not once per 20 KB tile.  Long rows (> TILE non-zeros) take the raw path.
+template <int G>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_stream16p(int nblocks, const int *__restrict__ rowblocks,
+                 const int *__restrict__ rowptr,
+                 const int *__restrict__ colidx,
+                 const unsigned short *__restrict__ c16,
+                 const int *__restrict__ c16base,
+                 const double *__restrict__ vals, const double *__restrict__ x,
+                 double *__restrict__ y, double alpha, double beta,
+                 const double *__restrict__ b) {
+    constexpr int TILE = kStreamNnz;
+    __shared__ double prod[TILE];
+    __shared__ double red[4];
+    __shared__ int rps[kBlock + 1];
+    // XCD-aware chunking as in k_spmv_stream: residue class c (= XCD) gets a
+    // contiguous range of chunks
+    const int gq = gridDim.x / 8, gr = gridDim.x % 8;
+    const int cls = blockIdx.x % 8;
+    const int chunk = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
+    const int per = (nblocks + gridDim.x - 1) / gridDim.x;
+    const int t0 = chunk * per;
+    const int t1 = min(nblocks, t0 + per);
+    if (t0 >= t1) return;
+    int r0 = rowblocks[t0], r1 = rowblocks[t0 + 1];
+    int k0 = rowptr[r0], k1 = rowptr[r1];
+    int blo = c16base[2 * t0], bhi = c16base[2 * t0 + 1];
+    for (int t = t0; t < t1; ++t) {
+        // descriptors of the next block (consumed one iteration later)
+        int nr1 = r1, nk1 = k1, nblo = 0, nbhi = 0;
+        if (t + 1 < t1) {
+            nr1 = rowblocks[t + 2];
+            nk1 = rowptr[nr1];
+            nblo = c16base[2 * t + 2];
+            nbhi = c16base[2 * t + 3];
+        }
+        const int nn = k1 - k0;
+        const int nr = r1 - r0;
+        if (nn > TILE) {
+            double s = 0.0;
+            for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
+                s = fma(vals[k], x[colidx[k]], s);
+            s = block_sum(s, red);
+            if (threadIdx.x == 0)
+                y[r0] = b ? fma(alpha, s, beta * b[r0]) : alpha * s;
+        } else {
+            if (threadIdx.x < nr)
+                rps[threadIdx.x] = rowptr[r0 + threadIdx.x] - k0;
+            if (threadIdx.x == 0) rps[nr] = nn;
+            if (blo >= 0) {
+#pragma unroll 2
+                for (int k = threadIdx.x; k < nn; k += kBlock) {
+                    const int e = c16[k0 + k];
+                    const int col = ((e & 0x8000) ? bhi : blo) + (e & 0x7fff);
+                    prod[k] = vals[k0 + k] * x[col];
+                }
+            } else {
+#pragma unroll 2
+                for (int k = threadIdx.x; k < nn; k += kBlock)
+                    prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
+            }
+            __syncthreads();
+            const int g = threadIdx.x % G, rsub = threadIdx.x / G;
+            for (int r = rsub; r < nr; r += kBlock / G) {
+                const int a0 = rps[r], a1 = rps[r + 1];
+                double s = 0.0;
+                for (int k = a0 + g; k < a1; k += G) s += prod[k];
+                s = subwave_sum<G>(s);
+                if (g == 0) {
+                    const int row = r0 + r;
+                    y[row] = b ? fma(alpha, s, beta * b[row]) : alpha * s;
+                }
+            }
+            __syncthreads();             // tile consumed before the next one
+        }
+        r0 = r1;
+        r1 = nr1;
+        k0 = k1;
+        k1 = nk1;
+        blo = nblo;
+        bhi = nbhi;
     }
 }
 
@@ -664,6 +773,45 @@ k_stream_read8(int64_t n2, const dns_double2 *__restrict__ a,
         s0 += u.x + u.y;
     }
     const double s = block_sum((s0 + s1) + (s2 + s3), red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// 8-byte lane loads (what a CSR value stream uses), eight in flight
+__global__ void __launch_bounds__(kBlock)
+k_stream_read_b64(int64_t n, const double *__restrict__ a,
+                  double *__restrict__ part) {
+    __shared__ double red[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 7 * stride < n; i += 8 * stride) {
+        s0 += a[i] + a[i + 4 * stride];
+        s1 += a[i + stride] + a[i + 5 * stride];
+        s2 += a[i + 2 * stride] + a[i + 6 * stride];
+        s3 += a[i + 3 * stride] + a[i + 7 * stride];
+    }
+    for (; i < n; i += stride) s0 += a[i];
+    const double s = block_sum((s0 + s1) + (s2 + s3), red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// block-contiguous 8-byte lane loads: workgroup b reads tiles b, b+grid, ...
+// of 2048 doubles (the access pattern of the CSR stream kernels)
+__global__ void __launch_bounds__(kBlock)
+k_stream_read_tiles(int64_t n, const double *__restrict__ a,
+                    double *__restrict__ part) {
+    __shared__ double red[4];
+    double s0 = 0.0, s1 = 0.0;
+    const int64_t ntiles = n / 2048;
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const double *p = a + t * 2048;
+#pragma unroll 2
+        for (int k = threadIdx.x; k < 2048; k += 2 * kBlock) {
+            s0 += p[k];
+            s1 += p[k + kBlock];
+        }
+    }
+    const double s = block_sum(s0 + s1, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 

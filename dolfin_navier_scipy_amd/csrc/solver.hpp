@@ -154,7 +154,29 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                        double alpha, double beta, const double *b, int variant,
                        hipStream_t s) {
     if (A.nrows == 0) return DNS_OK;
-    if (variant == DNS_SPMV_STREAM16 && A.c16.p) {
+    if (variant >= 5 && variant <= 8 && A.c16.p) {
+        // persistent workgroups: (variant - 4) * 4 workgroups per CU
+        const int nb = A.nrowblocks_t[1];
+        const int wpc = (variant == 5) ? 4 : (variant == 6 ? 8 : (variant == 7 ? 16 : 32));
+        const int grid = std::max(1, std::min(nb, 256 * wpc));
+        hipLaunchKernelGGL((k_spmv_stream16p<4>), grid, kBlock, 0, s, nb,
+                           A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p, A.c16.p,
+                           A.c16base.p, A.vals.p, x, y, alpha, beta, b);
+    } else if ((variant == 3 || variant == 4) && A.c16.p) {
+        // diagnostic variants of the 16-bit kernel (see k_spmv_stream16)
+        const int nb = A.nrowblocks_t[1];
+        const int grid = std::min(nb, 65535);
+        if (variant == 3)
+            hipLaunchKernelGGL((k_spmv_stream16<4, 1>), grid, kBlock, 0, s, nb,
+                               A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p,
+                               A.c16.p, A.c16base.p, A.vals.p, x, y, alpha,
+                               beta, b);
+        else
+            hipLaunchKernelGGL((k_spmv_stream16<4, 2>), grid, kBlock, 0, s, nb,
+                               A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p,
+                               A.c16.p, A.c16base.p, A.vals.p, x, y, alpha,
+                               beta, b);
+    } else if (variant == DNS_SPMV_STREAM16 && A.c16.p) {
         // the same with 16-bit column offsets: 10 instead of 12 bytes per
         // non-zero cross the HBM
         const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;

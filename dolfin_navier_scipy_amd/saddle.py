@@ -306,6 +306,7 @@ def hbm_probe(nbytes=2 << 30, kind='read', reps=20, device=0):
     C.check(C.load_library().dns_hbm_probe(
         int(device), int(nbytes),
         {'read': 0, 'copy': 1, 'triad': 2, 'read8a': 3, 'read8b': 4,
-         'read8c': 5}[kind],
+         'read8c': 5, 'read_b64': 6, 'read_tiles8': 7,
+         'read_tiles1': 8}[kind],
         int(reps), ct.byref(out)))
     return out.value
