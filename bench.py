@@ -465,8 +465,12 @@ def main():
         attain = None
         if args.roofline_refine > 0:
             attain = {k: saddle.hbm_probe(2 << 30, k, reps=20, device=device)
-                      for k in ('read', 'read8c', 'copy', 'triad')}
-            attain['read'] = max(attain['read'], attain.pop('read8c'))
+                      for k in ('read', 'read8c', 'read_tiles1', 'copy',
+                                'triad')}
+            # best read pattern: grid-stride 16-byte loads or workgroup-
+            # contiguous 16 KiB tiles (what the CSR stream kernels do)
+            attain['read'] = max(attain['read'], attain.pop('read8c'),
+                                 attain.pop('read_tiles1'))
         roofline = dict(bound='hbm', achieved=main_roof['achieved'],
                         peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=main_roof['achieved']/HBM_PEAK_GBS,

@@ -206,9 +206,27 @@ k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
         // lane-contiguous 8-byte value / 4-byte index loads (measured faster
         // here than 16-byte pair loads, whose LDS writes conflict 2-way, and
         // than non-temporal loads, which lose the Infinity Cache at mid sizes)
-#pragma unroll UNR
-        for (int k = threadIdx.x; k < nn; k += kBlock)
-            prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
+        if (UNR == 0 && nn > 0) {
+            // branch-free full-tile loads (see k_spmv_stream16)
+            constexpr int NI = TILE / kBlock;
+            double v[NI], xv[NI];
+            int c[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int kk = k0 + min((int)threadIdx.x + i * kBlock, nn - 1);
+                v[i] = vals[kk];
+                c[i] = colidx[kk];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) xv[i] = x[c[i]];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                prod[threadIdx.x + i * kBlock] = v[i] * xv[i];
+        } else {
+#pragma unroll(UNR > 0 ? UNR : 1)
+            for (int k = threadIdx.x; k < nn; k += kBlock)
+                prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
+        }
         __syncthreads();
         const int g = threadIdx.x % G, rsub = threadIdx.x / G;
         for (int r = rsub; r < nr; r += kBlock / G) {
@@ -308,94 +326,6 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
                 y[row] = b ? fma(alpha, s, beta * b[row]) : alpha * s;
             }
         }
-    }
-}
-
-// Persistent form of k_spmv_stream16: a workgroup owns a CONTIGUOUS run of row
-// blocks (grid = a few workgroups per CU) and fetches the next block's
-// descriptors (row range, bases) while it streams the current one, so the
-// dependent chain rowblocks -> rowptr -> stream is paid once per workgroup and
-// not once per 20 KB tile.  Long rows (> TILE non-zeros) take the raw path.
-template <int G>
-__global__ void __launch_bounds__(kBlock)
-k_spmv_stream16p(int nblocks, const int *__restrict__ rowblocks,
-                 const int *__restrict__ rowptr,
-                 const int *__restrict__ colidx,
-                 const unsigned short *__restrict__ c16,
-                 const int *__restrict__ c16base,
-                 const double *__restrict__ vals, const double *__restrict__ x,
-                 double *__restrict__ y, double alpha, double beta,
-                 const double *__restrict__ b) {
-    constexpr int TILE = kStreamNnz;
-    __shared__ double prod[TILE];
-    __shared__ double red[4];
-    __shared__ int rps[kBlock + 1];
-    // XCD-aware chunking as in k_spmv_stream: residue class c (= XCD) gets a
-    // contiguous range of chunks
-    const int gq = gridDim.x / 8, gr = gridDim.x % 8;
-    const int cls = blockIdx.x % 8;
-    const int chunk = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
-    const int per = (nblocks + gridDim.x - 1) / gridDim.x;
-    const int t0 = chunk * per;
-    const int t1 = min(nblocks, t0 + per);
-    if (t0 >= t1) return;
-    int r0 = rowblocks[t0], r1 = rowblocks[t0 + 1];
-    int k0 = rowptr[r0], k1 = rowptr[r1];
-    int blo = c16base[2 * t0], bhi = c16base[2 * t0 + 1];
-    for (int t = t0; t < t1; ++t) {
-        // descriptors of the next block (consumed one iteration later)
-        int nr1 = r1, nk1 = k1, nblo = 0, nbhi = 0;
-        if (t + 1 < t1) {
-            nr1 = rowblocks[t + 2];
-            nk1 = rowptr[nr1];
-            nblo = c16base[2 * t + 2];
-            nbhi = c16base[2 * t + 3];
-        }
-        const int nn = k1 - k0;
-        const int nr = r1 - r0;
-        if (nn > TILE) {
-            double s = 0.0;
-            for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
-                s = fma(vals[k], x[colidx[k]], s);
-            s = block_sum(s, red);
-            if (threadIdx.x == 0)
-                y[r0] = b ? fma(alpha, s, beta * b[r0]) : alpha * s;
-        } else {
-            if (threadIdx.x < nr)
-                rps[threadIdx.x] = rowptr[r0 + threadIdx.x] - k0;
-            if (threadIdx.x == 0) rps[nr] = nn;
-            if (blo >= 0) {
-#pragma unroll 2
-                for (int k = threadIdx.x; k < nn; k += kBlock) {
-                    const int e = c16[k0 + k];
-                    const int col = ((e & 0x8000) ? bhi : blo) + (e & 0x7fff);
-                    prod[k] = vals[k0 + k] * x[col];
-                }
-            } else {
-#pragma unroll 2
-                for (int k = threadIdx.x; k < nn; k += kBlock)
-                    prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
-            }
-            __syncthreads();
-            const int g = threadIdx.x % G, rsub = threadIdx.x / G;
-            for (int r = rsub; r < nr; r += kBlock / G) {
-                const int a0 = rps[r], a1 = rps[r + 1];
-                double s = 0.0;
-                for (int k = a0 + g; k < a1; k += G) s += prod[k];
-                s = subwave_sum<G>(s);
-                if (g == 0) {
-                    const int row = r0 + r;
-                    y[row] = b ? fma(alpha, s, beta * b[row]) : alpha * s;
-                }
-            }
-            __syncthreads();             // tile consumed before the next one
-        }
-        r0 = r1;
-        r1 = nr1;
-        k0 = k1;
-        k1 = nk1;
-        blo = nblo;
-        bhi = nbhi;
     }
 }
 

@@ -154,15 +154,7 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                        double alpha, double beta, const double *b, int variant,
                        hipStream_t s) {
     if (A.nrows == 0) return DNS_OK;
-    if (variant >= 5 && variant <= 8 && A.c16.p) {
-        // persistent workgroups: (variant - 4) * 4 workgroups per CU
-        const int nb = A.nrowblocks_t[1];
-        const int wpc = (variant == 5) ? 4 : (variant == 6 ? 8 : (variant == 7 ? 16 : 32));
-        const int grid = std::max(1, std::min(nb, 256 * wpc));
-        hipLaunchKernelGGL((k_spmv_stream16p<4>), grid, kBlock, 0, s, nb,
-                           A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p, A.c16.p,
-                           A.c16base.p, A.vals.p, x, y, alpha, beta, b);
-    } else if ((variant == 3 || variant == 4) && A.c16.p) {
+    if ((variant == 3 || variant == 4) && A.c16.p) {
         // diagnostic variants of the 16-bit kernel (see k_spmv_stream16)
         const int nb = A.nrowblocks_t[1];
         const int grid = std::min(nb, 65535);
@@ -200,9 +192,9 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                                rbp, A.rowptr.p, A.colidx.p, A.c16.p,
                                A.c16base.p, A.vals.p, x, y, alpha, beta, b);
     } else if (variant == DNS_SPMV_STREAM || variant == DNS_SPMV_STREAM16) {
-        // tile 2048, 2 loads in flight per lane, row pointers staged in LDS:
-        // the winner of scripts/spmv_tune.py on the 0.98 GB refined matrix
-        launch_stream_g<2048, 2, 1, 0>(A, 1, x, y, alpha, beta, b, s);
+        // tile 2048, branch-free full-tile loads (UNR = 0), row pointers
+        // staged in LDS
+        launch_stream_g<2048, 0, 1, 0>(A, 1, x, y, alpha, beta, b, s);
     } else if (variant >= 16 && variant < 32) {
         // tuning variants (scripts/spmv_tune.py), all on the 2048 tile
         switch (variant - 16) {

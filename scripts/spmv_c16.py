@@ -10,11 +10,10 @@ refine = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 _, sm, _ = bench.build_problem(N=2, Re=100., refine=refine)
 K = bench.saddle_csr((sm['M'] + .5/512*sm['A']).tocsr(), sm['J'])
 nb = bench.spmv_bytes(K)
-names = {1: 'stream (int32 cols)', 2: 'stream16 (u16 offsets)',
+names = {17: 'stream, 2 loads per lane in flight (earlier kernel)',
+         1: 'stream (int32 cols)', 2: 'stream16 (u16 offsets)',
          3: 'diag: stream16 without the x gather',
-         4: 'diag: ... and without the LDS row reduction',
-         5: 'stream16 persistent, 4 wg/CU', 6: 'stream16 persistent, 8 wg/CU',
-         7: 'stream16 persistent, 16 wg/CU', 8: 'stream16 persistent, 32 wg/CU'}
+         4: 'diag: ... and without the LDS row reduction'}
 res = {k: [] for k in names}
 for rnd in range(4):
     for k in names:
@@ -27,8 +26,4 @@ for k in sorted(names):
 x = np.random.default_rng(0).standard_normal(K.shape[1])
 y1 = saddle.spmv(K, x, variant='stream')
 y2 = saddle.spmv(K, x, variant='stream16')
-from dolfin_navier_scipy_amd import saddle as _s
-_s._VARIANTS['p8'] = 6
-y3 = saddle.spmv(K, x, variant='p8')
-print('max |y16p - y32| =', np.abs(y1 - y3).max())
 print('max |y16 - y32| =', np.abs(y1 - y2).max())
