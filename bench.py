@@ -150,6 +150,9 @@ def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64):
     opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=0)
     out = {}
     which = 0
+    # untimed pass: graph capture of the solver cycles (trajectory 0 = the
+    # linearisation points is not modified by a sweep)
+    ts.sweep(trange[:9], v0, which, True, opts=opts, record=False)
     for name, picard in (('picard', True), ('newton', False)):
         t0 = time.perf_counter()
         _, _, upd, st = ts.sweep(trange, v0, which, picard, opts=opts,
