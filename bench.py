@@ -223,6 +223,9 @@ def main():
                     help='store the explicit preconditioner matrices in fp32')
     ap.add_argument('--drop', type=float, default=1e-3,
                     help='relative drop tolerance of the explicit polynomial')
+    ap.add_argument('--fact', default='triangular',
+                    help="block structure of the preconditioner: "
+                    "'triangular' or 'full' (block LDU)")
     ap.add_argument('--reorth', type=int, default=2,
                     help='1: Gram-Schmidt applied twice (CGS2), 0: once, '
                     '2: once, folded into the head kernel of the next step')
@@ -299,7 +302,8 @@ def main():
         mode = ('ensemble: {0} independent simulations, one per GPU, no '
                 'data-path collective'.format(world))
     system.setup_precond(cheb_degree=args.cheb, schur='dense', fhat=args.fhat,
-                         fp32_store=bool(args.fp32), drop_tol=args.drop)
+                         fp32_store=bool(args.fp32), drop_tol=args.drop,
+                         factorization=args.fact)
     _capi.device_synchronize(device)
     t_setup = time.perf_counter() - t_setup
     from dolfin_navier_scipy_amd import convection
@@ -366,7 +370,7 @@ def main():
             system.set_comm(comm_obj)
             system.setup_precond(cheb_degree=args.cheb, schur='dense',
                                  fhat=args.fhat, fp32_store=bool(args.fp32),
-                                 drop_tol=args.drop)
+                                 drop_tol=args.drop, factorization=args.fact)
             psteps = min(args.steps, 200)
             pwall, _, piters, plast, _, _ = timed_run(
                 True, nsteps=psteps, nwarm=min(args.warmup, 20))
@@ -420,7 +424,7 @@ def main():
                str(args.Re), '--nts', str(args.nts), '--cheb', str(args.cheb),
                '--rtol', str(args.rtol), '--extrap', str(args.extrap),
                '--fp32', str(args.fp32), '--drop', str(args.drop),
-               '--fhat', args.fhat]
+               '--fhat', args.fhat, '--fact', args.fact]
         barrier()
         try:
             child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
@@ -515,6 +519,7 @@ def main():
                         parallelism=mode, collectives=None,
                         row_partitioned=partitioned,
                         method=args.method, cheb_degree=args.cheb,
+                        factorization=args.fact, drop_tol=args.drop,
                         schur='dense', rtol=args.rtol,
                         launch='eager' if args.eager else 'hipGraph',
                         krylov_iters_per_step=iters/float(args.steps),

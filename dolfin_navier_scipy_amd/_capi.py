@@ -54,7 +54,8 @@ class dns_precond_opts(ct.Structure):
                 ('fhat', ct.c_int32), ('fp32_store', ct.c_int32),
                 ('eig_lo_safety', ct.c_double), ('eig_hi_safety', ct.c_double),
                 ('eig_lo', ct.c_double), ('eig_hi', ct.c_double),
-                ('drop_tol', ct.c_double)]
+                ('drop_tol', ct.c_double), ('factorization', ct.c_int32),
+                ('pad', ct.c_int32)]
 
 
 class dns_solve_opts(ct.Structure):

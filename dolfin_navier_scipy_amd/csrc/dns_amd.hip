@@ -345,6 +345,29 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
     double *xp = xacc ? xacc + nv : nullptr;
     double *xpf = dist() ? nullptr : xp;     // fused x_p += z_p on one GPU only
     const int r0 = p0(), r1 = p1();
+    if (ldu_active()) {
+        // tau = r_p - (J Fh^-1) r_v; the Schur kernels read `rbase + nv`
+        DNS_TRY(launch_spmv(JG, rvec, tau.p, -1.0, 1.0, rvec + nv,
+                            DNS_SPMV_VECTOR, stream));
+        const double *tb = tau.p - nv;
+        if (popts.schur == DNS_SCHUR_DENSE) {
+            const int g = std::max(1, std::min(np, 2048));
+            if (fp32_store)
+                hipLaunchKernelGGL(k_schur_dense<float>, g, kBlock, 0, stream,
+                                   np, sinv32.p, tb, (size_t)0, zero_ptr(), nv,
+                                   zp, guard, xpf, 0, np);
+            else
+                hipLaunchKernelGGL(k_schur_dense<double>, g, kBlock, 0, stream,
+                                   np, sinv.p, tb, (size_t)0, zero_ptr(), nv,
+                                   zp, guard, xpf, 0, np);
+        } else {
+            hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(np), kBlock, 0,
+                               stream, np, sinv.p, tb, (size_t)0, zero_ptr(),
+                               nv, zp, guard, xpf, 0, np);
+        }
+        DNS_HIP(hipGetLastError());
+        return apply_fhat_part(rvec, zp, zout, guard, xacc);
+    }
     if (popts.schur == DNS_SCHUR_DENSE) {
         const int g = std::max(1, std::min(r1 - r0, 2048));
         if (fp32_store)
@@ -419,6 +442,15 @@ int dns_saddle::build_explicit(bool dense_schur) {
     DNS_TRY(Gc.upload(&gv, stream));
     if (fp32_store) DNS_TRY(to_f32(Gc.vals.p, gc32, (size_t)Gc.nnz));
     lap("hstack + upload Gc");
+    if (popts.factorization == DNS_FACT_FULL) {
+        HostCsr JGh = host_spgemm(Jh, G);
+        dns_csr jv = JGh.view();
+        DNS_TRY(JG.upload(&jv, stream));
+        DNS_TRY(tau.alloc((size_t)std::max(1, np)));
+        have_jg = true;
+        lap("J*G (full factorisation)");
+        if (dbg) fprintf(stderr, "[dns] setup nnz(JG) = %ld\n", (long)JG.nnz);
+    }
     if (dbg)
         fprintf(stderr, "[dns] setup nnz(G) = %ld, nnz(Gc) = %ld\n",
                 (long)G.vals.size(), (long)Gc.nnz);
@@ -535,8 +567,17 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     // bound (pattern of F^(k-1): more bytes, far fewer dependent launches)
     fhat_explicit = (popts.fhat == DNS_FHAT_EXPLICIT) ||
                     (popts.fhat == DNS_FHAT_AUTO && nv <= 200000 &&
-                     popts.cheb_degree >= 2 && popts.cheb_degree <= 6);
+                     popts.cheb_degree >= 2 && popts.cheb_degree <= 12);
     fp32_store = popts.fp32_store != 0;
+    have_jg = false;
+    if (popts.factorization != DNS_FACT_TRIANGULAR &&
+        popts.factorization != DNS_FACT_FULL)
+        return fail(DNS_ERR_BAD_ARGUMENT, "unknown factorization %d",
+                    popts.factorization);
+    if (popts.factorization == DNS_FACT_FULL && !fhat_explicit)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "the full block factorisation needs the explicit Fh^-1 "
+                    "(fhat = explicit / auto within its size limits)");
     if (fhat_explicit) {
         DNS_TRY(build_explicit(popts.schur == DNS_SCHUR_DENSE));
         if (popts.schur == DNS_SCHUR_JACOBI) DNS_TRY(build_jacobi_schur());
@@ -695,40 +736,48 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         const double *src = (j == 0) ? r.p : w.p;
         const double *spart = (j == 0) ? rr_part : partN.p;
         const int snp = (j == 0) ? rr_np : gridD;
+        // full block factorisation: tau = src_p - (J Fh^-1) src_v feeds the
+        // Schur block instead of src_p (unguarded: 3 us when already done)
+        const double *tin = nullptr;
+        if (ldu_active()) {
+            DNS_TRY(launch_spmv(JG, src, tau.p, -1.0, 1.0, src + nv,
+                                DNS_SPMV_VECTOR, stream));
+            tin = tau.p;
+        }
         if (fusedgs && j > 0) {
             if (dense && fp32_store)
                 hipLaunchKernelGGL(k_arn_head_f<2>, gridA, kBlock, 0, stream, n,
                                    nv, np, j, w.p, partA.p, gridC, V.p, ld,
                                    Z.p, (const void *)sinv32.p, ctl.p,
-                                   o->maxiter);
+                                   o->maxiter, tin);
             else if (dense)
                 hipLaunchKernelGGL(k_arn_head_f<1>, gridA, kBlock, 0, stream, n,
                                    nv, np, j, w.p, partA.p, gridC, V.p, ld,
                                    Z.p, (const void *)sinv.p, ctl.p,
-                                   o->maxiter);
+                                   o->maxiter, tin);
             else
                 hipLaunchKernelGGL(k_arn_head_f<0>, gridA, kBlock, 0, stream, n,
                                    nv, np, j, w.p, partA.p, gridC, V.p, ld,
                                    Z.p, (const void *)sinv.p, ctl.p,
-                                   o->maxiter);
+                                   o->maxiter, tin);
         } else if (dense && fp32_store)
             hipLaunchKernelGGL(k_arn_head<2>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv32.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (j == 0) ? first : 0);
+                               (j == 0) ? first : 0, tin);
         else if (dense)
             hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (j == 0) ? first : 0);
+                               (j == 0) ? first : 0, tin);
         else
             hipLaunchKernelGGL(k_arn_head<0>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (j == 0) ? first : 0);
+                               (j == 0) ? first : 0, tin);
         if (dd) DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, zj, done_ptr(),
                                 nullptr));
@@ -1057,6 +1106,8 @@ void dns_default_precond_opts(dns_precond_opts *o) {
     o->eig_hi_safety = 1.05;
     o->eig_lo = 0.0;
     o->eig_hi = 0.0;
+    o->factorization = DNS_FACT_TRIANGULAR;
+    o->pad = 0;
 }
 
 void dns_default_solve_opts(dns_solve_opts *o) {
@@ -1307,14 +1358,14 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv32.p, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
-                                           h->gridS, 1 << 30, 0, np, 0);
+                                           h->gridS, 1 << 30, 0, np, 0, (const double *)nullptr);
                     else
                         hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, s, n,
                                            nv, np, j, h->w.p, h->partN.p,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv.p, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
-                                           h->gridS, 1 << 30, 0, np, 0);
+                                           h->gridS, 1 << 30, 0, np, 0, (const double *)nullptr);
                     break;
                 case 1:
                     DNS_TRY(h->apply_fhat_part(h->V.p + (size_t)j * h->ld, zp,

@@ -117,7 +117,10 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
            double *__restrict__ V, size_t ld, const void *__restrict__ sinv,
            double *__restrict__ zp, DnsCtl *ctl, double rtol, double atol,
            const double *__restrict__ bb_part, int bb_nparts, int maxiter,
-           int prow0, int prow1, int first) {
+           int prow0, int prow1, int first,
+           const double *__restrict__ sp_in) {
+    // sp_in (full block factorisation): tau(src) = src_p - J Fh^-1 src_v
+    // replaces src_p as the input of the Schur block
     // `first` (only with j == 0): 1 = first cycle of a solve -- the counters of
     // the previous solve still sit in the control block and are reset here;
     // 2 = the solve goes on after a Gram-Schmidt fallback: only the status is
@@ -145,7 +148,7 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
         for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
              e += gridDim.x * kBlock)
             vj[e] = src[e] * scale;
-        const double *sp = src + nv;
+        const double *sp = sp_in ? sp_in : src + nv;
         if (SK == 1) {
             dense_rows_block<double>((const double *)sinv, sp, np, -scale, zp,
                                      nullptr, red4, prow0, prow1);
@@ -264,7 +267,10 @@ __global__ void __launch_bounds__(kBlock)
 k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
              const double *__restrict__ hpart, int hnparts,
              double *__restrict__ V, size_t ld, double *__restrict__ Z,
-             const void *__restrict__ sinv, DnsCtl *ctl, int maxiter) {
+             const void *__restrict__ sinv, DnsCtl *ctl, int maxiter,
+             const double *__restrict__ sp_in) {
+    // sp_in: tau(w) = w_p - J Fh^-1 w_v (full block factorisation); the
+    // linearity argument below holds for tau as it does for the pressure part
     if (ctl->done) return;
     __shared__ double h[kMaxRestart + 2];
     __shared__ double red4[4];
@@ -293,16 +299,17 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
                 we = fma(-h[i], V[(size_t)i * ld + e], we);
             vj[e] = we * scale;
         }
-        const double *wp = w + nv;
+        const double *wp = sp_in ? sp_in : w + nv;
         double *zp = Z + (size_t)j * ld + nv;
         if (SK == 0) {
+            // zp_j = (-sd .* wp - sum h_i zp_i) / hn  (zp_i kept in Z_i)
             const double *sd = (const double *)sinv;
             for (int r = blockIdx.x * kBlock + threadIdx.x; r < np;
                  r += gridDim.x * kBlock) {
-                double we = wp[r];
+                double acc = -sd[r] * wp[r];
                 for (int i = 0; i < j; ++i)
-                    we = fma(-h[i], V[(size_t)i * ld + nv + r], we);
-                zp[r] = -sd[r] * we * scale;
+                    acc = fma(-h[i], Z[(size_t)i * ld + nv + r], acc);
+                zp[r] = acc * scale;
             }
         } else {
             for (int row = blockIdx.x; row < np; row += gridDim.x) {

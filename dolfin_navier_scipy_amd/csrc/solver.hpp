@@ -292,6 +292,11 @@ struct dns_saddle {
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open
+    // full block factorisation: J Fh^-1 as one CSR matrix, tau = r_p - JG r_v
+    dns::CsrDev JG;
+    dns::DevBuf<double> tau;
+    bool have_jg = false;
+    bool ldu_active() const { return have_jg && !dist(); }
     bool fh_stale = false;            // F.vals changed on the device
     int device_values_changed();
     int gs_fallbacks = 0;             // solves in a row whose fused Gram-Schmidt

@@ -33,13 +33,15 @@ def solve_opts(method='gmres', restart=60, maxiter=400, reorth=True,
 
 def precond_opts(cheb_degree=4, schur='dense', fhat='auto', eig_lo=0.,
                  eig_hi=0., eig_lo_safety=0.9, eig_hi_safety=1.05,
-                 fp32_store=None, drop_tol=None):
+                 fp32_store=None, drop_tol=None, factorization='triangular'):
     o = C.dns_precond_opts()
     C.load_library().dns_default_precond_opts(ct.byref(o))
     if fp32_store is not None:
         o.fp32_store = 1 if fp32_store else 0
     if drop_tol is not None:
         o.drop_tol = float(drop_tol)
+    o.factorization = {'triangular': 0, 'full': 1}[factorization] \
+        if isinstance(factorization, str) else int(factorization)
     o.cheb_degree = int(cheb_degree)
     o.schur = _SCHUR[schur] if isinstance(schur, str) else schur
     o.fhat = _FHAT[fhat] if isinstance(fhat, str) else fhat

@@ -64,6 +64,19 @@ typedef struct dns_csr {         /* host-side CSR view (borrowed)            */
 #define DNS_FHAT_EXPLICIT    1   /* same polynomial as ONE explicit CSR matrix */
 #define DNS_FHAT_AUTO        2   /* explicit while the system is launch-bound  */
 
+/* block structure of the right preconditioner (both use the same Fh^-1 and the
+ * same Sh = J Fh^-1 JT):
+ *   TRIANGULAR  P = [[Fh, JT], [0, -Sh]]            one Fh^-1 apply
+ *   FULL        P = [[Fh, JT], [J, 0]] exactly (block LDU):
+ *               zp = -Sh^-1 (rp - J Fh^-1 rv),  zv = Fh^-1 (rv - JT zp)
+ *               one more sparse product (J Fh^-1, formed explicitly) per
+ *               apply; needs the explicit Fh^-1 and one GPU.  With a residual
+ *               whose pressure part vanishes (warm-started time steps) the
+ *               triangular form spends two Krylov steps before it starts to
+ *               converge; the full form gains ~2 orders in its first step.  */
+#define DNS_FACT_TRIANGULAR  0
+#define DNS_FACT_FULL        1
+
 typedef struct dns_precond_opts {
     int32_t cheb_degree;         /* terms of the Jacobi-Chebyshev F^-1 (>=1) */
     int32_t schur;               /* DNS_SCHUR_*                              */
@@ -76,6 +89,8 @@ typedef struct dns_precond_opts {
     double  eig_hi_safety;       /* multiply the estimated lambda_max (1.05) */
     double  eig_lo, eig_hi;      /* >0: use these bounds, skip the estimate  */
     double  drop_tol;            /* explicit Gc: drop |g_ij| < tol*max_j|g_ij| */
+    int32_t factorization;       /* DNS_FACT_*                               */
+    int32_t pad;
 } dns_precond_opts;
 
 typedef struct dns_solve_opts {

@@ -96,6 +96,17 @@ class BlockTriPrecond(object):
         return np.concatenate([zv, zp])
 
 
+class BlockFullPrecond(BlockTriPrecond):
+    """`P = [[Fh, JT], [J, 0]]` exactly, as a block LDU product (the device's
+    `DNS_FACT_FULL`): `zp = -Sh^-1 (rp - J Fh^-1 rv)`, `zv = Fh^-1 (rv - JT zp)`"""
+
+    def apply(self, r):
+        rv, rp = r[:self.NV], r[self.NV:]
+        zp = -(self.Sinv @ (rp - self.J @ self.cheb.apply(rv)))
+        zv = self.cheb.apply(rv - self.JT @ zp)
+        return np.concatenate([zv, zp])
+
+
 def gmres(K, b, prec, x0=None, rtol=1e-10, atol=0., restart=60, maxiter=400,
           reorth=True):
     """right-preconditioned GMRES(restart), CGS2; returns x, history"""

@@ -47,7 +47,7 @@ def test_status_strings_and_defaults(capi):
 def test_struct_layout_matches_header(capi):
     import ctypes as ct
     assert ct.sizeof(capi.dns_csr) == 40
-    assert ct.sizeof(capi.dns_precond_opts) == 56
+    assert ct.sizeof(capi.dns_precond_opts) == 64
     assert ct.sizeof(capi.dns_solve_opts) == 40
     assert ct.sizeof(capi.dns_solve_stats) == 48
     assert ct.sizeof(capi.dns_imex_coeffs) == 48

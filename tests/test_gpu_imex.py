@@ -135,8 +135,9 @@ def test_full_size_cnab_against_oracle(gtiu):
     assert np.linalg.norm(pg - po) <= PTOL*np.linalg.norm(po)
 
 
+@pytest.mark.parametrize('fact', ['triangular', 'full'])
 @pytest.mark.parametrize('order', [0, 1, 2, 3])
-def test_pipelined_run_warm_start_orders(gtiu, order):
+def test_pipelined_run_warm_start_orders(gtiu, order, fact):
     """`dns_imex_run` (grouped graphs, ring of five state buffers, replayed
     graphs advancing the host's view of the ring) against the oracle's
     factor-once loop, for every warm-start order; 45 steps = pipelined batches
@@ -163,14 +164,14 @@ def test_pipelined_run_warm_start_orders(gtiu, order):
         vp = lu(np.vstack([rhs, rhsd['fp']]))
         v, pt = vp[:NV], vp[NV:]
     system = saddle.SaddleSystem(F, J)
-    system.setup_precond(cheb_degree=4, schur='dense')
+    system.setup_precond(cheb_degree=4, schur='dense', factorization=fact)
     stp = saddle.ImexStepper(system, R1)
     stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
     stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
     cf = saddle.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
                                    pscale=-1./dt, extrapolate=order)
     opts = saddle.solve_opts(rtol=1e-12, maxiter=300, restart=60,
-                             use_graph=True)
+                             use_graph=True, reorth=2)
     _, its, last = stp.run(nsteps, cf, opts)
     vg, pg = stp.get_state()
     stp.close()
