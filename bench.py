@@ -143,7 +143,8 @@ def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64):
         th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
     trange = dt*np.arange(nsteps + 1)
     ts = dnp.TrapezoidalStepper(M, A, J, cvop, nslots=nsteps + 1, dt=dt,
-                                device=device, precond=dict(cheb_degree=6))
+                                device=device, precond=dict(cheb_degree=6, drop_tol=1e-3,
+                                             factorization='full'))
     ts.set_rhs(rhsd['fv'], rhsd['fp'])
     for k in range(nsteps + 1):       # first linearisation: the initial state
         ts.write_linpoint(0, k, v0)
@@ -217,13 +218,14 @@ def main():
     ap.add_argument('--method', default='gmres')
     ap.add_argument('--cheb', type=int, default=6)
     ap.add_argument('--rtol', type=float, default=1e-10)
-    ap.add_argument('--extrap', type=int, default=3,
-                    help='warm start: 0 none, 1 linear, 2 quadratic, 3 cubic')
+    ap.add_argument('--extrap', type=int, default=4,
+                    help='warm start: 0 none, 1 linear, 2 quadratic, 3 cubic, '
+                    '4 quartic')
     ap.add_argument('--fp32', type=int, default=1,
                     help='store the explicit preconditioner matrices in fp32')
     ap.add_argument('--drop', type=float, default=1e-3,
                     help='relative drop tolerance of the explicit polynomial')
-    ap.add_argument('--fact', default='triangular',
+    ap.add_argument('--fact', default='full',
                     help="block structure of the preconditioner: "
                     "'triangular' or 'full' (block LDU)")
     ap.add_argument('--reorth', type=int, default=2,

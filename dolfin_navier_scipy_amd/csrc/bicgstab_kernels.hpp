@@ -236,7 +236,7 @@ k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
 // n rows of K; replaces gather + k_imex_rhs + k_lincomb* + k_resid_norm):
 //   nfc_c = scale * (convection gather)            [if a device operator is on]
 //   b_v   = R1 (a_c v_c + a_p v_p) + cn_c nfc_c + cn_o nfc_o + g ;  b_p = gp
-//   x0    = e_c x_c + e_p x_p + e_pp x_pp + e_p3 x_p3   (warm start)
+//   x0    = e_c x_c + e_p x_p + e_pp x_pp + e_p3 x_p3 + e_p4 x_p4   (warm start)
 //   r     = b - K x0 ,  partials of ||r||^2 and ||b||^2
 // K x0 is formed from the history vectors directly (x0 of other rows is not
 // available inside the launch): up to three gathers per non-zero.
@@ -251,8 +251,9 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
                 const double *__restrict__ r_vals,
                 const double *__restrict__ x_c, const double *__restrict__ x_p,
                 const double *__restrict__ x_pp,
-                const double *__restrict__ x_p3, double e_c, double e_p,
-                double e_pp, double e_p3, double a_c, double a_p,
+                const double *__restrict__ x_p3,
+                const double *__restrict__ x_p4, double e_c, double e_p,
+                double e_pp, double e_p3, double e_p4, double a_c, double a_p,
                 double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
                 double cn_c, double cn_o, const double *__restrict__ g,
                 const double *__restrict__ gp, const int *__restrict__ gptr,
@@ -302,6 +303,7 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
             if (e_p != 0.0) xv = fma(e_p, x_p[kc], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[kc], xv);
             if (e_p3 != 0.0) xv = fma(e_p3, x_p3[kc], xv);
+            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[kc], xv);
             kx = kval * xv;
         }
         if (r_on) {
@@ -316,6 +318,7 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
             if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
             if (e_p3 != 0.0) xv = fma(e_p3, x_p3[c], xv);
+            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[c], xv);
             kx = fma(k_vals[kk], xv, kx);
         }
         for (rk += LPR; rk < rend; rk += LPR) {
@@ -341,6 +344,7 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
             if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
             if (e_p3 != 0.0) xv = fma(e_p3, x_p3[row], xv);
+            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[row], xv);
             const double rv = bv - kx;
             b[row] = bv;
             x0[row] = xv;

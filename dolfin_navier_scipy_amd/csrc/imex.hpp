@@ -8,22 +8,23 @@ struct dns_imex {
     dns_saddle *sys = nullptr;
     dns::CsrDev R1;
     // two solution-space vectors [v; p~] (current, previous) + work
-    // current, previous, pre-previous, pre-pre-previous, work
-    dns::DevBuf<double> xs[5];
-    dns::DevBuf<double> ck[4];     // checkpoint of the history for a batch
+    // current and the four solutions before it, work
+    dns::DevBuf<double> xs[6];
+    dns::DevBuf<double> ck[5];     // checkpoint of the history for a batch
     dns::DevBuf<double> ckn[2];    // ... and of the convection history
-    int cur = 0, prev = 1, pprev = 2, p3 = 3, work = 4;
-    int nsol = 0;                  // how many valid solution vectors (0..4)
+    int cur = 0, prev = 1, pprev = 2, p3 = 3, p4 = 4, work = 5;
+    int nsol = 0;                  // how many valid solution vectors (0..5)
     long steps_enqueued = 0;       // counts step_device calls (graph replay
                                    // must advance the host state itself)
-    void rotate_host() {           // p3 <- pprev <- prev <- cur <- new
-        const int old = p3;
+    void rotate_host() {           // p4 <- p3 <- pprev <- prev <- cur <- new
+        const int old = p4;
+        p4 = p3;
         p3 = pprev;
         pprev = prev;
         prev = cur;
         cur = work;
         work = old;
-        if (nsol < 4) nsol++;
+        if (nsol < 5) nsol++;
     }
     dns::DevBuf<double> nfc[2];
     int nc = 0, no = 1;

@@ -27,9 +27,9 @@ from .saddle import SaddleSystem, solve_opts
 __all__ = ['solve_sadpnt_smw', 'app_prj_via_sadpnt', 'apply_massinv',
            'SpslaKrylovCounter', 'clear_cache', 'DEFAULTS']
 
-DEFAULTS = dict(direct_tol=1e-12, maxiter=600, restart=60, cheb_degree=4,
-                schur='auto', schur_dense_max=6000, refresh_tol=0.1,
-                device=0, cache_size=4)
+DEFAULTS = dict(direct_tol=1e-12, maxiter=600, restart=60, cheb_degree=6,
+                factorization='full', schur='auto', schur_dense_max=6000,
+                refresh_tol=0.1, device=0, cache_size=4)
 
 _cache = {}          # pattern key -> _Entry
 _cache_order = []
@@ -62,14 +62,17 @@ def _canonical(mat):
     return mat
 
 
-def _precond_kwargs(NP, krplsprms):
+def _precond_kwargs(NP, krplsprms, NV=0):
     prm = dict(krplsprms or {})
     schur = prm.get('schur', DEFAULTS['schur'])
     if schur == 'auto':
         schur = 'dense' if NP <= DEFAULTS['schur_dense_max'] else 'jacobi'
-    return dict(cheb_degree=prm.get('cheb_degree', DEFAULTS['cheb_degree']),
-                schur=schur, eig_lo=prm.get('eig_lo', 0.),
-                eig_hi=prm.get('eig_hi', 0.))
+    deg = prm.get('cheb_degree', DEFAULTS['cheb_degree'])
+    fact = prm.get('factorization', DEFAULTS['factorization'])
+    if NV > 200000 or not 2 <= deg <= 12:
+        fact = 'triangular'      # no explicit polynomial matrix there
+    return dict(cheb_degree=deg, schur=schur, eig_lo=prm.get('eig_lo', 0.),
+                eig_hi=prm.get('eig_hi', 0.), factorization=fact)
 
 
 def _get_system(amat, jmat, jmatT, krplsprms):
@@ -79,7 +82,7 @@ def _get_system(amat, jmat, jmatT, krplsprms):
     than `refresh_tol`"""
     amat, jmat = _canonical(amat), _canonical(jmat)
     key = _pattern_key(amat, jmat)
-    pkw = _precond_kwargs(jmat.shape[0], krplsprms)
+    pkw = _precond_kwargs(jmat.shape[0], krplsprms, NV=jmat.shape[1])
     diag = amat.diagonal()
     ent = _cache.get(key)
     if ent is None:

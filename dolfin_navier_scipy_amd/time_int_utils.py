@@ -28,8 +28,9 @@ __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 
 # solver settings of the time loops; `rtol` is relative to ||rhs||
 SOLVER = dict(method='gmres', rtol=1e-12, maxiter=400, restart=60,
-              cheb_degree=4, schur='auto', extrapolate=3, device=0,
-              check_every=2, use_graph=True)
+              cheb_degree=6, drop_tol=1e-3, factorization='full', reorth=2,
+              schur='auto', extrapolate=4, device=0, check_every=2,
+              use_graph=True)
 
 
 def _checkuniformgrid(trange):
@@ -85,11 +86,16 @@ def _device_system(fmat, J, prm):
     if schur == 'auto':
         schur = 'dense' if NP <= lau.DEFAULTS['schur_dense_max'] else 'jacobi'
     system = SaddleSystem(fmat, J, device=prm['device'])
-    system.setup_precond(cheb_degree=prm['cheb_degree'], schur=schur)
+    # the full block factorisation needs the explicit polynomial matrix
+    fact = prm['factorization']
+    if fmat.shape[0] > 200000 or not 2 <= prm['cheb_degree'] <= 12:
+        fact = 'triangular'
+    system.setup_precond(cheb_degree=prm['cheb_degree'], schur=schur,
+                         drop_tol=prm['drop_tol'], factorization=fact)
     opts = solve_opts(method=prm['method'], rtol=prm['rtol'],
                       maxiter=prm['maxiter'], restart=prm['restart'],
                       check_every=prm['check_every'],
-                      use_graph=prm['use_graph'])
+                      use_graph=prm['use_graph'], reorth=prm['reorth'])
     return system, opts
 
 

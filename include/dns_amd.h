@@ -229,7 +229,8 @@ typedef struct dns_imex_coeffs {
     double pscale;               /* p = pscale * p~  (scalep/dt, tiu:137)    */
     int32_t extrapolate_x0;      /* warm start: 0: x0 = x_c, 1: 2 x_c - x_p,
                                     2: 3 x_c - 3 x_p + x_pp (quadratic),
-                                    3: 4 x_c - 6 x_p + 4 x_pp - x_ppp (cubic) */
+                                    3: 4 x_c - 6 x_p + 4 x_pp - x_ppp (cubic),
+                                    4: 5, -10, 10, -5, 1 (quartic)            */
     int32_t pad;
 } dns_imex_coeffs;
 

@@ -136,7 +136,7 @@ def test_full_size_cnab_against_oracle(gtiu):
 
 
 @pytest.mark.parametrize('fact', ['triangular', 'full'])
-@pytest.mark.parametrize('order', [0, 1, 2, 3])
+@pytest.mark.parametrize('order', [0, 1, 2, 3, 4])
 def test_pipelined_run_warm_start_orders(gtiu, order, fact):
     """`dns_imex_run` (grouped graphs, ring of five state buffers, replayed
     graphs advancing the host's view of the ring) against the oracle's
