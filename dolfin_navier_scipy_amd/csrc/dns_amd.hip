@@ -740,8 +740,13 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         // Schur block instead of src_p (unguarded: 3 us when already done)
         const double *tin = nullptr;
         if (ldu_active()) {
-            DNS_TRY(launch_spmv(JG, src, tau.p, -1.0, 1.0, src + nv,
-                                DNS_SPMV_VECTOR, stream));
+            const int jt = (fusedgs && j > 0) ? j : 0;
+            DNS_LPR_SWITCH(
+                JG.lpr,
+                hipLaunchKernelGGL(k_tau_guard<L>, grid_for_rows(np, JG.lpr),
+                                   kBlock, 0, stream, np, nv, JG.rowptr.p,
+                                   JG.colidx.p, JG.vals.p, src, tau.p, partA.p,
+                                   gridC, jt, ctl.p));
             tin = tau.p;
         }
         if (fusedgs && j > 0) {

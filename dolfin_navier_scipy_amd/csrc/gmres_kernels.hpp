@@ -170,6 +170,7 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
                 ctl->conv = 0;
             }
             if (first) ctl->status = DNS_OK;
+            ctl->predone = 0;
             ctl->jdone = 0;
             ctl->zero = 0;
             ctl->beta = hn;
@@ -274,6 +275,9 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
     if (ctl->done) return;
     __shared__ double h[kMaxRestart + 2];
     __shared__ double red4[4];
+    // the tau kernel in front may have found that column j-1 converges: then
+    // V_j and zp_j are never used and only the column is closed
+    const bool pre = ctl->predone != 0;
     reduce_partials(hpart, hnparts, hnparts, j + 1, h);
     const double hn = pythagoras_norm(h, j);
     if (hn < 0.0) {
@@ -289,7 +293,7 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
         }
         return;
     }
-    if (hn > 0.0) {
+    if (hn > 0.0 && !pre) {
         const double scale = 1.0 / hn;
         double *vj = V + (size_t)j * ld;
         for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
@@ -344,10 +348,55 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         for (int i = 0; i < j; ++i) ctl->hcol[i] = h[i];
         givens_close(ctl, j - 1, hn, maxiter);
+        if (pre) ctl->done = 1;      // (V_j was not formed)
 #ifdef DNS_TRACE_GS
         printf("[gs] j=%d hn/|w|=%.3e res=%.3e\n", j, hn / sqrt(h[j]),
                ctl->resnorm);
 #endif
+    }
+}
+
+// tau = src_p - (J Fh^-1) src_v, the Schur input of the full block
+// factorisation.  With j >= 1 (fused Gram-Schmidt) every workgroup first
+// repeats, read-only, the arithmetic with which the next head kernel will close
+// column j-1; if that column converges nobody needs tau (nor V_j): the verdict
+// goes to ctl->predone and the rows are skipped.
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_tau_guard(int np, int nv, const int *__restrict__ rowptr,
+            const int *__restrict__ colidx, const double *__restrict__ vals,
+            const double *__restrict__ src, double *__restrict__ tau,
+            const double *__restrict__ hpart, int hnparts, int j, DnsCtl *ctl) {
+    if (j > 0) {
+        if (ctl->done) return;
+        __shared__ double h[kMaxRestart + 2];
+        __shared__ int verdict;
+        reduce_partials(hpart, hnparts, hnparts, j + 1, h);
+        if (threadIdx.x == 0) {
+            int v = 0;
+            const double hn = pythagoras_norm(h, j);
+            if (hn >= 0.0) {
+                // column j-1 under the rotations 0..j-2 (as givens_close)
+                double lo = h[0];
+                for (int i = 0; i + 1 < j; ++i)
+                    lo = -ctl->sn[i] * lo + ctl->cs[i] * h[i + 1];
+                const double den = hypot(lo, hn);
+                const double sn = den > 0.0 ? hn / den : 0.0;
+                v = !(fabs(sn * ctl->g[j - 1]) > ctl->tol);
+            }
+            verdict = v;
+            if (blockIdx.x == 0) ctl->predone = v;
+        }
+        __syncthreads();
+        if (verdict) return;
+    }
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    for (int row = sub; row < np; row += nsub) {
+        const double s = csr_row_dot<LPR>(rowptr, colidx, vals, src, row,
+                                          sublane);
+        if (sublane == 0) tau[row] = src[nv + row] - s;
     }
 }
 

@@ -21,7 +21,7 @@ constexpr int kGsFallback = 100;
 
 struct DnsCtl {
     int jdone;       // completed Arnoldi columns of the current cycle
-    int jpad;
+    int predone;     // k_tau_guard: the column about to be closed converges
     int done;        // != 0: all later kernels of this solve return at once
     int status;      // DNS_OK / DNS_BREAKDOWN
     int zero;        // constant 0 (vector selector / never-raised guard)

@@ -219,7 +219,7 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
 }
 
 struct CtlHeader {   // leading part of DnsCtl, copied back to the host
-    int jdone, jpad;
+    int jdone, predone;
     int done, status, zero, total_it, hist_len, conv;
     double beta, tol, resnorm, bnorm;
 };
