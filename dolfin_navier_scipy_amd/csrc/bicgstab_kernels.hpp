@@ -370,6 +370,18 @@ k_lincomb2(int n, double e_c, const double *__restrict__ x_c, double e_p,
         out[i] = fma(e_c, x_c[i], e_p * x_p[i]);
 }
 
+// x0 = 5 x_c - 10 x_p + 10 x_pp - 5 x_p3 + x_p4  (quartic extrapolation)
+__global__ void __launch_bounds__(kBlock)
+k_lincomb5(int n, const double *__restrict__ x_c,
+           const double *__restrict__ x_p, const double *__restrict__ x_pp,
+           const double *__restrict__ x_p3, const double *__restrict__ x_p4,
+           double *__restrict__ out) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock)
+        out[i] = 5.0 * x_c[i] - 10.0 * x_p[i] + 10.0 * x_pp[i] -
+                 5.0 * x_p3[i] + x_p4[i];
+}
+
 // x0 = 4 x_c - 6 x_p + 4 x_pp - x_p3  (cubic extrapolation of the last four)
 __global__ void __launch_bounds__(kBlock)
 k_lincomb4(int n, const double *__restrict__ x_c,

@@ -345,42 +345,33 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
     double *xp = xacc ? xacc + nv : nullptr;
     double *xpf = dist() ? nullptr : xp;     // fused x_p += z_p on one GPU only
     const int r0 = p0(), r1 = p1();
-    if (ldu_active()) {
-        // tau = r_p - (J Fh^-1) r_v; the Schur kernels read `rbase + nv`
-        DNS_TRY(launch_spmv(JG, rvec, tau.p, -1.0, 1.0, rvec + nv,
-                            DNS_SPMV_VECTOR, stream));
-        const double *tb = tau.p - nv;
-        if (popts.schur == DNS_SCHUR_DENSE) {
-            const int g = std::max(1, std::min(np, 2048));
-            if (fp32_store)
-                hipLaunchKernelGGL(k_schur_dense<float>, g, kBlock, 0, stream,
-                                   np, sinv32.p, tb, (size_t)0, zero_ptr(), nv,
-                                   zp, guard, xpf, 0, np);
-            else
-                hipLaunchKernelGGL(k_schur_dense<double>, g, kBlock, 0, stream,
-                                   np, sinv.p, tb, (size_t)0, zero_ptr(), nv,
-                                   zp, guard, xpf, 0, np);
-        } else {
-            hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(np), kBlock, 0,
-                               stream, np, sinv.p, tb, (size_t)0, zero_ptr(),
-                               nv, zp, guard, xpf, 0, np);
-        }
-        DNS_HIP(hipGetLastError());
-        return apply_fhat_part(rvec, zp, zout, guard, xacc);
+    const double *rvec_schur = rvec;
+    if (have_jg) {
+        // full block factorisation: tau = r_p - (J Fh^-1) r_v (this rank's
+        // rows, gathered) is what the Schur block sees; its kernels read
+        // `rbase + nv`
+        DNS_LPR_SWITCH(
+            JG.lpr,
+            hipLaunchKernelGGL(k_tau_guard<L>, grid_for_rows(r1 - r0, JG.lpr),
+                               kBlock, 0, stream, np, nv, JG.rowptr.p,
+                               JG.colidx.p, JG.vals.p, rvec, tau.p,
+                               (const double *)nullptr, 0, 0, ctl.p, r0, r1));
+        if (dist()) DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
+        rvec_schur = tau.p - nv;
     }
     if (popts.schur == DNS_SCHUR_DENSE) {
         const int g = std::max(1, std::min(r1 - r0, 2048));
         if (fp32_store)
             hipLaunchKernelGGL(k_schur_dense<float>, g, kBlock, 0, stream, np,
-                               sinv32.p, rvec, (size_t)0, zero_ptr(), nv, zp,
+                               sinv32.p, rvec_schur, (size_t)0, zero_ptr(), nv, zp,
                                guard, xpf, r0, r1);
         else
             hipLaunchKernelGGL(k_schur_dense<double>, g, kBlock, 0, stream, np,
-                               sinv.p, rvec, (size_t)0, zero_ptr(), nv, zp,
+                               sinv.p, rvec_schur, (size_t)0, zero_ptr(), nv, zp,
                                guard, xpf, r0, r1);
     } else {
         hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(r1 - r0), kBlock, 0,
-                           stream, np, sinv.p, rvec, (size_t)0, zero_ptr(), nv,
+                           stream, np, sinv.p, rvec_schur, (size_t)0, zero_ptr(), nv,
                            zp, guard, xpf, r0, r1);
     }
     if (dist()) {
@@ -739,14 +730,16 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         // full block factorisation: tau = src_p - (J Fh^-1) src_v feeds the
         // Schur block instead of src_p (unguarded: 3 us when already done)
         const double *tin = nullptr;
-        if (ldu_active()) {
+        if (have_jg) {
             const int jt = (fusedgs && j > 0) ? j : 0;
             DNS_LPR_SWITCH(
                 JG.lpr,
-                hipLaunchKernelGGL(k_tau_guard<L>, grid_for_rows(np, JG.lpr),
-                                   kBlock, 0, stream, np, nv, JG.rowptr.p,
-                                   JG.colidx.p, JG.vals.p, src, tau.p, partA.p,
-                                   gridC, jt, ctl.p));
+                hipLaunchKernelGGL(k_tau_guard<L>,
+                                   grid_for_rows(q1 - q0, JG.lpr), kBlock, 0,
+                                   stream, np, nv, JG.rowptr.p, JG.colidx.p,
+                                   JG.vals.p, src, tau.p, partA.p, gridC, jt,
+                                   ctl.p, q0, q1));
+            if (dd) DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
             tin = tau.p;
         }
         if (fusedgs && j > 0) {

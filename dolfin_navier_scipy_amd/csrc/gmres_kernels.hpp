@@ -366,7 +366,11 @@ __global__ void __launch_bounds__(kBlock)
 k_tau_guard(int np, int nv, const int *__restrict__ rowptr,
             const int *__restrict__ colidx, const double *__restrict__ vals,
             const double *__restrict__ src, double *__restrict__ tau,
-            const double *__restrict__ hpart, int hnparts, int j, DnsCtl *ctl) {
+            const double *__restrict__ hpart, int hnparts, int j, DnsCtl *ctl,
+            int row0, int row1) {
+    // rows [row0, row1): all of them on one GPU, this rank's Schur rows in
+    // the row-partitioned solve
+    (void)np;
     if (j > 0) {
         if (ctl->done) return;
         __shared__ double h[kMaxRestart + 2];
@@ -393,7 +397,7 @@ k_tau_guard(int np, int nv, const int *__restrict__ rowptr,
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < np; row += nsub) {
+    for (int row = row0 + sub; row < row1; row += nsub) {
         const double s = csr_row_dot<LPR>(rowptr, colidx, vals, src, row,
                                           sublane);
         if (sublane == 0) tau[row] = src[nv + row] - s;

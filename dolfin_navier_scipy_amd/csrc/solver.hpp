@@ -296,7 +296,6 @@ struct dns_saddle {
     dns::CsrDev JG;
     dns::DevBuf<double> tau;
     bool have_jg = false;
-    bool ldu_active() const { return have_jg && !dist(); }
     bool fh_stale = false;            // F.vals changed on the device
     int device_values_changed();
     int gs_fallbacks = 0;             // solves in a row whose fused Gram-Schmidt

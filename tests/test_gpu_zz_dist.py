@@ -43,12 +43,15 @@ def _problem():
                 v0=rng.standard_normal(NV), nfc=M @ rng.standard_normal(NV))
 
 
-def _solve_and_step(sad, comm, fhat, reorth):
+def _solve_and_step(sad, comm, fhat, reorth, fact='triangular'):
     pr = _problem()
     system = sad.SaddleSystem(pr['F'], pr['J'])
     if comm is not None:
         system.set_comm(comm)
-    system.setup_precond(cheb_degree=4, schur='dense', fhat=fhat)
+    if fhat == 'full':          # full block factorisation (explicit Fh^-1)
+        fhat, fact = 'explicit', 'full'
+    system.setup_precond(cheb_degree=4, schur='dense', fhat=fhat,
+                         factorization=fact)
     x = system.solve(pr['rhsv'], pr['rhsp'], rtol=1e-12, reorth=reorth)
     stats = dict(system.last_stats)
     # a few device-resident CNAB steps through the same communicator
@@ -71,7 +74,7 @@ def test_rccl_world_size_one_equals_plain_solve():
     assert _capi.device_count() > 0
     x0, st0, v0, p0 = _solve_and_step(saddle, None, 'explicit', True)
     cm = dcomm.Comm.rccl(0, 1, 0, dcomm.rccl_unique_id())
-    for fhat in ('explicit', 'cheb'):
+    for fhat in ('explicit', 'cheb', 'full'):
         x1, st1, v1, p1 = _solve_and_step(saddle, cm, fhat, True)
         assert st1['status'] == 0 and st1['true_relres'] <= 5e-12
         assert np.linalg.norm(x1 - x0) <= 1e-9*np.linalg.norm(x0)
@@ -97,7 +100,7 @@ def _worker(rank, world, port, outdir):
     from dolfin_navier_scipy_amd import saddle, comm as dcomm
     cm = dcomm.Comm.gloo(0)
     out = {}
-    for fhat, reorth in (('explicit', False), ('cheb', True)):
+    for fhat, reorth in (('explicit', False), ('cheb', True), ('full', False)):
         x, st, v, p = _solve_and_step(saddle, cm, fhat, reorth)
         out[fhat] = (x, v, p, st['iters'], st['true_relres'])
     np.savez(os.path.join(outdir, 'rank{0}.npz'.format(rank)),
@@ -127,7 +130,8 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
                                          rhsp=pr['rhsp']).reshape(-1)
     NV = pr['F'].shape[0]
     xs, sts, vs, ps = _solve_and_step(saddle, None, 'explicit', False)
-    for fhat in ('explicit', 'cheb'):
+    xf, stf, _, _ = _solve_and_step(saddle, None, 'full', False)
+    for fhat in ('explicit', 'cheb', 'full'):
         x_a, x_b = r0[fhat + '_0'], r1[fhat + '_0']
         # both ranks end with the same full iterate ...
         assert np.array_equal(x_a, x_b)
@@ -140,3 +144,7 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
         assert np.linalg.norm(r0[fhat + '_1'] - vs) <= 1e-9*np.linalg.norm(vs)
         assert np.linalg.norm(r0[fhat + '_2'] - ps) <= 1e-7*np.linalg.norm(ps)
     assert abs(int(r0['explicit_3']) - sts['iters']) <= 1
+    # the full block factorisation is partitioned too (one more all-gather
+    # per apply) and needs the same few steps as on one GPU
+    assert abs(int(r0['full_3']) - stf['iters']) <= 1
+    assert int(r0['full_3']) < int(r0['explicit_3'])
