@@ -356,7 +356,8 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
                                kBlock, 0, stream, np, nv, JG.rowptr.p,
                                JG.colidx.p, JG.vals.p, rvec, tau.p,
                                (const double *)nullptr, 0, 0, ctl.p, r0, r1));
-        if (dist()) DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
+        if (dist() && !repl_schur())
+            DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
         rvec_schur = tau.p - nv;
     }
     if (popts.schur == DNS_SCHUR_DENSE) {
@@ -375,7 +376,7 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
                            zp, guard, xpf, r0, r1);
     }
     if (dist()) {
-        DNS_TRY(comm->allgatherv(zp, st_p, stream));
+        if (!repl_schur()) DNS_TRY(comm->allgatherv(zp, st_p, stream));
         if (xp) {
             hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
                                (int64_t)np, 1.0, zp, 1.0, xp);
@@ -739,7 +740,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                    stream, np, nv, JG.rowptr.p, JG.colidx.p,
                                    JG.vals.p, src, tau.p, partA.p, gridC, jt,
                                    ctl.p, q0, q1));
-            if (dd) DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
+            if (dd && !repl_schur())
+                DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
             tin = tau.p;
         }
         if (fusedgs && j > 0) {
@@ -776,7 +778,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
                                (j == 0) ? first : 0, tin);
-        if (dd) DNS_TRY(comm->allgatherv(zp, st_p, stream));
+        if (dd && !repl_schur())
+            DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, zj, done_ptr(),
                                 nullptr));
         if (fuse_dots) {
