@@ -161,3 +161,67 @@ def test_device_newton_picard_driver_matches_oracle(setup, cvop):
         ep = np.linalg.norm(got_p[t] - ref_p[t])/np.linalg.norm(ref_p[t])
         assert ev <= 1e-8 and ep <= 1e-6, (t, ev, ep)
     stp.close()
+
+
+def test_full_size_picard_and_newton_sweep_against_oracle():
+    """cylinder wake N=2 (NV=9356, NP=1289), Re=100, dt=1/512: a Picard and a
+    Newton sweep of 6 steps, device path vs the oracle's restatement with the
+    host assembler (BASELINE config 3 at its real size)"""
+    from dolfin_navier_scipy_amd import convection, saddle
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    from oracle import saddle_oracle
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=100)
+    th, inv = femp['V'], femp['invinds']
+    dbcinds, dbcvals = femp['dbcinds'], femp['dbcvals']
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    vp0 = saddle_oracle.solve_sadpnt_smw(amat=A, jmat=J, rhsv=rhsd['fv'],
+                                         rhsp=rhsd['fp'])
+    iniv = vp0[:NV]
+
+    def appnd(vvec):
+        full = np.zeros((th.vdim, 1))
+        full[inv] = vvec
+        full[dbcinds, 0] = dbcvals
+        return full
+
+    bcsv = np.zeros((th.vdim, 1))
+    bcsv[dbcinds, 0] = dbcvals
+
+    def conv(vfull, picard):
+        if vfull.shape[0] == NV:
+            vfull = appnd(vfull)
+        N1, N2, fv3 = th.convection_mats(vfull, keep_pattern=True)
+        Nm = N1 if picard else (N1 + N2)
+        return (Nm[inv, :][:, inv].tocsr(),
+                0.*fv3[inv, :] if picard else fv3[inv, :],
+                -(Nm @ bcsv)[inv, :])
+
+    tr = np.arange(7)/512.
+    lin0 = {t: iniv for t in tr}
+    cv = convection.ConvectionP2.from_taylor_hood(th, inv, dbcinds, dbcvals)
+    stp = dnp.TrapezoidalStepper(M, A, J, cv, nslots=tr.size, dt=tr[1] - tr[0])
+    stp.set_rhs(rhsd['fv'], rhsd['fp'])
+    opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True, reorth=2)
+    mnorm = lambda x: np.sqrt((x.T @ (M @ x)).item())
+    lin = lin0
+    which = 0
+    for k, t in enumerate(tr):
+        stp.write_linpoint(which, k, lin[t])
+    for picard in (True, False):
+        ref_v, ref_p, ref_upd = npo.trapezoidal_sweep(
+            tr, iniv, M=M, A=A, J=J, fv=rhsd['fv'], fp=rhsd['fp'], conv=conv,
+            appndbcs=appnd, linpoints=lin, picard=picard)
+        got_v, got_p, upd, st = stp.sweep(tr, iniv, which, picard, opts=opts)
+        for t in tr[1:]:
+            assert mnorm(got_v[t] - ref_v[t]) <= 1e-8*mnorm(ref_v[t]), t
+            assert np.linalg.norm(got_p[t] - ref_p[t]) <= \
+                1e-6*np.linalg.norm(ref_p[t]), t
+        assert abs(upd - ref_upd) <= 1e-6*abs(ref_upd) + 1e-20
+        lin = ref_v                      # next sweep: about the oracle's result
+        which = 1 - which
+        for k, t in enumerate(tr):
+            stp.write_linpoint(which, k, lin[t])
+    stp.close()
+    cv.close()
