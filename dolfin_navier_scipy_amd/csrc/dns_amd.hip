@@ -71,7 +71,33 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     n = nv + np;
     ld = ((size_t)n + 63) / 64 * 64;
     DNS_HIP(hipSetDevice(device));
-    DNS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // DNS_CU_MASK (experiment knob, read when the handle is created)
+    // restricts the handle's stream to a subset of the CUs: "8=k" = the CUs i
+    // with i % 8 == k, "8<k" = i % 8 < k.  Measured at N=2: a time step runs as
+    // fast on the 32 CUs of "8=0" as on all 256 (it is latency bound), so
+    // several simulations can share one GPU (scripts/xcd_ensemble.py: 1 / 2 /
+    // 4 concurrent simulations advance 16.0k / 26.5k / 37.7k steps/s in total;
+    // 8 host threads fall back to 22k -- launch-side contention).
+    if (const char *cm = getenv("DNS_CU_MASK")) {
+        int mod = 0, arg = 0;
+        char op = 0;
+        if (sscanf(cm, "%d%c%d", &mod, &op, &arg) != 3 || mod < 1 ||
+            (op != '=' && op != '<') || arg < 0)
+            return fail(DNS_ERR_BAD_ARGUMENT, "bad DNS_CU_MASK '%s'", cm);
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int count = 0;
+        for (int i = 0; i < 256; ++i) {
+            const bool on = (op == '=') ? (i % mod) == arg : (i % mod) < arg;
+            if (on) {
+                mask[i / 32] |= (1u << (i % 32));
+                ++count;
+            }
+        }
+        if (count == 0) return fail(DNS_ERR_BAD_ARGUMENT, "empty DNS_CU_MASK");
+        DNS_HIP(hipExtStreamCreateWithCUMask(&stream, 8, mask));
+    } else {
+        DNS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    }
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
