@@ -75,6 +75,41 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
                                                 int nscal, double *out) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int nw = blockDim.x >> 6;
+    if (2 * nscal <= nw) {
+        // few scalars (the norms at the head of a cycle, one-column Arnoldi
+        // steps): several waves share a scalar, so that its ~1e3 partials are
+        // fetched in ONE batch of independent loads instead of three
+        __shared__ double rp_tmp[16];
+        const int wps = nw / nscal;              // waves per scalar
+        const int s = wave / wps, q = wave % wps;
+        if (s < nscal) {
+            const double *ps = part + (size_t)s * pstride;
+            const int step = 64 * wps;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            double a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+            for (int p = lane + 64 * q; p < nparts; p += 8 * step) {
+                a0 += ps[p];
+                a1 += (p + step < nparts) ? ps[p + step] : 0.0;
+                a2 += (p + 2 * step < nparts) ? ps[p + 2 * step] : 0.0;
+                a3 += (p + 3 * step < nparts) ? ps[p + 3 * step] : 0.0;
+                a4 += (p + 4 * step < nparts) ? ps[p + 4 * step] : 0.0;
+                a5 += (p + 5 * step < nparts) ? ps[p + 5 * step] : 0.0;
+                a6 += (p + 6 * step < nparts) ? ps[p + 6 * step] : 0.0;
+                a7 += (p + 7 * step < nparts) ? ps[p + 7 * step] : 0.0;
+            }
+            double a = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+            a = wave_sum(a);
+            if (lane == 0) rp_tmp[wave] = a;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < nscal) {
+            double a = 0.0;
+            for (int k = 0; k < wps; ++k) a += rp_tmp[threadIdx.x * wps + k];
+            out[threadIdx.x] = a;
+        }
+        __syncthreads();
+        return;
+    }
     for (int s = wave; s < nscal; s += nw) {
         // 8 independent loads in flight per lane: the partials sit in L2 /
         // Infinity Cache and a dependent chain of loads would cost a round
