@@ -656,6 +656,8 @@ int dns_saddle::true_residual(const double *b, const double *x, double *out) {
 }
 
 void dns_saddle::drop_graphs() {
+    // replays may still be in flight on the stream
+    if (!graphs.empty() && stream) (void)hipStreamSynchronize(stream);
     for (auto &g : graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (g.graph) (void)hipGraphDestroy(g.graph);
