@@ -531,9 +531,12 @@ k_arn_tail(int c, const double *__restrict__ norm_part, int nparts,
     // fused: `norm_part` holds the partials of h_0..h_{c-1} and <w, w> of the
     // last step (no Gram-Schmidt kernel ran), else those of ||w||^2
     __shared__ double sc[kMaxRestart + 2];
-    reduce_partials(norm_part, nparts, nparts, fused ? c + 1 : 1, sc);
+    // (the cycle usually stopped earlier: then there is nothing to reduce)
+    const bool open_col = !ctl->done && c > 0;
+    if (open_col)
+        reduce_partials(norm_part, nparts, nparts, fused ? c + 1 : 1, sc);
     if (threadIdx.x != 0) return;
-    if (!ctl->done && c > 0) {
+    if (open_col) {
         double hn;
         if (fused) {
             hn = pythagoras_norm(sc, c);
