@@ -386,6 +386,10 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
             DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
         rvec_schur = tau.p - nv;
     }
+    if (popts.schur == DNS_SCHUR_MG) {
+        DNS_TRY(schur_mg_apply(rvec_schur + nv, zp, xp));
+        return apply_fhat_part(rvec, zp, zout, guard, xacc);
+    }
     if (popts.schur == DNS_SCHUR_DENSE) {
         const int g = std::max(1, std::min(r1 - r0, 2048));
         if (fp32_store)
@@ -485,6 +489,11 @@ int dns_saddle::build_explicit(bool dense_schur) {
         lap("densify + upload S");
         DNS_TRY(invert_dense(sinv.p, np));
         lap("Gauss-Jordan inverse");
+    } else if (popts.schur == DNS_SCHUR_MG) {
+        HostCsr S = host_spgemm(Jh, GJT);
+        lap("S = J*(G*JT)");
+        DNS_TRY(build_mg_schur(S));
+        lap("multigrid hierarchy");
     }
     return DNS_OK;
 }
@@ -531,6 +540,124 @@ int dns_saddle::build_dense_schur() {
     return invert_dense(sinv.p, np);
 }
 
+// Multigrid hierarchy of the Schur block: S_0 given (sparse), Galerkin coarse
+// operators through the prolongations handed over by dns_saddle_set_schur_mg,
+// dense inverse on the coarsest level.
+int dns_saddle::build_mg_schur(const HostCsr &S0) {
+    mg_ready = false;
+    if (!mg_set)
+        return fail(DNS_ERR_NOT_READY,
+                    "DNS_SCHUR_MG needs dns_saddle_set_schur_mg first");
+    if (!mg_prol_h.empty() && mg_prol_h[0].nrows != np)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "finest prolongation has %d rows, NP = %d",
+                    mg_prol_h[0].nrows, np);
+    const int L = (int)mg_prol_h.size() + 1;
+    mg.clear();
+    for (int l = 0; l < L; ++l) mg.emplace_back();
+    HostCsr Sl = S0;
+    for (int l = 0; l < L; ++l) {
+        MgLevel &lv = mg[l];
+        lv.n = Sl.nrows;
+        DNS_TRY(lv.x.alloc((size_t)lv.n));
+        DNS_TRY(lv.b.alloc((size_t)lv.n));
+        DNS_TRY(lv.r.alloc((size_t)lv.n));
+        if (l == L - 1) {
+            // coarsest: dense inverse
+            std::vector<double> sd((size_t)lv.n * lv.n, 0.0);
+            for (int i = 0; i < lv.n; ++i)
+                for (int k = Sl.rowptr[i]; k < Sl.rowptr[i + 1]; ++k)
+                    sd[(size_t)i * lv.n + Sl.colidx[k]] += Sl.vals[k];
+            if ((int64_t)lv.n * lv.n * 8 > (int64_t)8 << 30)
+                return fail(DNS_ERR_BAD_ARGUMENT,
+                            "coarsest multigrid level too large (%d)", lv.n);
+            DNS_TRY(mg_cinv.alloc(sd.size()));
+            DNS_TRY(mg_cinv.upload(sd.data(), sd.size(), stream));
+            DNS_HIP(hipStreamSynchronize(stream));
+            DNS_TRY(invert_dense(mg_cinv.p, lv.n));
+            break;
+        }
+        const HostCsr &P = mg_prol_h[l];
+        if (P.nrows != lv.n)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "prolongation %d has %d rows, level has %d", l, P.nrows,
+                        lv.n);
+        std::vector<double> dv((size_t)lv.n, 1.0);
+        for (int i = 0; i < lv.n; ++i) {
+            double d = 0.0;
+            for (int k = Sl.rowptr[i]; k < Sl.rowptr[i + 1]; ++k)
+                if (Sl.colidx[k] == i) d += Sl.vals[k];
+            dv[i] = (d != 0.0) ? 1.0 / d : 1.0;
+        }
+        lv.omega = 4.0 / (3.0 * std::max(1e-300, host_jacobi_lmax(Sl)));
+        HostCsr PT = host_transpose(P);
+        dns_csr sv = Sl.view(), pv = P.view(), tv = PT.view();
+        DNS_TRY(lv.S.upload(&sv, stream));
+        DNS_TRY(lv.P.upload(&pv, stream));
+        DNS_TRY(lv.PT.upload(&tv, stream));
+        DNS_TRY(lv.dinv.alloc((size_t)lv.n));
+        DNS_TRY(lv.dinv.upload(dv.data(), dv.size(), stream));
+        DNS_HIP(hipStreamSynchronize(stream));
+        Sl = host_spgemm(PT, host_spgemm(Sl, P));
+    }
+    mg_ready = true;
+    return DNS_OK;
+}
+
+// zp = -MG(in): one V(nu, nu) cycle with damped Jacobi; xacc: x_p += zp
+int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc) {
+    const int L = (int)mg.size();
+    auto smooth = [&](MgLevel &lv, const double *b, bool from_zero) -> int {
+        for (int sweep = 0; sweep < mg_nu; ++sweep) {
+            if (from_zero && sweep == 0) {
+                hipLaunchKernelGGL(k_mg_jacobi, grid_for_elems(lv.n), kBlock, 0,
+                                   stream, lv.n, lv.omega, lv.dinv.p, b, lv.x.p,
+                                   0);
+            } else {
+                DNS_TRY(launch_spmv(lv.S, lv.x.p, lv.r.p, -1.0, 1.0, b,
+                                    DNS_SPMV_VECTOR, stream));
+                hipLaunchKernelGGL(k_mg_jacobi, grid_for_elems(lv.n), kBlock, 0,
+                                   stream, lv.n, lv.omega, lv.dinv.p, lv.r.p,
+                                   lv.x.p, 1);
+            }
+        }
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
+    };
+    for (int l = 0; l + 1 < L; ++l) {
+        MgLevel &lv = mg[l];
+        const double *b = (l == 0) ? in : lv.b.p;
+        DNS_TRY(smooth(lv, b, true));
+        DNS_TRY(launch_spmv(lv.S, lv.x.p, lv.r.p, -1.0, 1.0, b,
+                            DNS_SPMV_VECTOR, stream));
+        DNS_TRY(launch_spmv(lv.PT, lv.r.p, mg[l + 1].b.p, 1.0, 0.0, nullptr,
+                            DNS_SPMV_VECTOR, stream));
+    }
+    {
+        MgLevel &lc = mg[L - 1];
+        const double *b = (L == 1) ? in : lc.b.p;
+        hipLaunchKernelGGL(k_gemv_rows,
+                           std::max(1, std::min((lc.n + 3) / 4, 2048)), kBlock,
+                           0, stream, lc.n, mg_cinv.p, b, lc.x.p, 1.0,
+                           (const DnsCtl *)nullptr);
+        DNS_HIP(hipGetLastError());
+    }
+    for (int l = L - 2; l >= 0; --l) {
+        MgLevel &lv = mg[l];
+        const double *b = (l == 0) ? in : lv.b.p;
+        DNS_TRY(launch_spmv(lv.P, mg[l + 1].x.p, lv.x.p, 1.0, 1.0, lv.x.p,
+                            DNS_SPMV_VECTOR, stream));
+        DNS_TRY(smooth(lv, b, false));
+    }
+    hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
+                       (int64_t)np, -1.0, mg[0].x.p, 0.0, zp);
+    if (xacc)
+        hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
+                           (int64_t)np, 1.0, zp, 1.0, xacc);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
 int dns_saddle::build_jacobi_schur() {
     DNS_TRY(sinv.alloc((size_t)np));
     hipLaunchKernelGGL(k_schur_diag, grid_for_elems(np), kBlock, 0, stream, np,
@@ -574,9 +701,14 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
             rho = rho_new;
         }
     }
-    if (popts.schur != DNS_SCHUR_DENSE && popts.schur != DNS_SCHUR_JACOBI)
+    if (popts.schur != DNS_SCHUR_DENSE && popts.schur != DNS_SCHUR_JACOBI &&
+        popts.schur != DNS_SCHUR_MG)
         return fail(DNS_ERR_BAD_ARGUMENT, "unknown Schur option %d",
                     popts.schur);
+    if (popts.schur == DNS_SCHUR_MG && comm)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "the multigrid Schur block runs on one GPU (this round)");
+    mg_ready = false;
     if (popts.schur == DNS_SCHUR_DENSE &&
         (int64_t)np * np * 8 > (int64_t)64 << 30)
         return fail(DNS_ERR_BAD_ARGUMENT,
@@ -584,7 +716,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     // explicit polynomial matrix: worth it while the apply is launch-latency
     // bound (pattern of F^(k-1): more bytes, far fewer dependent launches)
     fhat_explicit = (popts.fhat == DNS_FHAT_EXPLICIT) ||
-                    (popts.fhat == DNS_FHAT_AUTO && nv <= 200000 &&
+                    (popts.fhat == DNS_FHAT_AUTO && nv <= 1000000 &&
                      popts.cheb_degree >= 2 && popts.cheb_degree <= 12);
     fp32_store = popts.fp32_store != 0;
     have_jg = false;
@@ -606,6 +738,18 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         if (fp32_store) DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
     } else if (popts.schur == DNS_SCHUR_JACOBI) {
         DNS_TRY(build_jacobi_schur());
+    } else if (popts.schur == DNS_SCHUR_MG) {
+        // recurrence form of Fh^-1: the multigrid works on J D^-1 JT
+        HostCsr DJT = JTh;
+        std::vector<double> dv((size_t)nv, 1.0);
+        for (int i = 0; i < nv; ++i) {
+            double d = 0.0;
+            for (int k = Fh.rowptr[i]; k < Fh.rowptr[i + 1]; ++k)
+                if (Fh.colidx[k] == i) d += Fh.vals[k];
+            dv[i] = (d != 0.0) ? 1.0 / d : 1.0;
+        }
+        host_scale_rows(dv, DJT);
+        DNS_TRY(build_mg_schur(host_spgemm(Jh, DJT)));
     } else {
         return fail(DNS_ERR_BAD_ARGUMENT, "unknown Schur option %d",
                     popts.schur);
@@ -759,7 +903,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         // full block factorisation: tau = src_p - (J Fh^-1) src_v feeds the
         // Schur block instead of src_p (unguarded: 3 us when already done)
         const double *tin = nullptr;
-        if (have_jg) {
+        const bool mgs = popts.schur == DNS_SCHUR_MG;
+        if (have_jg && !mgs) {
             const int jt = (fusedgs && j > 0) ? j : 0;
             DNS_LPR_SWITCH(
                 JG.lpr,
@@ -772,7 +917,18 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
             tin = tau.p;
         }
-        if (fusedgs && j > 0) {
+        if (fusedgs && j > 0 && mgs) {
+            hipLaunchKernelGGL(k_arn_head_f<3>, gridA, kBlock, 0, stream, n, nv,
+                               np, j, w.p, partA.p, gridC, V.p, ld, Z.p,
+                               (const void *)nullptr, ctl.p, o->maxiter,
+                               (const double *)nullptr);
+        } else if (!(fusedgs && j > 0) && mgs) {
+            hipLaunchKernelGGL(k_arn_head<3>, gridA, kBlock, 0, stream, n, nv,
+                               np, j, src, spart, snp, V.p, ld,
+                               (const void *)nullptr, zp, ctl.p, o->rtol,
+                               o->atol, bb_part, rr_np, o->maxiter, q0, q1,
+                               (j == 0) ? first : 0, (const double *)nullptr);
+        } else if (fusedgs && j > 0) {
             if (dense && fp32_store)
                 hipLaunchKernelGGL(k_arn_head_f<2>, gridA, kBlock, 0, stream, n,
                                    nv, np, j, w.p, partA.p, gridC, V.p, ld,
@@ -806,6 +962,23 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
                                (j == 0) ? first : 0, tin);
+        if (mgs) {
+            // Schur block = V-cycle on V_j,p (or tau(V_j))
+            const double *sin = V.p + (size_t)j * ld + nv;
+            if (have_jg) {
+                DNS_LPR_SWITCH(
+                    JG.lpr,
+                    hipLaunchKernelGGL(k_tau_guard<L>,
+                                       grid_for_rows(np, JG.lpr), kBlock, 0,
+                                       stream, np, nv, JG.rowptr.p,
+                                       JG.colidx.p, JG.vals.p,
+                                       V.p + (size_t)j * ld, tau.p,
+                                       (const double *)nullptr, 0, 0, ctl.p, 0,
+                                       np));
+                sin = tau.p;
+            }
+            DNS_TRY(schur_mg_apply(sin, zp, nullptr));
+        }
         if (dd && !repl_schur())
             DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, zj, done_ptr(),
@@ -1175,6 +1348,32 @@ void dns_saddle_destroy(dns_saddle *h) {
 int dns_saddle_update_values(dns_saddle *h, const double *f_vals) {
     if (!h || !f_vals) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     return h->update_values(f_vals);
+}
+
+int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
+                            int32_t smooth_steps) {
+    if (!h || nprol < 0 || (nprol > 0 && !prol) || smooth_steps < 1 ||
+        smooth_steps > 8)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    std::vector<HostCsr> ps;
+    int rows = h->np;
+    for (int l = 0; l < nprol; ++l) {
+        DNS_TRY(check_csr(&prol[l], "prolongation"));
+        if (prol[l].nrows != rows || prol[l].ncols < 1 ||
+            prol[l].ncols > rows)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "prolongation %d is %d x %d, expected %d rows and at "
+                        "most as many columns", l, prol[l].nrows,
+                        prol[l].ncols, rows);
+        ps.push_back(host_copy(&prol[l]));
+        rows = prol[l].ncols;
+    }
+    h->mg_prol_h.swap(ps);
+    h->mg_set = true;
+    h->mg_nu = smooth_steps;
+    h->mg_ready = false;
+    if (h->popts.schur == DNS_SCHUR_MG) h->precond_ready = false;
+    return DNS_OK;
 }
 
 int dns_saddle_setup_precond(dns_saddle *h, const dns_precond_opts *opts) {

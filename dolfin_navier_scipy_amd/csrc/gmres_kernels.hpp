@@ -110,6 +110,7 @@ __device__ inline void givens_close(DnsCtl *ctl, int j, double hn,
 // residual r for j == 0, else w of step j-1) with its ||.||^2 partials.
 //   SK 1/2: zp = -Sinv * src_p / ||src||  (Sinv dense fp64 / fp32)
 //   SK 0  : zp = -sdinv .* src_p / ||src||
+//   SK 3  : no Schur block here (multigrid V-cycle launched behind the head)
 template <int SK>
 __global__ void __launch_bounds__(kBlock)
 k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
@@ -155,12 +156,12 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
         } else if (SK == 2) {
             dense_rows_block<float>((const float *)sinv, sp, np, -scale, zp,
                                     nullptr, red4, prow0, prow1);
-        } else {
+        } else if (SK == 0) {
             const double *sd = (const double *)sinv;
             for (int i = prow0 + blockIdx.x * kBlock + threadIdx.x; i < prow1;
                  i += gridDim.x * kBlock)
                 zp[i] = -sd[i] * sp[i] * scale;
-        }
+        }   // SK == 3: the Schur block is a multi-kernel V-cycle behind this
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (j == 0) {
@@ -305,7 +306,9 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
         }
         const double *wp = sp_in ? sp_in : w + nv;
         double *zp = Z + (size_t)j * ld + nv;
-        if (SK == 0) {
+        if (SK == 3) {
+            // multigrid Schur block: applied to V_j,p by the kernels behind
+        } else if (SK == 0) {
             // zp_j = (-sd .* wp - sum h_i zp_i) / hn  (zp_i kept in Z_i)
             const double *sd = (const double *)sinv;
             for (int r = blockIdx.x * kBlock + threadIdx.x; r < np;

@@ -286,6 +286,52 @@ inline HostCsr host_cheb_poly(const HostCsr &DF, const std::vector<double> &dv,
     return G;
 }
 
+// A^T (sorted columns)
+inline HostCsr host_transpose(const HostCsr &A) {
+    HostCsr T;
+    T.nrows = A.ncols;
+    T.ncols = A.nrows;
+    T.rowptr.assign((size_t)A.ncols + 1, 0);
+    for (int c : A.colidx) T.rowptr[(size_t)c + 1]++;
+    for (int i = 0; i < A.ncols; ++i) T.rowptr[i + 1] += T.rowptr[i];
+    T.colidx.resize(A.colidx.size());
+    T.vals.resize(A.vals.size());
+    std::vector<int> pos(T.rowptr.begin(), T.rowptr.end() - 1);
+    for (int i = 0; i < A.nrows; ++i)
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+            const int q = pos[A.colidx[k]]++;
+            T.colidx[q] = i;
+            T.vals[q] = A.vals[k];
+        }
+    return T;
+}
+
+// largest eigenvalue (in modulus) of D^-1 A by power iterations, D = diag(A)
+inline double host_jacobi_lmax(const HostCsr &A, int iters = 20) {
+    const int n = A.nrows;
+    std::vector<double> d((size_t)n, 1.0), x((size_t)n), y((size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+            if (A.colidx[k] == i && A.vals[k] != 0.0) d[i] = 1.0 / A.vals[k];
+    for (int i = 0; i < n; ++i) x[i] = 1.0 + 0.5 * std::sin(0.37 * i + 1.0);
+    double lam = 1.0;
+    for (int it = 0; it < iters; ++it) {
+        double nx = 0.0, ny = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+                s += A.vals[k] * x[A.colidx[k]];
+            y[i] = d[i] * s;
+            nx += x[i] * x[i];
+            ny += y[i] * y[i];
+        }
+        lam = std::sqrt(ny / nx);
+        const double sc = 1.0 / std::sqrt(ny);
+        for (int i = 0; i < n; ++i) x[i] = y[i] * sc;
+    }
+    return lam;
+}
+
 // [A, B] side by side (same number of rows)
 inline HostCsr host_hstack(const HostCsr &A, const HostCsr &B) {
     HostCsr C;

@@ -804,6 +804,18 @@ k_stream_triad(int64_t n2, const dns_double2 *__restrict__ a,
     }
 }
 
+// multigrid smoother pieces: x = omega * dinv .* b   and
+// x += omega * dinv .* t   (t = b - S x from the SpMV kernel in front)
+__global__ void __launch_bounds__(kBlock)
+k_mg_jacobi(int n, double omega, const double *__restrict__ dinv,
+            const double *__restrict__ t, double *__restrict__ x, int accumulate) {
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock) {
+        const double v = omega * dinv[i] * t[i];
+        x[i] = accumulate ? x[i] + v : v;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_to_f32(int64_t n, const double *__restrict__ in, float *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n;

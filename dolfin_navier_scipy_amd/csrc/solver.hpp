@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
+#include <deque>
 #include <functional>
 
 #include "bicgstab_kernels.hpp"
@@ -297,6 +298,20 @@ struct dns_saddle {
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open
+    // multigrid Schur block (DNS_SCHUR_MG): level 0 = the pressure space
+    struct MgLevel {
+        int n = 0;
+        double omega = 0.6;               // Jacobi damping, 4 / (3 lambda_max)
+        dns::CsrDev S, P, PT;             // operator, prolongation from l+1, P^T
+        dns::DevBuf<double> dinv, x, b, r;
+    };
+    std::deque<MgLevel> mg;               // (device buffers do not move)
+    std::vector<dns::HostCsr> mg_prol_h;  // prolongations as handed over
+    dns::DevBuf<double> mg_cinv;          // dense inverse on the coarsest level
+    int mg_nu = 2;
+    bool mg_ready = false, mg_set = false;
+    int build_mg_schur(const dns::HostCsr &S0);
+    int schur_mg_apply(const double *in, double *zp, double *xacc);
     // full block factorisation: J Fh^-1 as one CSR matrix, tau = r_p - JG r_v
     dns::CsrDev JG;
     dns::DevBuf<double> tau;

@@ -3,4 +3,5 @@ from .mesh2d import (Mesh2D, read_dolfin_xml, load_npz_mesh, save_npz_mesh,
                      refine_uniform, rectangle_mesh, channel_cylinder_mesh)
 from .taylor_hood import TaylorHood
 from .problem_setups import (get_sysmats, condense_sysmatsbybcs,
-                             cylinder_mesh, GOLDEN_DIR)
+                             cylinder_mesh, cylinder_mesh_hierarchy,
+                             pressure_prolongations, GOLDEN_DIR)

@@ -16,7 +16,7 @@ from .mesh2d import (load_npz_mesh, refine_uniform, channel_cylinder_mesh,
 from .taylor_hood import TaylorHood
 
 __all__ = ['get_sysmats', 'condense_sysmatsbybcs', 'cylinder_mesh',
-           'GOLDEN_DIR']
+           'cylinder_mesh_hierarchy', 'pressure_prolongations', 'GOLDEN_DIR']
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(
     os.path.abspath(__file__)))), 'tests', 'golden')
@@ -66,6 +66,40 @@ def cylinder_mesh(N=2, refine=0):
     for _ in range(refine):
         mesh, _ = refine_uniform(mesh, snap=snap)
     return mesh
+
+
+def cylinder_mesh_hierarchy(N=2, refine=0):
+    """`[(mesh_0, None), (mesh_1, parents_1), ...]`: the level-`N` mesh and its
+    `refine` red refinements with the parent vertices of every fine vertex
+    (`refine_uniform`) -- what a pressure multigrid needs"""
+    mesh = load_npz_mesh(os.path.join(GOLDEN_DIR,
+                                      'mesh_cylinder_{0}.npz'.format(N)))
+    snap = _snap_to_cylinder()
+    out = [(mesh, None)]
+    for _ in range(refine):
+        mesh, parents = refine_uniform(mesh, snap=snap)
+        out.append((mesh, parents))
+    return out
+
+
+def pressure_prolongations(spaces, parents):
+    """P1 prolongations between the pressure spaces of nested meshes, FINEST
+    FIRST: `P[l]` maps level `l+1` (coarser) to level `l`, in the pressure-dof
+    numbering of the `TaylorHood` spaces (`spaces[0]` the finest; `parents[l]`
+    the parent table of `spaces[l]`'s mesh)"""
+    prols = []
+    for l in range(len(spaces) - 1):
+        fine, coarse = spaces[l], spaces[l + 1]
+        par = parents[l]
+        nvf = fine.mesh.nverts
+        rows = np.repeat(fine.vert_pdof[np.arange(nvf)], 2)
+        cols = coarse.vert_pdof[par].reshape(-1)
+        P = sps.coo_matrix((np.full(2*nvf, 0.5), (rows, cols)),
+                           shape=(fine.pdim, coarse.pdim)).tocsr()
+        P.sum_duplicates()          # coarse vertices: 0.5 + 0.5 = 1
+        P.sort_indices()
+        prols.append(P)
+    return prols
 
 
 def get_sysmats(problem='cylinderwake', N=2, refine=0, Re=None, nu=None,

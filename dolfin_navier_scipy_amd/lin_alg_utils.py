@@ -69,7 +69,7 @@ def _precond_kwargs(NP, krplsprms, NV=0):
         schur = 'dense' if NP <= DEFAULTS['schur_dense_max'] else 'jacobi'
     deg = prm.get('cheb_degree', DEFAULTS['cheb_degree'])
     fact = prm.get('factorization', DEFAULTS['factorization'])
-    if NV > 200000 or not 2 <= deg <= 12:
+    if NV > 1000000 or not 2 <= deg <= 12:
         fact = 'triangular'      # no explicit polynomial matrix there
     return dict(cheb_degree=deg, schur=schur, eig_lo=prm.get('eig_lo', 0.),
                 eig_hi=prm.get('eig_hi', 0.), factorization=fact)
@@ -87,6 +87,10 @@ def _get_system(amat, jmat, jmatT, krplsprms):
     ent = _cache.get(key)
     if ent is None:
         system = SaddleSystem(amat, jmat, JT=jmatT, device=DEFAULTS['device'])
+        prols = (krplsprms or {}).get('prolongations')
+        if prols is not None:       # nested pressure spaces: multigrid Schur
+            system.set_schur_mg(prols)
+            pkw['schur'] = 'mg'
         system.setup_precond(**pkw)
         ent = _Entry(system, diag, pkw)
         _cache[key] = ent

@@ -10,7 +10,7 @@ __all__ = ['SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
            'dense_inverse', 'spmv_bench', 'solve_opts', 'precond_opts']
 
 _METHODS = {'gmres': C.DNS_METHOD_GMRES, 'bicgstab': C.DNS_METHOD_BICGSTAB}
-_SCHUR = {'dense': C.DNS_SCHUR_DENSE, 'jacobi': C.DNS_SCHUR_JACOBI}
+_SCHUR = {'dense': C.DNS_SCHUR_DENSE, 'jacobi': C.DNS_SCHUR_JACOBI, 'mg': 2}
 _VARIANTS = {'vector': C.DNS_SPMV_VECTOR, 'stream': C.DNS_SPMV_STREAM,
              'stream16': 2}
 _FHAT = {'cheb': C.DNS_FHAT_CHEB, 'explicit': C.DNS_FHAT_EXPLICIT,
@@ -87,6 +87,16 @@ class SaddleSystem(object):
         self._comm = comm
         C.check(self.lib.dns_saddle_set_comm(
             self._h, comm._h if comm is not None else None))
+        self.precond_ready = False
+
+    def set_schur_mg(self, prolongations, smooth_steps=2):
+        """nested pressure spaces for `schur='mg'`: `prolongations[l]` maps
+        level `l+1` (coarser) to level `l`, finest first; the coarsest level
+        gets a dense inverse"""
+        views = [C.CsrView(p) for p in prolongations]
+        arr = (C.dns_csr*max(len(views), 1))(*[v.struct for v in views])
+        C.check(self.lib.dns_saddle_set_schur_mg(self._h, len(views), arr,
+                                                 int(smooth_steps)))
         self.precond_ready = False
 
     def update_values(self, fdata):

@@ -86,9 +86,13 @@ def _device_system(fmat, J, prm):
     if schur == 'auto':
         schur = 'dense' if NP <= lau.DEFAULTS['schur_dense_max'] else 'jacobi'
     system = SaddleSystem(fmat, J, device=prm['device'])
+    if prm.get('prolongations') is not None:
+        # nested pressure spaces given: multigrid Schur block (refined meshes)
+        system.set_schur_mg(prm['prolongations'])
+        schur = 'mg'
     # the full block factorisation needs the explicit polynomial matrix
     fact = prm['factorization']
-    if fmat.shape[0] > 200000 or not 2 <= prm['cheb_degree'] <= 12:
+    if fmat.shape[0] > 1000000 or not 2 <= prm['cheb_degree'] <= 12:
         fact = 'triangular'
     system.setup_precond(cheb_degree=prm['cheb_degree'], schur=schur,
                          drop_tol=prm['drop_tol'], factorization=fact)

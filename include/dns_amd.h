@@ -44,6 +44,8 @@ extern "C" {
 
 #define DNS_SCHUR_DENSE      0   /* explicit inverse of J Fh^-1 JT (NP small) */
 #define DNS_SCHUR_JACOBI     1   /* diag(J D^-1 JT)^-1  (always available)   */
+#define DNS_SCHUR_MG         2   /* one multigrid V-cycle on the sparse Schur
+                                    complement (dns_saddle_set_schur_mg)     */
 
 #define DNS_SPMV_VECTOR      0   /* sub-wave per row, shuffle reduction      */
 #define DNS_SPMV_STREAM      1   /* row blocks streamed through LDS          */
@@ -306,6 +308,18 @@ int dns_dense_inverse(int device, int32_t n, double *a_rowmajor);
  * time (HIP events on the launch stream) -- the roofline measurement */
 int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
                    int32_t warmup, double *avg_seconds, double *checksum);
+
+/* Multigrid Schur block for pressure spaces too large for the dense inverse
+ * (refined meshes).  `prol[l]` (CSR, n_l x n_{l+1}, l = 0 .. nprol-1) are the
+ * prolongations of a nested hierarchy of pressure spaces, finest first (n_0 =
+ * NP); the coarsest space gets a dense inverse, so keep n_nprol at a few
+ * thousand.  At `dns_saddle_setup_precond(schur = DNS_SCHUR_MG)` the library
+ * forms the sparse Schur complement S_0 = J Fh^-1 JT (explicit Fh^-1) or
+ * J D^-1 JT (recurrence), the Galerkin operators S_{l+1} = P_l^T S_l P_l and
+ * applies Sh^-1 ~ one V(nu,nu)-cycle with damped Jacobi smoothing.
+ * (Reference counterpart: none -- its direct solver does not need one.) */
+int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
+                            int32_t smooth_steps);
 
 /* ---- linearised convection matrices + Newton/Picard trapezoidal sweeps ------
  * (reference: `get_v_conv_conts` snu:109-133 with `get_convmats` dts:325-376

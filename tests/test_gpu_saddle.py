@@ -337,3 +337,61 @@ def test_lau_surface(small):
         lau.solve_sadpnt_smw(jmat=J, rhsv=rhsv, decouplevp=True,
                              symmetric=True, solve_A=lambda x: x)
     lau.clear_cache()
+
+
+def test_multigrid_schur_block_on_a_refined_mesh(sad):
+    """`schur='mg'` (one V-cycle on the sparse Schur complement, nested
+    pressure spaces of a red-refined mesh, dense inverse on the coarsest):
+    the solve of the once-refined cylinder problem (NV=38 018, NP=4 991)
+    matches the oracle's direct solve, needs only a few more Krylov steps than
+    the dense Schur inverse, and the single-level hierarchy IS the dense one"""
+    from dolfin_navier_scipy_amd.fem import (
+        get_sysmats, cylinder_mesh_hierarchy, pressure_prolongations,
+        TaylorHood)
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, refine=1, Re=100)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    hier = cylinder_mesh_hierarchy(N=2, refine=1)
+    spaces = [TaylorHood(m) for m, _ in hier][::-1]
+    prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
+    assert prols[0].shape == (NP, 1289)
+    F = (M + A/1024.).tocsr()
+    rng = np.random.default_rng(1)
+    rhsv = M @ rng.standard_normal(NV)
+    rhsp = 1e-3*(J @ rng.standard_normal(NV))
+    ref = saddle_oracle.solve_sadpnt_smw(amat=F, jmat=J, rhsv=rhsv,
+                                         rhsp=rhsp).reshape(-1)
+    its = {}
+    for name, schur, fact, fhat, pr in (
+            ('dense', 'dense', 'full', 'explicit', None),
+            ('mg full', 'mg', 'full', 'explicit', prols),
+            ('mg tri', 'mg', 'triangular', 'explicit', prols),
+            ('mg cheb', 'mg', 'triangular', 'cheb', prols),
+            ('mg 1 level', 'mg', 'full', 'explicit', [])):
+        system = sad.SaddleSystem(F, J)
+        if pr is not None:
+            system.set_schur_mg(pr)
+        system.setup_precond(cheb_degree=6, schur=schur, fhat=fhat,
+                             drop_tol=1e-3, factorization=fact)
+        for reorth in (1, 2):
+            x = system.solve(rhsv, rhsp, rtol=1e-11, maxiter=400,
+                             reorth=reorth, use_graph=True)
+            st = system.last_stats
+            assert st['status'] == 0 and st['true_relres'] <= 2e-11, (name, st)
+            assert np.linalg.norm(x[:NV] - ref[:NV]) <= \
+                1e-9*np.linalg.norm(ref[:NV]), name
+            assert np.linalg.norm(x[NV:] - ref[NV:]) <= \
+                1e-6*np.linalg.norm(ref[NV:]), name
+        its[name] = st['iters']
+        system.close()
+    assert abs(its['mg 1 level'] - its['dense']) <= 1    # (fp64 vs fp32 inverse)
+    assert its['mg full'] <= 3*its['dense'] + 2
+    assert its['mg tri'] <= 25 and its['mg cheb'] <= 40
+    # the multigrid needs its hierarchy
+    from dolfin_navier_scipy_amd import _capi
+    system = sad.SaddleSystem(F, J)
+    with pytest.raises(_capi.DnsError):
+        system.setup_precond(cheb_degree=4, schur='mg')
+    with pytest.raises(_capi.DnsError):
+        system.set_schur_mg([prols[0][:-1, :]])
+    system.close()
