@@ -387,7 +387,7 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
         rvec_schur = tau.p - nv;
     }
     if (popts.schur == DNS_SCHUR_MG) {
-        DNS_TRY(schur_mg_apply(rvec_schur + nv, zp, xp));
+        DNS_TRY(schur_mg_apply(rvec_schur + nv, zp, xp, guard));
         return apply_fhat_part(rvec, zp, zout, guard, xacc);
     }
     if (popts.schur == DNS_SCHUR_DENSE) {
@@ -562,6 +562,7 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
         DNS_TRY(lv.x.alloc((size_t)lv.n));
         DNS_TRY(lv.b.alloc((size_t)lv.n));
         DNS_TRY(lv.r.alloc((size_t)lv.n));
+        DNS_TRY(lv.x2.alloc((size_t)lv.n));
         if (l == L - 1) {
             // coarsest: dense inverse
             std::vector<double> sd((size_t)lv.n * lv.n, 0.0);
@@ -604,56 +605,67 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
     return DNS_OK;
 }
 
-// zp = -MG(in): one V(nu, nu) cycle with damped Jacobi; xacc: x_p += zp
-int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc) {
+// zp = -MG(in): one V(nu, nu) cycle with damped Jacobi; xacc: x_p += zp;
+// guard: device flag (solve finished) that turns every launch into a no-op
+int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
+                               const int *guard) {
     const int L = (int)mg.size();
-    auto smooth = [&](MgLevel &lv, const double *b, bool from_zero) -> int {
+    // sweeps ping-pong between lv.x and lv.x2; returns where the result is
+    auto smooth = [&](MgLevel &lv, const double *b, bool from_zero,
+                      double *cur) -> double * {
         for (int sweep = 0; sweep < mg_nu; ++sweep) {
-            if (from_zero && sweep == 0) {
-                hipLaunchKernelGGL(k_mg_jacobi, grid_for_elems(lv.n), kBlock, 0,
-                                   stream, lv.n, lv.omega, lv.dinv.p, b, lv.x.p,
-                                   0);
-            } else {
-                DNS_TRY(launch_spmv(lv.S, lv.x.p, lv.r.p, -1.0, 1.0, b,
-                                    DNS_SPMV_VECTOR, stream));
-                hipLaunchKernelGGL(k_mg_jacobi, grid_for_elems(lv.n), kBlock, 0,
-                                   stream, lv.n, lv.omega, lv.dinv.p, lv.r.p,
-                                   lv.x.p, 1);
-            }
+            double *nxt = (cur == lv.x.p) ? lv.x2.p : lv.x.p;
+            const double *xin = (from_zero && sweep == 0) ? nullptr : cur;
+            DNS_LPR_SWITCH(
+                lv.S.lpr,
+                hipLaunchKernelGGL(k_mg_sweep<L>, grid_for_rows(lv.n, lv.S.lpr),
+                                   kBlock, 0, stream, lv.n, lv.S.rowptr.p,
+                                   lv.S.colidx.p, lv.S.vals.p, lv.dinv.p,
+                                   lv.omega, b, xin, nxt, guard));
+            cur = nxt;
         }
-        DNS_HIP(hipGetLastError());
-        return DNS_OK;
+        return cur;
     };
+    std::vector<double *> xat((size_t)L, nullptr);
     for (int l = 0; l + 1 < L; ++l) {
         MgLevel &lv = mg[l];
         const double *b = (l == 0) ? in : lv.b.p;
-        DNS_TRY(smooth(lv, b, true));
-        DNS_TRY(launch_spmv(lv.S, lv.x.p, lv.r.p, -1.0, 1.0, b,
-                            DNS_SPMV_VECTOR, stream));
+        xat[l] = smooth(lv, b, true, lv.x2.p);
+        DNS_TRY(launch_spmv(lv.S, xat[l], lv.r.p, -1.0, 1.0, b,
+                            DNS_SPMV_VECTOR, stream, guard));
         DNS_TRY(launch_spmv(lv.PT, lv.r.p, mg[l + 1].b.p, 1.0, 0.0, nullptr,
-                            DNS_SPMV_VECTOR, stream));
+                            DNS_SPMV_VECTOR, stream, guard));
     }
     {
         MgLevel &lc = mg[L - 1];
         const double *b = (L == 1) ? in : lc.b.p;
+        // (the dense kernel's own guard is the solve's control block)
         hipLaunchKernelGGL(k_gemv_rows,
                            std::max(1, std::min((lc.n + 3) / 4, 2048)), kBlock,
                            0, stream, lc.n, mg_cinv.p, b, lc.x.p, 1.0,
-                           (const DnsCtl *)nullptr);
-        DNS_HIP(hipGetLastError());
+                           (guard && guard == done_ptr())
+                               ? (const DnsCtl *)ctl.p
+                               : (const DnsCtl *)nullptr);
+        xat[L - 1] = lc.x.p;
     }
     for (int l = L - 2; l >= 0; --l) {
         MgLevel &lv = mg[l];
         const double *b = (l == 0) ? in : lv.b.p;
-        DNS_TRY(launch_spmv(lv.P, mg[l + 1].x.p, lv.x.p, 1.0, 1.0, lv.x.p,
-                            DNS_SPMV_VECTOR, stream));
-        DNS_TRY(smooth(lv, b, false));
+        DNS_TRY(launch_spmv(lv.P, xat[l + 1], xat[l], 1.0, 1.0, xat[l],
+                            DNS_SPMV_VECTOR, stream, guard));
+        xat[l] = smooth(lv, b, false, xat[l]);
     }
-    hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
-                       (int64_t)np, -1.0, mg[0].x.p, 0.0, zp);
-    if (xacc)
+    if (!guard) {
         hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
-                           (int64_t)np, 1.0, zp, 1.0, xacc);
+                           (int64_t)np, -1.0, xat[0], 0.0, zp);
+        if (xacc)
+            hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
+                               (int64_t)np, 1.0, zp, 1.0, xacc);
+    } else {
+        // guarded form: zp = -x through the (guarded) Jacobi kernel
+        hipLaunchKernelGGL(k_mg_jacobi_guard, grid_for_elems(np), kBlock, 0,
+                           stream, np, xat[0], zp, xacc, guard);
+    }
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }
@@ -973,11 +985,11 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                        stream, np, nv, JG.rowptr.p,
                                        JG.colidx.p, JG.vals.p,
                                        V.p + (size_t)j * ld, tau.p,
-                                       (const double *)nullptr, 0, 0, ctl.p, 0,
-                                       np));
+                                       (const double *)nullptr, 0, -1, ctl.p,
+                                       0, np));
                 sin = tau.p;
             }
-            DNS_TRY(schur_mg_apply(sin, zp, nullptr));
+            DNS_TRY(schur_mg_apply(sin, zp, nullptr, done_ptr()));
         }
         if (dd && !repl_schur())
             DNS_TRY(comm->allgatherv(zp, st_p, stream));

@@ -372,8 +372,9 @@ k_tau_guard(int np, int nv, const int *__restrict__ rowptr,
             const double *__restrict__ hpart, int hnparts, int j, DnsCtl *ctl,
             int row0, int row1) {
     // rows [row0, row1): all of them on one GPU, this rank's Schur rows in
-    // the row-partitioned solve
+    // the row-partitioned solve.  j < 0: no verdict, but skip a finished solve
     (void)np;
+    if (j < 0 && ctl->done) return;
     if (j > 0) {
         if (ctl->done) return;
         __shared__ double h[kMaxRestart + 2];

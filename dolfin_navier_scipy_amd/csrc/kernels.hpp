@@ -174,7 +174,9 @@ __global__ void __launch_bounds__(kBlock)
 k_spmv_vec(int nrows, const int *__restrict__ rowptr,
            const int *__restrict__ colidx, const double *__restrict__ vals,
            const double *__restrict__ x, double *__restrict__ y, double alpha,
-           double beta, const double *__restrict__ b) {
+           double beta, const double *__restrict__ b,
+           const int *__restrict__ guard = nullptr) {
+    if (guard && *guard) return;       // (e.g. ctl->done: solve has finished)
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
@@ -813,6 +815,40 @@ k_mg_jacobi(int n, double omega, const double *__restrict__ dinv,
          i += gridDim.x * kBlock) {
         const double v = omega * dinv[i] * t[i];
         x[i] = accumulate ? x[i] + v : v;
+    }
+}
+
+// zp = -x (and xacc += zp) unless the guard is raised
+__global__ void __launch_bounds__(kBlock)
+k_mg_jacobi_guard(int n, const double *__restrict__ x, double *__restrict__ zp,
+                  double *__restrict__ xacc, const int *__restrict__ guard) {
+    if (*guard) return;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock) {
+        const double v = -x[i];
+        zp[i] = v;
+        if (xacc) xacc[i] += v;
+    }
+}
+
+// one damped-Jacobi sweep  xout = xin + omega * dinv .* (b - S xin)
+// (xin == nullptr: from zero, xout = omega * dinv .* b)
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_mg_sweep(int n, const int *__restrict__ rowptr,
+           const int *__restrict__ colidx, const double *__restrict__ vals,
+           const double *__restrict__ dinv, double omega,
+           const double *__restrict__ b, const double *__restrict__ xin,
+           double *__restrict__ xout, const int *__restrict__ guard) {
+    if (guard && *guard) return;
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    for (int row = sub; row < n; row += nsub) {
+        double s = 0.0;
+        if (xin) s = csr_row_dot<LPR>(rowptr, colidx, vals, xin, row, sublane);
+        if (sublane == 0)
+            xout[row] = (xin ? xin[row] : 0.0) + omega * dinv[row] * (b[row] - s);
     }
 }
 

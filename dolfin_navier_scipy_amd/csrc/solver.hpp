@@ -153,7 +153,8 @@ inline void launch_stream_g(const CsrDev &A, int t, const double *x, double *y,
 // y = alpha*A*x + beta*b on `s` (device pointers)
 inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                        double alpha, double beta, const double *b, int variant,
-                       hipStream_t s) {
+                       hipStream_t s, const int *guard = nullptr) {
+    // guard (vector kernel only): device flag, non-zero = skip the launch's work
     if (A.nrows == 0) return DNS_OK;
     if ((variant == 3 || variant == 4) && A.c16.p) {
         // diagnostic variants of the 16-bit kernel (see k_spmv_stream16)
@@ -213,7 +214,8 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
         DNS_LPR_SWITCH(A.lpr,
                        hipLaunchKernelGGL(k_spmv_vec<L>, grid, kBlock, 0, s,
                                           A.nrows, A.rowptr.p, A.colidx.p,
-                                          A.vals.p, x, y, alpha, beta, b));
+                                          A.vals.p, x, y, alpha, beta, b,
+                                          guard));
     }
     DNS_HIP(hipGetLastError());
     return DNS_OK;
@@ -303,7 +305,7 @@ struct dns_saddle {
         int n = 0;
         double omega = 0.6;               // Jacobi damping, 4 / (3 lambda_max)
         dns::CsrDev S, P, PT;             // operator, prolongation from l+1, P^T
-        dns::DevBuf<double> dinv, x, b, r;
+        dns::DevBuf<double> dinv, x, b, r, x2;
     };
     std::deque<MgLevel> mg;               // (device buffers do not move)
     std::vector<dns::HostCsr> mg_prol_h;  // prolongations as handed over
@@ -311,7 +313,8 @@ struct dns_saddle {
     int mg_nu = 2;
     bool mg_ready = false, mg_set = false;
     int build_mg_schur(const dns::HostCsr &S0);
-    int schur_mg_apply(const double *in, double *zp, double *xacc);
+    int schur_mg_apply(const double *in, double *zp, double *xacc,
+                       const int *guard);
     // full block factorisation: J Fh^-1 as one CSR matrix, tau = r_p - JG r_v
     dns::CsrDev JG;
     dns::DevBuf<double> tau;

@@ -1,0 +1,104 @@
+"""CNAB time stepping on uniformly refined cylinder meshes (multigrid Schur
+block): device steps/s against the prefactored SuperLU step of the reference's
+algorithm on the host.
+
+    python scripts/refined_bench.py [refine] [nts] [nsteps] [with_cpu]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sps
+import scipy.sparse.linalg as spsla
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
+from dolfin_navier_scipy_amd import saddle, convection, _capi  # noqa: E402
+from dolfin_navier_scipy_amd.fem import (  # noqa: E402
+    get_sysmats, cylinder_mesh_hierarchy, pressure_prolongations, TaylorHood)
+
+
+def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True):
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, refine=refine,
+                                 Re=Re)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    th, inv = femp['V'], femp['invinds']
+    dt = 1./nts
+    hier = cylinder_mesh_hierarchy(N=2, refine=refine)
+    spaces = [TaylorHood(m) for m, _ in hier][::-1]
+    prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
+    F = (M + .5*dt*A).tocsr()
+    R1 = (M - .5*dt*A).tocsr()
+    t0 = time.perf_counter()
+    system = saddle.SaddleSystem(F, J)
+    system.set_schur_mg(prols)
+    system.setup_precond(cheb_degree=6, schur='mg', drop_tol=1e-3,
+                         factorization='full')
+    t_setup = time.perf_counter() - t0
+    # initial value: a few steps of startup from rest with the inflow data
+    cv = convection.ConvectionP2.from_taylor_hood(th, inv, femp['dbcinds'],
+                                                  femp['dbcvals'])
+    v0 = np.zeros((NV, 1))
+    stp = saddle.ImexStepper(system, R1)
+    nfc = cv.apply(v0, scale=-1.0)
+    stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+    stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    stp.set_convection(cv, scale=-1.0)
+    cf = saddle.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                   pscale=-1./dt, extrapolate=4)
+    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=graph,
+                             reorth=2)
+    stp.run(40, cf, opts)
+    vstart = stp.get_state()[0]
+    _capi.device_synchronize(0)
+    t0 = time.perf_counter()
+    ds, its, last = stp.run(nsteps, cf, opts)
+    _capi.device_synchronize(0)
+    wall = time.perf_counter() - t0
+    v_gpu, p_gpu = stp.get_state()
+    out = dict(refine=refine, NV=int(NV), NP=int(NP), n=int(NV + NP), dt=dt,
+               steps=nsteps, gpu_steps_per_s=nsteps/wall,
+               gpu_ms_per_step=1e3*wall/nsteps,
+               krylov_iters_per_step=its/float(nsteps),
+               true_relres_last=last['true_relres'], setup_s=t_setup)
+    stp.close()
+    system.close()
+    if with_cpu:
+        K = sps.bmat([[F, J.T], [J, None]], format='csc')
+        t0 = time.perf_counter()
+        lu = spsla.splu(K)
+        out['cpu_factor_s'] = time.perf_counter() - t0
+        out['cpu_lu_nnz'] = int(lu.L.nnz + lu.U.nnz)
+        # same steps on the host (few of them), convection via the device op
+        v = vstart.copy()
+        nc = cv.apply(v, scale=-1.0)
+        no = nc.copy()
+        ncpu = min(nsteps, 10)
+        tcpu = 0.
+        for k in range(ncpu):
+            t0 = time.perf_counter()
+            rhs = R1 @ v + dt*(1.5*nc - .5*no) + dt*rhsd['fv']
+            x = lu.solve(np.vstack([rhs, rhsd['fp']])[:, 0])
+            tcpu += time.perf_counter() - t0
+            v = x[:NV].reshape((-1, 1))
+            no = nc
+            nc = cv.apply(v, scale=-1.0)
+        out['cpu_steps_per_s'] = ncpu/tcpu
+        out['cpu_ms_per_step'] = 1e3*tcpu/ncpu
+        out['speedup'] = out['gpu_steps_per_s']/out['cpu_steps_per_s']
+        if ncpu == nsteps:
+            out['parity_v'] = float(np.linalg.norm(v_gpu - v)
+                                    / np.linalg.norm(v))
+    cv.close()
+    return out
+
+
+if __name__ == '__main__':
+    r = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    nts = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    cpu = not (len(sys.argv) > 4 and sys.argv[4] == '0')
+    graph = not (len(sys.argv) > 5 and sys.argv[5] == 'eager')
+    print(json.dumps(run(r, nts, n, cpu, graph=graph)))
