@@ -33,7 +33,7 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True):
     R1 = (M - .5*dt*A).tocsr()
     t0 = time.perf_counter()
     system = saddle.SaddleSystem(F, J)
-    system.set_schur_mg(prols)
+    system.set_schur_mg(prols, smooth_steps=int(os.environ.get('MG_NU', '2')))
     system.setup_precond(cheb_degree=6, schur='mg', drop_tol=1e-3,
                          factorization='full')
     t_setup = time.perf_counter() - t0
