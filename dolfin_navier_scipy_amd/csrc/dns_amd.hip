@@ -717,9 +717,6 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         popts.schur != DNS_SCHUR_MG)
         return fail(DNS_ERR_BAD_ARGUMENT, "unknown Schur option %d",
                     popts.schur);
-    if (popts.schur == DNS_SCHUR_MG && comm)
-        return fail(DNS_ERR_BAD_ARGUMENT,
-                    "the multigrid Schur block runs on one GPU (this round)");
     mg_ready = false;
     if (popts.schur == DNS_SCHUR_DENSE &&
         (int64_t)np * np * 8 > (int64_t)64 << 30)

@@ -291,8 +291,11 @@ struct dns_saddle {
     int v0() const { return dist() ? st_v[comm->rank] : 0; }
     int v1() const { return dist() ? st_v[comm->rank + 1] : nv; }
     // the Schur block (tau, Sh^-1 rows) of a small pressure space is computed
-    // in full by every rank: 10 us of redundant work instead of two collectives
-    bool repl_schur() const { return dist() && np <= 8192; }
+    // in full by every rank: 10 us of redundant work instead of two
+    // collectives; so is the multigrid V-cycle (not partitioned this round)
+    bool repl_schur() const {
+        return dist() && (np <= 8192 || popts.schur == DNS_SCHUR_MG);
+    }
     int p0() const { return (dist() && !repl_schur()) ? st_p[comm->rank] : 0; }
     int p1() const {
         return (dist() && !repl_schur()) ? st_p[comm->rank + 1] : np;

@@ -316,7 +316,8 @@ int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
  * thousand.  At `dns_saddle_setup_precond(schur = DNS_SCHUR_MG)` the library
  * forms the sparse Schur complement S_0 = J Fh^-1 JT (explicit Fh^-1) or
  * J D^-1 JT (recurrence), the Galerkin operators S_{l+1} = P_l^T S_l P_l and
- * applies Sh^-1 ~ one V(nu,nu)-cycle with damped Jacobi smoothing.
+ * applies Sh^-1 ~ one V(nu,nu)-cycle with damped Jacobi smoothing (in the
+ * row-partitioned solve every rank runs the whole cycle).
  * (Reference counterpart: none -- its direct solver does not need one.) */
 int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
                             int32_t smooth_steps);

@@ -43,15 +43,41 @@ def _problem():
                 v0=rng.standard_normal(NV), nfc=M @ rng.standard_normal(NV))
 
 
+def _mg_problem():
+    """the toy mesh refined once, with the prolongation of its pressure space"""
+    from dolfin_navier_scipy_amd.fem import (
+        get_sysmats, channel_cylinder_mesh, refine_uniform, TaylorHood,
+        pressure_prolongations)
+    coarse = channel_cylinder_mesh()
+    fine, parents = refine_uniform(coarse)
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N='toy', Re=40.,
+                                 mesh=fine)
+    prols = pressure_prolongations([femp['V'], TaylorHood(coarse)],
+                                   [parents, None])
+    M, A, J = sm['M'], sm['A'], sm['J']
+    dt = 5e-3
+    rng = np.random.default_rng(11)
+    NP, NV = J.shape
+    return dict(M=M, A=A, J=J, F=(M + .5*dt*A).tocsr(),
+                R1=(M - .5*dt*A).tocsr(), rhsv=M @ rng.standard_normal(NV),
+                rhsp=1e-3*(J @ rng.standard_normal(NV)), dt=dt,
+                v0=rng.standard_normal(NV), nfc=M @ rng.standard_normal(NV),
+                prols=prols)
+
+
 def _solve_and_step(sad, comm, fhat, reorth, fact='triangular'):
-    pr = _problem()
+    mgs = fhat == 'mg'
+    pr = _mg_problem() if mgs else _problem()
     system = sad.SaddleSystem(pr['F'], pr['J'])
     if comm is not None:
         system.set_comm(comm)
     if fhat == 'full':          # full block factorisation (explicit Fh^-1)
         fhat, fact = 'explicit', 'full'
-    system.setup_precond(cheb_degree=4, schur='dense', fhat=fhat,
-                         factorization=fact)
+    if mgs:                     # multigrid Schur block + full factorisation
+        system.set_schur_mg(pr['prols'])
+        fhat, fact = 'explicit', 'full'
+    system.setup_precond(cheb_degree=4, schur='mg' if mgs else 'dense',
+                         fhat=fhat, factorization=fact)
     x = system.solve(pr['rhsv'], pr['rhsp'], rtol=1e-12, reorth=reorth)
     stats = dict(system.last_stats)
     # a few device-resident CNAB steps through the same communicator
@@ -100,7 +126,8 @@ def _worker(rank, world, port, outdir):
     from dolfin_navier_scipy_amd import saddle, comm as dcomm
     cm = dcomm.Comm.gloo(0)
     out = {}
-    for fhat, reorth in (('explicit', False), ('cheb', True), ('full', False)):
+    for fhat, reorth in (('explicit', False), ('cheb', True), ('full', False),
+                         ('mg', False)):
         x, st, v, p = _solve_and_step(saddle, cm, fhat, reorth)
         out[fhat] = (x, v, p, st['iters'], st['true_relres'])
     np.savez(os.path.join(outdir, 'rank{0}.npz'.format(rank)),
@@ -144,6 +171,13 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
         assert np.linalg.norm(r0[fhat + '_1'] - vs) <= 1e-9*np.linalg.norm(vs)
         assert np.linalg.norm(r0[fhat + '_2'] - ps) <= 1e-7*np.linalg.norm(ps)
     assert abs(int(r0['explicit_3']) - sts['iters']) <= 1
+    # multigrid Schur block (replicated per rank) on the refined toy mesh
+    xm, stm, vm, pm = _solve_and_step(saddle, None, 'mg', False)
+    assert np.array_equal(r0['mg_0'], r1['mg_0'])
+    assert float(r0['mg_4']) <= 5e-12
+    assert np.linalg.norm(r0['mg_0'] - xm) <= 1e-9*np.linalg.norm(xm)
+    assert np.linalg.norm(r0['mg_1'] - vm) <= 1e-9*np.linalg.norm(vm)
+    assert abs(int(r0['mg_3']) - stm['iters']) <= 1
     # the full block factorisation is partitioned too (one more all-gather
     # per apply) and needs the same few steps as on one GPU
     assert abs(int(r0['full_3']) - stf['iters']) <= 1
