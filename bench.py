@@ -245,6 +245,9 @@ def main():
                     help='skip the secondary Newton/Picard sweep figures')
     ap.add_argument('--replicas', action='store_true',
                     help='N>1: skip the secondary row-partitioned leg')
+    ap.add_argument('--refine', type=int, default=0,
+                    help='(partitioned-only runs) red refinements of the mesh; '
+                    'uses the multigrid Schur block')
     ap.add_argument('--partitioned-only', action='store_true',
                     help='(internal) run only the row-partitioned leg and '
                     'print its figures')
@@ -281,15 +284,28 @@ def main():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
 
     dt = 1./args.nts
-    femp, sm, rhsd = build_problem(N=args.level, Re=args.Re)
+    femp, sm, rhsd = build_problem(N=args.level, Re=args.Re,
+                                   refine=args.refine)
     M, A, J = sm['M'], sm['A'], sm['J']
+    prols = None
+    if args.refine > 0:
+        # refined mesh (partitioned-only child runs): the pressure space is
+        # too large for the dense Schur inverse -> multigrid Schur block
+        from dolfin_navier_scipy_amd.fem import (
+            cylinder_mesh_hierarchy, pressure_prolongations, TaylorHood)
+        hier = cylinder_mesh_hierarchy(N=args.level, refine=args.refine)
+        spaces = [TaylorHood(m) for m, _ in hier][::-1]
+        prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
     NP, NV = J.shape
     th, inv = femp['V'], femp['invinds']
 
     def factory(F, Jm):
         return saddle.SaddleSystem(F, Jm, device=device)
 
-    v0, pt0, st0 = initial_state(sm, rhsd, factory)
+    if args.refine > 0:
+        v0, pt0, st0 = np.zeros((NV, 1)), None, None     # start from rest
+    else:
+        v0, pt0, st0 = initial_state(sm, rhsd, factory)
     vfull = np.zeros((th.vdim, 1))
     vfull[inv] = v0
     vfull[femp['dbcinds'], 0] = femp['dbcvals']
@@ -303,9 +319,13 @@ def main():
     if world > 1:
         mode = ('ensemble: {0} independent simulations, one per GPU, no '
                 'data-path collective'.format(world))
-    system.setup_precond(cheb_degree=args.cheb, schur='dense', fhat=args.fhat,
-                         fp32_store=bool(args.fp32), drop_tol=args.drop,
-                         factorization=args.fact)
+    schur_kind = 'dense'
+    if prols is not None:
+        system.set_schur_mg(prols)
+        schur_kind = 'mg'
+    system.setup_precond(cheb_degree=args.cheb, schur=schur_kind,
+                         fhat=args.fhat, fp32_store=bool(args.fp32),
+                         drop_tol=args.drop, factorization=args.fact)
     _capi.device_synchronize(device)
     t_setup = time.perf_counter() - t_setup
     from dolfin_navier_scipy_amd import convection
@@ -370,7 +390,7 @@ def main():
                     comm_obj = dcomm.Comm.rccl(device, 1, 0,
                                                dcomm.rccl_unique_id())
             system.set_comm(comm_obj)
-            system.setup_precond(cheb_degree=args.cheb, schur='dense',
+            system.setup_precond(cheb_degree=args.cheb, schur=schur_kind,
                                  fhat=args.fhat, fp32_store=bool(args.fp32),
                                  drop_tol=args.drop, factorization=args.fact)
             psteps = min(args.steps, 200)
@@ -380,7 +400,8 @@ def main():
                 steps_per_s=psteps/pwall, steps=psteps, scaling='strong',
                 krylov_iters_per_step=piters/float(psteps),
                 true_relres_last=plast['true_relres'],
-                collectives=comm_obj.stats(),
+                collectives=comm_obj.stats(), unknowns=int(NV + NP),
+                dt=dt,
                 what='one simulation, rows of every operator apply '
                      'partitioned over {0} rank(s); RCCL all-gather-v + '
                      'all-reduce per Arnoldi step'.format(world))
@@ -413,20 +434,23 @@ def main():
     # a time limit: a collective that never completes must not take the
     # headline measurement with it.
     partitioned = None
-    if args.force_dist and world == 1:
-        partitioned = partitioned_leg()
-    elif world > 1 and not args.replicas:
+    partitioned_refined = None
+
+    def run_children(port_offset, steps, warmup, nts, refine):
+        """the row-partitioned leg in one child process per rank"""
         import subprocess
         env = dict(os.environ)
         env['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500'))
-                                 + 17)
+                                 + port_offset)
         cmd = [sys.executable, os.path.abspath(__file__), '--partitioned-only',
-               '--gpus', str(world), '--steps', str(args.steps), '--warmup',
-               str(args.warmup), '--level', str(args.level), '--Re',
-               str(args.Re), '--nts', str(args.nts), '--cheb', str(args.cheb),
+               '--gpus', str(world), '--steps', str(steps), '--warmup',
+               str(warmup), '--level', str(args.level), '--Re',
+               str(args.Re), '--nts', str(nts), '--cheb', str(args.cheb),
                '--rtol', str(args.rtol), '--extrap', str(args.extrap),
                '--fp32', str(args.fp32), '--drop', str(args.drop),
-               '--fhat', args.fhat, '--fact', args.fact]
+               '--fhat', args.fhat, '--fact', args.fact, '--refine',
+               str(refine)]
+        res = None
         barrier()
         try:
             child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
@@ -437,17 +461,26 @@ def main():
                 lines = [ln for ln in cout.decode().splitlines()
                          if ln.startswith('{')]
                 if rank == 0:
-                    partitioned = (json.loads(lines[-1]) if lines else
-                                   dict(error='child exited with code {0} and '
-                                        'no result'.format(child.returncode)))
+                    res = (json.loads(lines[-1]) if lines else
+                           dict(error='child exited with code {0} and no '
+                                'result'.format(child.returncode)))
             except subprocess.TimeoutExpired:
                 os.killpg(child.pid, 9)
                 child.wait()
-                partitioned = dict(error='no result within {0} s (killed)'
-                                   .format(args.partitioned_timeout))
+                res = dict(error='no result within {0} s (killed)'
+                           .format(args.partitioned_timeout))
         except Exception as exc:
-            partitioned = dict(error=str(exc))
+            res = dict(error=str(exc))
         barrier()
+        return res
+
+    if args.force_dist and world == 1:
+        partitioned = partitioned_leg()
+    elif world > 1 and not args.replicas:
+        partitioned = run_children(17, args.steps, args.warmup, args.nts, 0)
+        # the same on the mesh refined twice (n = 173k, multigrid Schur
+        # block, dt/4): the size at which partitioning starts to have a chance
+        partitioned_refined = run_children(29, 100, 10, 4*args.nts, 2)
 
     out = None
     if rank == 0:
@@ -520,6 +553,7 @@ def main():
                         .format(args.level, args.Re, args.nts, NV, NP),
                         parallelism=mode, collectives=None,
                         row_partitioned=partitioned,
+                        row_partitioned_refined=partitioned_refined,
                         method=args.method, cheb_degree=args.cheb,
                         factorization=args.fact, drop_tol=args.drop,
                         schur='dense', rtol=args.rtol,
