@@ -251,7 +251,7 @@ def main():
     ap.add_argument('--partitioned-only', action='store_true',
                     help='(internal) run only the row-partitioned leg and '
                     'print its figures')
-    ap.add_argument('--partitioned-timeout', type=float, default=150.,
+    ap.add_argument('--partitioned-timeout', type=float, default=100.,
                     help='time limit [s] of the row-partitioned child run')
     ap.add_argument('--force-dist', action='store_true',
                     help='attach an RCCL communicator even with one rank '
