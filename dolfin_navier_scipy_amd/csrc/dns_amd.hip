@@ -1001,12 +1001,19 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                    gridC, ctl.p, n0, n1, fusedgs ? 1 : 0));
             if (fusedgs) continue;       // no Gram-Schmidt kernel
         } else {
-            DNS_LPR_SWITCH(
-                K.lpr,
-                hipLaunchKernelGGL(k_spmv_guard<L>,
-                                   grid_for_rows(n1 - n0, K.lpr), kBlock, 0,
-                                   stream, n, K.rowptr.p, K.colidx.p, K.vals.p,
-                                   zj, w.p, ctl.p, n0, n1));
+            if (!dd && K.c16.p) {
+                // bandwidth regime on one GPU: the LDS-streaming kernel with
+                // 16-bit column offsets (the roofline kernel of bench.py)
+                DNS_TRY(launch_spmv(K, zj, w.p, 1.0, 0.0, nullptr,
+                                    DNS_SPMV_STREAM16, stream, done_ptr()));
+            } else {
+                DNS_LPR_SWITCH(
+                    K.lpr,
+                    hipLaunchKernelGGL(k_spmv_guard<L>,
+                                       grid_for_rows(n1 - n0, K.lpr), kBlock,
+                                       0, stream, n, K.rowptr.p, K.colidx.p,
+                                       K.vals.p, zj, w.p, ctl.p, n0, n1));
+            }
             if (dd) DNS_TRY(comm->allgatherv(w.p, st_n, stream));
             // full-vector dots (every rank alike once w is gathered)
             hipLaunchKernelGGL(k_multidot, gridC, kBlock, 0, stream, n, V.p,

@@ -295,7 +295,9 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
                 const int *__restrict__ c16base,
                 const double *__restrict__ vals, const double *__restrict__ x,
                 double *__restrict__ y, double alpha, double beta,
-                const double *__restrict__ b) {
+                const double *__restrict__ b,
+                const int *__restrict__ guard = nullptr) {
+    if (guard && *guard) return;     // (ctl->done inside a Krylov cycle)
     constexpr int TILE = kStreamNnz;
     __shared__ double prod[TILE];
     __shared__ double red[4];

@@ -154,7 +154,7 @@ inline void launch_stream_g(const CsrDev &A, int t, const double *x, double *y,
 inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                        double alpha, double beta, const double *b, int variant,
                        hipStream_t s, const int *guard = nullptr) {
-    // guard (vector kernel only): device flag, non-zero = skip the launch's work
+    // guard (vector and stream16 kernels): device flag, non-zero = skip the work
     if (A.nrows == 0) return DNS_OK;
     if ((variant == 3 || variant == 4) && A.c16.p) {
         // diagnostic variants of the 16-bit kernel (see k_spmv_stream16)
@@ -180,19 +180,19 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
         if (avg <= 6)
             hipLaunchKernelGGL((k_spmv_stream16<1>), grid, kBlock, 0, s, nb, rbp,
                                A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                               A.vals.p, x, y, alpha, beta, b);
+                               A.vals.p, x, y, alpha, beta, b, guard);
         else if (avg <= 12)
             hipLaunchKernelGGL((k_spmv_stream16<2>), grid, kBlock, 0, s, nb, rbp,
                                A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                               A.vals.p, x, y, alpha, beta, b);
+                               A.vals.p, x, y, alpha, beta, b, guard);
         else if (avg <= 48)
             hipLaunchKernelGGL((k_spmv_stream16<4>), grid, kBlock, 0, s, nb, rbp,
                                A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                               A.vals.p, x, y, alpha, beta, b);
+                               A.vals.p, x, y, alpha, beta, b, guard);
         else
             hipLaunchKernelGGL((k_spmv_stream16<16>), grid, kBlock, 0, s, nb,
                                rbp, A.rowptr.p, A.colidx.p, A.c16.p,
-                               A.c16base.p, A.vals.p, x, y, alpha, beta, b);
+                               A.c16base.p, A.vals.p, x, y, alpha, beta, b, guard);
     } else if (variant == DNS_SPMV_STREAM || variant == DNS_SPMV_STREAM16) {
         // tile 2048, branch-free full-tile loads (UNR = 0), row pointers
         // staged in LDS
