@@ -34,7 +34,9 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True):
     t0 = time.perf_counter()
     system = saddle.SaddleSystem(F, J)
     system.set_schur_mg(prols, smooth_steps=int(os.environ.get('MG_NU', '2')))
-    system.setup_precond(cheb_degree=6, schur='mg', drop_tol=1e-3,
+    system.setup_precond(cheb_degree=int(os.environ.get('MG_DEG', '6')),
+                         schur='mg',
+                         drop_tol=float(os.environ.get('MG_DROP', '1e-3')),
                          factorization='full')
     t_setup = time.perf_counter() - t0
     # initial value: a few steps of startup from rest with the inflow data
