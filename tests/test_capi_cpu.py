@@ -131,3 +131,28 @@ def test_pattern_helpers_of_the_newton_picard_module():
     with pytest.raises(ValueError):
         dnp.values_in_pattern(sps.identity(40, format='csr') + A,
                               dnp.union_pattern(A))
+
+
+def test_pressure_prolongations_of_a_refined_mesh():
+    """input of the multigrid Schur block: P1 prolongations between nested
+    pressure spaces in the spaces' own (RCM) dof numbering"""
+    from dolfin_navier_scipy_amd.fem import (
+        channel_cylinder_mesh, refine_uniform, TaylorHood,
+        pressure_prolongations)
+    coarse = channel_cylinder_mesh()
+    mid, par1 = refine_uniform(coarse)
+    fine, par2 = refine_uniform(mid)
+    spaces = [TaylorHood(fine), TaylorHood(mid), TaylorHood(coarse)]
+    prols = pressure_prolongations(spaces, [par2, par1, None])
+    assert [p.shape for p in prols] == [(fine.nverts, mid.nverts),
+                                        (mid.nverts, coarse.nverts)]
+    for l, P in enumerate(prols):
+        assert np.abs(np.asarray(P.sum(axis=1)).ravel() - 1.).max() < 1e-15
+        assert P.data.min() >= 0.5 - 1e-15 and P.data.max() <= 1. + 1e-15
+        # affine functions are reproduced (straight edges: exactly)
+        fs, cs = spaces[l], spaces[l + 1]
+        xc = np.empty(cs.pdim)
+        xc[cs.vert_pdof] = 2*cs.mesh.verts[:, 0] - cs.mesh.verts[:, 1] + 3
+        xf = np.empty(fs.pdim)
+        xf[fs.vert_pdof] = 2*fs.mesh.verts[:, 0] - fs.mesh.verts[:, 1] + 3
+        assert np.abs(P @ xc - xf).max() < 1e-12
