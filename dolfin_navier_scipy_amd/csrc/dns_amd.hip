@@ -331,11 +331,34 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
 // (`xacc`: also x_v += zv, the fused correction at the end of a cycle)
 int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
                                 double *zv, const int *guard, double *xacc) {
-    if (fhat_explicit) {
+    bool xacc_fused = false;
+    if (fhat_explicit && !dist() && nv > 350000 && Gc.c16.p) {
+        // bandwidth regime: [rv; zp] packed, then the LDS-streaming kernel
+        // with 16-bit column offsets (6 instead of 8 bytes per non-zero with
+        // fp32 values)
+        hipLaunchKernelGGL(k_pack2, grid_for_elems(n), kBlock, 0, stream, nv,
+                           rvec, np, zp, xcat.p, guard);
+        const int nb = Gc.nrowblocks_t[1];
+        const int grid = std::min(nb, 65535);
+        if (fp32_store)
+            hipLaunchKernelGGL((k_spmv_stream16<4, 0, float>), grid, kBlock, 0,
+                               stream, nb, Gc.rowblocks_t[1].p, Gc.rowptr.p,
+                               Gc.colidx.p, Gc.c16.p, Gc.c16base.p, gc32.p,
+                               xcat.p, zv, 1.0, 0.0, (const double *)nullptr,
+                               guard);
+        else
+            hipLaunchKernelGGL((k_spmv_stream16<4, 0, double>), grid, kBlock,
+                               0, stream, nb, Gc.rowblocks_t[1].p, Gc.rowptr.p,
+                               Gc.colidx.p, Gc.c16.p, Gc.c16base.p, Gc.vals.p,
+                               xcat.p, zv, 1.0, 0.0, (const double *)nullptr,
+                               guard);
+        DNS_HIP(hipGetLastError());
+    } else if (fhat_explicit) {
         const int r0 = v0(), r1 = v1();
         const int g = grid_for_rows(r1 - r0, Gc.lpr);
         // fused correction only on one GPU (every rank needs ALL of x)
         double *xa = dist() ? nullptr : xacc;
+        xacc_fused = xa != nullptr;
         if (fp32_store) {
             DNS_LPR_SWITCH(
                 Gc.lpr,
@@ -356,7 +379,7 @@ int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
     } else {
         DNS_TRY(apply_fhat(this, rvec, 0, zero_ptr(), zp, zv, guard));
     }
-    if (xacc && (dist() || !fhat_explicit)) {
+    if (xacc && !xacc_fused) {
         hipLaunchKernelGGL(k_axpby, grid_for_elems(nv), kBlock, 0, stream,
                            (int64_t)nv, 1.0, zv, 1.0, xacc);
         DNS_HIP(hipGetLastError());
@@ -781,6 +804,7 @@ int dns_saddle::ensure_workspace(int m) {
         drop_graphs();
         DNS_TRY(Z.alloc((size_t)m * ld));
     }
+    if (xcat.n < ld) DNS_TRY(xcat.alloc(ld));
     return DNS_OK;
 }
 
@@ -974,7 +998,13 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         if (mgs) {
             // Schur block = V-cycle on V_j,p (or tau(V_j))
             const double *sin = V.p + (size_t)j * ld + nv;
-            if (have_jg) {
+            if (have_jg && !dd && n > 400000 && JG.c16.p) {
+                // tau = V_j,p - JG V_j,v through the streaming kernel
+                const double *vj = V.p + (size_t)j * ld;
+                DNS_TRY(launch_spmv(JG, vj, tau.p, -1.0, 1.0, vj + nv,
+                                    DNS_SPMV_STREAM16, stream, done_ptr()));
+                sin = tau.p;
+            } else if (have_jg) {
                 DNS_LPR_SWITCH(
                     JG.lpr,
                     hipLaunchKernelGGL(k_tau_guard<L>,

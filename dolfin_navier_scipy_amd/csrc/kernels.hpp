@@ -287,13 +287,13 @@ k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
 // DIAG != 0 are diagnostic variants (scripts/spmv_c16.py; wrong results by
 // design): 1 = x read at the stream position instead of the column (no
 // gather), 2 = additionally no LDS reduction phase
-template <int G, int DIAG = 0>
+template <int G, int DIAG = 0, typename VT = double>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
                 const int *__restrict__ rowptr, const int *__restrict__ colidx,
                 const unsigned short *__restrict__ c16,
                 const int *__restrict__ c16base,
-                const double *__restrict__ vals, const double *__restrict__ x,
+                const VT *__restrict__ vals, const double *__restrict__ x,
                 double *__restrict__ y, double alpha, double beta,
                 const double *__restrict__ b,
                 const int *__restrict__ guard = nullptr) {
@@ -313,7 +313,7 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
         if (nn > TILE) {
             double s = 0.0;
             for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
-                s = fma(vals[k], x[colidx[k]], s);
+                s = fma((double)vals[k], x[colidx[k]], s);
             s = block_sum(s, red);
             if (threadIdx.x == 0)
                 y[r0] = b ? fma(alpha, s, beta * b[r0]) : alpha * s;
@@ -335,7 +335,7 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int kk = k0 + min((int)threadIdx.x + i * kBlock, nn - 1);
-                v[i] = vals[kk];
+                v[i] = (double)vals[kk];
                 e[i] = c16[kk];
             }
             double xv[NI];
@@ -351,7 +351,7 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
         } else {
 #pragma unroll 2
             for (int k = threadIdx.x; k < nn; k += kBlock)
-                prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
+                prod[k] = (double)vals[k0 + k] * x[colidx[k0 + k]];
         }
         __syncthreads();
         const int g = threadIdx.x % G, rsub = threadIdx.x / G;
@@ -806,6 +806,18 @@ k_stream_triad(int64_t n2, const dns_double2 *__restrict__ a,
         r.y = fma(sc, v.y, u.y);
         c[i] = r;
     }
+}
+
+// xcat = [a[0..n1) ; b[0..n2)]  (input vector of the explicit Fh^-1 matrix
+// Gc = [G, -G JT] when it runs through the streaming kernel)
+__global__ void __launch_bounds__(kBlock)
+k_pack2(int n1, const double *__restrict__ a, int n2,
+        const double *__restrict__ b, double *__restrict__ out,
+        const int *__restrict__ guard) {
+    if (guard && *guard) return;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n1 + n2;
+         i += gridDim.x * kBlock)
+        out[i] = (i < n1) ? a[i] : b[i - n1];
 }
 
 // multigrid smoother pieces: x = omega * dinv .* b   and

@@ -270,6 +270,7 @@ struct dns_saddle {
                                               // vector kernels
     bool fuse_dots = true;
     dns::DevBuf<double> V, Z, w, z, u, r, xdev, bdev;   // Z_j = P^-1 V_j
+    dns::DevBuf<double> xcat;        // [r_v; z_p] packed for the streaming Gc
     dns::DevBuf<double> partA, partN, partR, partB, partC, partE;
     dns::DevBuf<double> bi_rhat, bi_p, bi_v, bi_s, bi_t, bi_y, histdev;
     dns::DevBuf<dns::DnsCtl> ctl;
