@@ -241,6 +241,8 @@ def main():
                     help='red refinements of the mesh for the HBM roofline '
                     'SpMV (0 disables)')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--no-refined', action='store_true',
+                    help='skip the secondary refined-mesh figures')
     ap.add_argument('--no-picard', action='store_true',
                     help='skip the secondary Newton/Picard sweep figures')
     ap.add_argument('--replicas', action='store_true',
@@ -526,6 +528,15 @@ def main():
         picard = None
         if world == 1 and not args.eager and not args.no_picard:
             picard = picard_sweep_figures(femp, sm, rhsd, v0, dt, device)
+        refined = None
+        if world == 1 and not args.eager and not args.no_refined:
+            # bandwidth regime, end to end: the same CNAB loop on the mesh
+            # refined twice (n = 173k, multigrid Schur block, dt/4) next to
+            # the prefactored SuperLU step on the host
+            sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+            import refined_bench
+            refined = refined_bench.run(refine=2, nts=4*args.nts, nsteps=200,
+                                        with_cpu=not args.no_cpu, Re=args.Re)
         cpu = None
         parity = None
         if not args.no_cpu and world == 1:     # rank 0 at N=1 only
@@ -565,6 +576,7 @@ def main():
                             iters_fr/float(args.steps)),
                         true_relres_last=last['true_relres'],
                         newton_picard_sweeps=picard,
+                        refined_mesh=refined,
                         device_ms_per_step=1e3*dev_s/args.steps,
                         precond_setup_s=t_setup,
                         initial_stokes=st0,
