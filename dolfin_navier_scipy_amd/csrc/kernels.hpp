@@ -820,18 +820,6 @@ k_pack2(int n1, const double *__restrict__ a, int n2,
         out[i] = (i < n1) ? a[i] : b[i - n1];
 }
 
-// multigrid smoother pieces: x = omega * dinv .* b   and
-// x += omega * dinv .* t   (t = b - S x from the SpMV kernel in front)
-__global__ void __launch_bounds__(kBlock)
-k_mg_jacobi(int n, double omega, const double *__restrict__ dinv,
-            const double *__restrict__ t, double *__restrict__ x, int accumulate) {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
-         i += gridDim.x * kBlock) {
-        const double v = omega * dinv[i] * t[i];
-        x[i] = accumulate ? x[i] + v : v;
-    }
-}
-
 // zp = -x (and xacc += zp) unless the guard is raised
 __global__ void __launch_bounds__(kBlock)
 k_mg_jacobi_guard(int n, const double *__restrict__ x, double *__restrict__ zp,

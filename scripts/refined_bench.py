@@ -37,6 +37,7 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True):
     system.setup_precond(cheb_degree=int(os.environ.get('MG_DEG', '6')),
                          schur='mg',
                          drop_tol=float(os.environ.get('MG_DROP', '1e-3')),
+                         fhat=os.environ.get('MG_FHAT', 'auto'),
                          factorization='full')
     t_setup = time.perf_counter() - t0
     # initial value: a few steps of startup from rest with the inflow data
