@@ -572,6 +572,10 @@ k_arn_tail(int c, const double *__restrict__ norm_part, int nparts,
     ctl->acc_solves += 1;
     ctl->acc_iters += ctl->total_it;
     if (ctl->total_it > ctl->acc_maxit) ctl->acc_maxit = ctl->total_it;
+    if (ctl->conv && ctl->tol > 0.0) {
+        const double rel = ctl->resnorm / ctl->tol;
+        if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
+    }
     if (!ctl->conv) ctl->acc_fail += 1;
 }
 

@@ -34,7 +34,7 @@ struct DnsCtl {
     int acc_solves, acc_fail, acc_iters, acc_maxit;
     // BiCGStab scalars
     double rho, alpha, omega;
-    double pad2;
+    double acc_maxrel;   // batch maximum of (final residual / tolerance)
     double hcol[kMaxRestart + 1];
     double cs[kMaxRestart], sn[kMaxRestart], g[kMaxRestart + 1];
     double y[kMaxRestart];

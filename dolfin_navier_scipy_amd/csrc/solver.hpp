@@ -230,6 +230,8 @@ struct CtlHeader {   // leading part of DnsCtl, copied back to the host
 struct CtlHeaderAcc {   // header + the batch accumulators behind it
     CtlHeader h;
     int acc_solves, acc_fail, acc_iters, acc_maxit;
+    double rho, alpha, omega;          // (BiCGStab scalars, layout of DnsCtl)
+    double acc_maxrel;
 };
 
 // a captured chunk of work, replayed with hipGraphLaunch
