@@ -260,7 +260,7 @@ k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
             for (int i = 0; i < NI; ++i)
                 prod[threadIdx.x + i * kBlock] = v[i] * xv[i];
         } else {
-#pragma unroll(UNR > 0 ? UNR : 1)
+#pragma unroll 2
             for (int k = threadIdx.x; k < nn; k += kBlock)
                 prod[k] = vals[k0 + k] * x[colidx[k0 + k]];
         }
