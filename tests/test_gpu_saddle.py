@@ -395,3 +395,36 @@ def test_multigrid_schur_block_on_a_refined_mesh(sad):
     with pytest.raises(_capi.DnsError):
         system.set_schur_mg([prols[0][:-1, :]])
     system.close()
+
+
+@pytest.mark.parametrize('fact', ['triangular', 'full'])
+def test_driven_cavity_stokes_and_step(sad, fact):
+    """BASELINE config 0 (`tests/mini_setup.py` plumbing case): enclosed flow,
+    pressure pinned by dropping the last pressure dof (dnsps:178-182).  The
+    steady Stokes system `[[A, JT],[J, 0]]` (no mass shift: the hardest system
+    for the Krylov solver, snu:903-907) and one implicit step, both through the
+    drop-in `lau`, against the oracle's direct solves"""
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='drivencavity', N=24, Re=50)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    assert femp['ppin'] == -1 and NP == 25*25 - 1
+    ref = saddle_oracle.solve_sadpnt_smw(amat=A, jmat=J, rhsv=rhsd['fv'],
+                                         rhsp=rhsd['fp'])
+    lau.clear_cache()
+    got = lau.solve_sadpnt_smw(amat=A, jmat=J, rhsv=rhsd['fv'], rhsp=rhsd['fp'],
+                               krplsprms=dict(factorization=fact))
+    assert np.linalg.norm(got[:NV] - ref[:NV]) <= 1e-8*np.linalg.norm(ref[:NV])
+    assert np.linalg.norm(got[NV:] - ref[NV:]) <= 1e-6*np.linalg.norm(ref[NV:])
+    assert np.abs(J @ got[:NV] - rhsd['fp']).max() <= 1e-9
+    dt = 1e-2
+    F = (M + dt*A).tocsr()
+    rhs = M @ ref[:NV] + dt*rhsd['fv']
+    ref2 = saddle_oracle.solve_sadpnt_smw(amat=F, jmat=J, rhsv=rhs,
+                                          rhsp=rhsd['fp'])
+    got2 = lau.solve_sadpnt_smw(amat=F, jmat=J, rhsv=rhs, rhsp=rhsd['fp'],
+                                krplsprms=dict(factorization=fact))
+    assert np.linalg.norm(got2[:NV] - ref2[:NV]) <= \
+        1e-8*np.linalg.norm(ref2[:NV])
+    lau.clear_cache()
