@@ -428,3 +428,31 @@ def test_driven_cavity_stokes_and_step(sad, fact):
     assert np.linalg.norm(got2[:NV] - ref2[:NV]) <= \
         1e-8*np.linalg.norm(ref2[:NV])
     lau.clear_cache()
+
+
+def test_stiff_penalty_entries_like_robin_control(sad, small):
+    """BASELINE config 4's `A += Arob/alpha`, alpha = 1e-5 (reference
+    tests/time_dep_nse_double_rotcyl_bcrob.py:37-38): a few velocity dofs carry
+    entries 1e5 x larger than the rest.  The Jacobi scaling inside the
+    Chebyshev polynomial has to absorb that"""
+    F, J = small['F'], small['J']
+    NV = F.shape[0]
+    rng = np.random.default_rng(8)
+    idx = rng.choice(NV, 24, replace=False)
+    pen = sps.csr_matrix((np.full(idx.size, 1e5*abs(F.diagonal()).mean()),
+                          (idx, idx)), shape=F.shape)
+    # coupled 2x2 blocks as a boundary mass matrix would produce
+    off = sps.csr_matrix((np.full(idx.size//2, 3e4*abs(F.diagonal()).mean()),
+                          (idx[0::2], idx[1::2])), shape=F.shape)
+    Fp = (F + small['dt']*(pen + off + off.T)).tocsr()
+    ref = saddle_oracle.solve_sadpnt_smw(amat=Fp, jmat=J, rhsv=small['rhsv'],
+                                         rhsp=small['rhsp']).reshape(-1)
+    for fact in ('triangular', 'full'):
+        system = sad.SaddleSystem(Fp, J)
+        system.setup_precond(cheb_degree=6, schur='dense', factorization=fact)
+        x = system.solve(small['rhsv'], small['rhsp'], rtol=1e-12, maxiter=400)
+        st = system.last_stats
+        assert st['status'] == 0 and st['true_relres'] <= 5e-12, (fact, st)
+        assert st['iters'] <= 60, (fact, st['iters'])
+        assert np.linalg.norm(x[:NV] - ref[:NV]) <= 1e-8*np.linalg.norm(ref[:NV])
+        system.close()
