@@ -148,7 +148,7 @@ def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64):
     ts.set_rhs(rhsd['fv'], rhsd['fp'])
     for k in range(nsteps + 1):       # first linearisation: the initial state
         ts.write_linpoint(0, k, v0)
-    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=0)
+    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=2)
     out = {}
     which = 0
     # untimed pass: graph capture of the solver cycles (trajectory 0 = the
