@@ -185,6 +185,11 @@ SIGNATURES = {
                                  ct.POINTER(dns_solve_stats)]),
     'dns_trap_get_state': (ct.c_int, [ct.c_void_p, c_double_p, c_double_p]),
     'dns_trap_update_norm': (ct.c_int, [ct.c_void_p, c_double_p]),
+    'dns_trap_set_pipeline': (ct.c_int, [ct.c_void_p, ct.c_int32]),
+    'dns_trap_poll': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32),
+                                 ct.POINTER(ct.c_int32),
+                                 ct.POINTER(ct.c_int32),
+                                 ct.POINTER(ct.c_int32)]),
     'dns_hbm_probe': (ct.c_int, [ct.c_int, ct.c_int64, ct.c_int32, ct.c_int32,
                                  c_double_p]),
 }

@@ -52,6 +52,18 @@ k_trap_rhs(int nv, int np, const int *__restrict__ rowptr,
         b[nv + i] = fp[i];
 }
 
+// acc[0] += scale * sum(partials)   (one workgroup; the update norm of a
+// pipelined sweep stays on the device)
+__global__ void __launch_bounds__(kBlock)
+k_trap_acc(const double *__restrict__ partials, int nparts, double scale,
+           double *__restrict__ acc) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += kBlock) s += partials[p];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) acc[0] += scale * s;
+}
+
 // d = x - y
 __global__ void __launch_bounds__(kBlock)
 k_trap_diff(int n, const double *__restrict__ x, const double *__restrict__ y,
@@ -74,6 +86,8 @@ struct dns_trap {
     dns::DevBuf<double> fv, fp, fvn_c, fvn_n, rhsbc, rhscon, b, dtmp, mtmp;
     dns::DevBuf<double> traj[2];
     double updnorm = 0.0;                      // sum dt ||v_n - v_lin||_M^2
+    dns::DevBuf<double> updnorm_dev;           // ... its part still on the device
+    int pipeline_c = 0;                        // > 0: steps do not synchronise
     double last_dt = 0.0;
     // N_c, f_c at the current velocity
     int assemble_current(int newton);

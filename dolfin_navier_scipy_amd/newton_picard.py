@@ -143,13 +143,24 @@ class TrapezoidalStepper(object):
         C.check(self.lib.dns_trap_get_state(self._h, C.dptr(v), C.dptr(p)))
         return v.reshape((-1, 1)), p.reshape((-1, 1))
 
+    def set_pipeline(self, cycle_len):
+        """`cycle_len > 0`: `step` only enqueues (no host synchronisation, no
+        stats); `poll()` collects the batch's counters"""
+        C.check(self.lib.dns_trap_set_pipeline(self._h, int(cycle_len)))
+
+    def poll(self):
+        vals = [ct.c_int32(0) for _ in range(4)]
+        C.check(self.lib.dns_trap_poll(self._h, *[ct.byref(v) for v in vals]))
+        return dict(zip(('solves', 'fails', 'iters', 'maxit'),
+                        [v.value for v in vals]))
+
     def update_norm(self):
         out = ct.c_double(0.)
         C.check(self.lib.dns_trap_update_norm(self._h, ct.byref(out)))
         return out.value
 
     def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=2,
-              record=True):
+              record=True, pipeline=True):
         """one sweep over `trange` linearised about trajectory `lin_which`
         (slot k <-> trange[k]); the new velocities go to the other trajectory.
         Returns `(vdict, pdict, norm_nwtnupd, stats)` (dicts empty unless
@@ -159,19 +170,36 @@ class TrapezoidalStepper(object):
             raise ValueError('trajectory buffers hold {0} slots'.format(
                 self.nslots))
         newton = not picard
-        self.start(iniv, newton)
-        self.write_linpoint(1 - lin_which, 0, iniv)
-        vdict, pdict = {}, {}
-        if record:
-            vdict[trange[0]] = np.asarray(iniv, dtype=float).reshape((-1, 1))
-        iters, secs = 0, 0.
-        for k in range(1, trange.size):
-            st = self.step(trange[k] - trange[k-1], lin_which, k, k, newton,
-                           opts=opts, extrapolate=extrapolate)
-            iters += st['iters']
-            secs += st['device_seconds']
+        steps = np.diff(trange)
+        uniform = steps.size > 3 and \
+            np.abs(steps - steps[0]).max() <= 1e-12*abs(steps[0])
+        for attempt in ('pipelined', 'synchronous'):
+            self.start(iniv, newton)
+            self.write_linpoint(1 - lin_which, 0, iniv)
+            vdict, pdict = {}, {}
             if record:
-                vdict[trange[k]], pdict[trange[k]] = self.state()
+                vdict[trange[0]] = np.asarray(iniv,
+                                              dtype=float).reshape((-1, 1))
+            iters, secs, ok = 0, 0., True
+            pipelined = pipeline and uniform and attempt == 'pipelined'
+            for k in range(1, trange.size):
+                if pipelined and k == 3:
+                    # cycle length: what the first steps needed + one slack
+                    self.set_pipeline(max(2, self.last_stats['iters'] + 1))
+                st = self.step(trange[k] - trange[k-1], lin_which, k, k,
+                               newton, opts=opts, extrapolate=extrapolate)
+                if not (pipelined and k >= 3):
+                    iters += st['iters']
+                    secs += st['device_seconds']
+                if record:
+                    vdict[trange[k]], pdict[trange[k]] = self.state()
+            if pipelined and trange.size > 3:
+                acc = self.poll()
+                self.set_pipeline(0)
+                iters += acc['iters']
+                ok = acc['fails'] == 0
+            if ok:
+                break
         return vdict, pdict, self.update_norm(), dict(iters=iters,
                                                       device_seconds=secs)
 

@@ -365,6 +365,15 @@ int dns_trap_step(dns_trap *t, double dt, int32_t lin_which, int32_t lin_slot,
                   const dns_solve_opts *opts, dns_solve_stats *stats);
 int dns_trap_get_state(dns_trap *t, double *v, double *p);
 int dns_trap_update_norm(dns_trap *t, double *out);
+/* pipelined sweeps: with cycle_len > 0 `dns_trap_step` only enqueues (one GMRES
+ * cycle of that length, no host synchronisation, `stats` not filled); the
+ * device counts solves / unconverged solves / Krylov steps and keeps the update
+ * norm; `dns_trap_poll` synchronises, hands the counters back (and resets
+ * them) and folds the device part of the update norm in.  A sweep with
+ * `fails > 0` has to be repeated with cycle_len = 0. */
+int dns_trap_set_pipeline(dns_trap *t, int32_t cycle_len);
+int dns_trap_poll(dns_trap *t, int32_t *solves, int32_t *fails, int32_t *iters,
+                  int32_t *maxit);
 
 /* attainable HBM bandwidth of the device, measured with plain streaming
  * kernels over `bytes` of fp64 data (kind 0: read + reduce, 1: copy,
