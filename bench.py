@@ -45,6 +45,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 
+# solver settings of the timed loop (tests/test_gpu_long_horizon.py runs the
+# 512 steps of BASELINE config 2 with exactly these and checks the 1e-8 parity)
+DEFAULTS = dict(cheb=6, rtol=1e-10, extrap=4, fp32=1, drop=1e-3, fact='full',
+                reorth=2)
+
 
 class stdout_to_stderr(object):
     """RCCL prints a version banner on fd 1 when a communicator is created;
@@ -124,6 +129,82 @@ def cpu_baseline(sm, rhsd, v0, nfc0, dt, conv_host, nsteps):
                 '({1:.3f} s, untimed) + per-step rhs, 2 triangular solves, '
                 'rescale; convection callback evaluated on the host but not '
                 'timed'.format(nsteps, tfac)), v, p
+
+
+def cpu_baseline_extras(sm, rhsd, v0, nfc0, dt, nsteps_gmres=3,
+                        nsteps_threads=40):
+    """the other two CPU lines of SURVEY 8d:
+    (iii) un-preconditioned `scipy.sparse.linalg.gmres(rtol=1e-3,
+          maxiter=800)` per step -- the stand-in for the reference's krypy path
+          (`tests/time_dep_nse_krylov.py:4-7`: tol 1e-3, maxiter 800);
+    "all cores": the prefactored SuperLU step again with every host core the
+          process may use handed to the BLAS/OpenMP runtimes (SuperLU's
+          triangular solves and SciPy's CSR products are single-threaded, so
+          this mostly shows that the reference algorithm does not scale with
+          cores)"""
+    import scipy.sparse as sps
+    import scipy.sparse.linalg as spsla
+    from oracle.saddle_oracle import SaddleLU
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    F = (M + .5*dt*A).tocsr()
+    K = sps.bmat([[F, J.T], [J, None]], format='csr')
+    fv, fp = rhsd['fv'], rhsd['fp']
+    out = {}
+    # (iii) Krylov stand-in
+    v = v0.copy()
+    el, its = 0., 0
+    x0 = np.zeros(NV + NP)
+    x0[:NV] = v0[:, 0]
+    cnt = [0]
+
+    def cb(_):
+        cnt[0] += 1
+    for k in range(nsteps_gmres):
+        t0 = time.perf_counter()
+        rhs = M @ v - .5*dt*(A @ v) + dt*nfc0 + dt*fv
+        b = np.vstack([rhs, fp]).flatten()
+        x, info = spsla.gmres(K, b, x0=x0, rtol=1e-3, atol=0., restart=800,
+                              maxiter=1, callback=cb, callback_type='pr_norm')
+        el += time.perf_counter() - t0
+        x0 = x
+        v = x[:NV].reshape((NV, 1))
+    out['krylov_unpreconditioned'] = dict(
+        value=nsteps_gmres/el, unit='timesteps/s', cores=1, kind='port',
+        inner_iterations_per_step=cnt[0]/float(nsteps_gmres),
+        sample='{0} CNAB steps, each solved by scipy.sparse.linalg.gmres('
+        'rtol=1e-3, 800 inner iterations at most, no preconditioner, warm '
+        'start from the previous step) -- stand-in for the krypy path of '
+        'tests/time_dep_nse_krylov.py (tol 1e-3, maxiter 800); convection '
+        'frozen'.format(nsteps_gmres))
+    # all cores
+    ncores = len(os.sched_getaffinity(0))
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        threadpool_limits = None
+    klu = SaddleLU(F.tocsc(), J)
+    v = v0.copy()
+    el = 0.
+    ctx = threadpool_limits(limits=ncores) if threadpool_limits else None
+    try:
+        for k in range(nsteps_threads):
+            t0 = time.perf_counter()
+            rhs = M @ v - .5*dt*(A @ v) + dt*nfc0 + dt*fv
+            vp = klu(np.vstack([rhs, fp]).flatten())
+            v = vp[:NV].reshape((NV, 1))
+            el += time.perf_counter() - t0
+    finally:
+        if ctx is not None:
+            ctx.restore_original_limits()
+    out['all_cores'] = dict(
+        value=nsteps_threads/el, unit='timesteps/s', cores=ncores,
+        kind='port',
+        sample='{0} prefactored-SuperLU CNAB steps with the BLAS/OpenMP '
+        'thread pools opened to all {1} cores of the process (SuperLU '
+        'triangular solves and CSR products stay single-threaded)'.format(
+            nsteps_threads, ncores))
+    return out
 
 
 def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64):
@@ -212,23 +293,28 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=400)
     ap.add_argument('--warmup', type=int, default=40)
+    ap.add_argument('--spinup', type=int, default=256,
+                    help='untimed steps between the impulsive start (Stokes '
+                    'state) and the warm-up: the timed window then samples the '
+                    'developed run, not the first instants of the start-up '
+                    'transient (reported separately in config.early_transient)')
     ap.add_argument('--level', type=int, default=2, help='mesh level N')
     ap.add_argument('--Re', type=float, default=100.)
     ap.add_argument('--nts', type=int, default=512, help='dt = 1/nts')
     ap.add_argument('--method', default='gmres')
-    ap.add_argument('--cheb', type=int, default=6)
-    ap.add_argument('--rtol', type=float, default=1e-10)
-    ap.add_argument('--extrap', type=int, default=4,
+    ap.add_argument('--cheb', type=int, default=DEFAULTS['cheb'])
+    ap.add_argument('--rtol', type=float, default=DEFAULTS['rtol'])
+    ap.add_argument('--extrap', type=int, default=DEFAULTS['extrap'],
                     help='warm start: 0 none, 1 linear, 2 quadratic, 3 cubic, '
                     '4 quartic')
-    ap.add_argument('--fp32', type=int, default=1,
+    ap.add_argument('--fp32', type=int, default=DEFAULTS['fp32'],
                     help='store the explicit preconditioner matrices in fp32')
-    ap.add_argument('--drop', type=float, default=1e-3,
+    ap.add_argument('--drop', type=float, default=DEFAULTS['drop'],
                     help='relative drop tolerance of the explicit polynomial')
-    ap.add_argument('--fact', default='full',
+    ap.add_argument('--fact', default=DEFAULTS['fact'],
                     help="block structure of the preconditioner: "
                     "'triangular' or 'full' (block LDU)")
-    ap.add_argument('--reorth', type=int, default=2,
+    ap.add_argument('--reorth', type=int, default=DEFAULTS['reorth'],
                     help='1: Gram-Schmidt applied twice (CGS2), 0: once, '
                     '2: once, folded into the head kernel of the next step')
     ap.add_argument('--fhat', default='auto',
@@ -240,6 +326,11 @@ def main():
     ap.add_argument('--roofline-refine', type=int, default=4,
                     help='red refinements of the mesh for the HBM roofline '
                     'SpMV (0 disables)')
+    ap.add_argument('--profile-step', action='store_true',
+                    help='profiling aid (rocprofv3 --kernel-trace --stats): '
+                    'only the timed CNAB loop runs -- start from rest instead '
+                    'of the Stokes solve, no secondary legs, no CPU leg -- so '
+                    'that the kernel table is the table of the step')
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--no-refined', action='store_true',
                     help='skip the secondary refined-mesh figures')
@@ -304,7 +395,10 @@ def main():
     def factory(F, Jm):
         return saddle.SaddleSystem(F, Jm, device=device)
 
-    if args.refine > 0:
+    if args.profile_step:
+        args.no_cpu = args.no_refined = args.no_picard = True
+        args.roofline_refine = 0
+    if args.refine > 0 or args.profile_step:
         v0, pt0, st0 = np.zeros((NV, 1)), None, None     # start from rest
     else:
         v0, pt0, st0 = initial_state(sm, rhsd, factory)
@@ -352,17 +446,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_run(with_convection, nsteps=None, nwarm=None):
+    def timed_run(with_convection, nsteps=None, nwarm=None, spinup=None):
         nsteps = args.steps if nsteps is None else nsteps
         nwarm = args.warmup if nwarm is None else nwarm
+        spinup = args.spinup if spinup is None else spinup
         stp = saddle.ImexStepper(system, R1)
         stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
         stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
-        cvop = None
-        if with_convection:
-            cvop = convection.ConvectionP2.from_taylor_hood(
-                th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
-            stp.set_convection(cvop, scale=-1.0)
+        cvop = convection.ConvectionP2.from_taylor_hood(
+            th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
+        stp.set_convection(cvop, scale=-1.0)
+        if spinup > 0:
+            stp.run(spinup, cf, opts)        # always with the convection
+        if not with_convection:
+            stp.set_convection(None)         # history frozen from here on
         stp.run(nwarm, cf, opts)
         barrier()
         t0 = time.perf_counter()
@@ -376,9 +473,9 @@ def main():
             dist.all_reduce(tw, op=dist.ReduceOp.MAX)
             wl = float(tw.item())
         vv, pp = stp.get_state()
+        lst = dict(lst, run_record=dict(stp.last_run))
         stp.close()
-        if cvop is not None:
-            cvop.close()
+        cvop.close()
         return wl, dev_s, its, lst, vv, pp
 
     def partitioned_leg():
@@ -397,7 +494,7 @@ def main():
                                  drop_tol=args.drop, factorization=args.fact)
             psteps = min(args.steps, 200)
             pwall, _, piters, plast, _, _ = timed_run(
-                True, nsteps=psteps, nwarm=min(args.warmup, 20))
+                True, nsteps=psteps, nwarm=min(args.warmup, 20), spinup=0)
             res = dict(
                 steps_per_s=psteps/pwall, steps=psteps, scaling='strong',
                 krylov_iters_per_step=piters/float(psteps),
@@ -426,8 +523,14 @@ def main():
 
     # headline: the complete time step, convection evaluated on the device
     wall, dev_s, iters, last, v_gpu, p_gpu = timed_run(True)
-    # secondary: convection history frozen (the linear algebra alone)
-    wall_fr, _, iters_fr, _, _, _ = timed_run(False)
+    if args.profile_step:
+        wall_fr, iters_fr, wall_et, iters_et = wall, iters, wall, iters
+    else:
+        # secondary: convection history frozen (the linear algebra alone)
+        wall_fr, _, iters_fr, _, _, _ = timed_run(False)
+        # secondary: the same window right behind the impulsive start (Stokes
+        # state, no spin-up): the solves need about two Krylov steps there
+        wall_et, _, iters_et, _, _, _ = timed_run(True, spinup=0)
 
     # secondary (N > 1, or --force-dist): ONE simulation whose operator applies
     # are row-partitioned over the ranks -- RCCL all-gather-v of the row blocks
@@ -487,9 +590,14 @@ def main():
     out = None
     if rank == 0:
         value = world*args.steps/wall
-        roof = roofline_spmv(saddle, saddle_csr(F, J), 200,
-                             'K at the benchmark size (cache resident)',
-                             variants=('vector',))
+        from dolfin_navier_scipy_amd import perfmodel
+        step_roof = perfmodel.step_roofline(
+            system.precond_info(), int(R1.nnz), int(th.mesh.ncells),
+            iters/float(args.steps), 1e3*wall/args.steps,
+            peak_GBs=HBM_PEAK_GBS)
+        roof = None if args.profile_step else roofline_spmv(
+            saddle, saddle_csr(F, J), 200,
+            'K at the benchmark size (cache resident)', variants=('vector',))
         roof_hbm = None
         if args.roofline_refine > 0:
             _, smr, _ = build_problem(N=args.level, Re=args.Re,
@@ -505,6 +613,9 @@ def main():
         else:
             traffic = None
         main_roof = roof_hbm if roof_hbm is not None else roof
+        if main_roof is None:          # --profile-step: the step's own figure
+            main_roof = dict(achieved=step_roof['achieved'],
+                             kernel='(whole CNAB step, see roofline.step)')
         # what plain streaming kernels get out of this HBM (2 GiB, fp64)
         attain = None
         if args.roofline_refine > 0:
@@ -524,7 +635,10 @@ def main():
                         frac_of_attainable_read=(
                             main_roof['achieved']/attain['read']
                             if attain else None),
-                        at_benchmark_size=roof)
+                        at_benchmark_size=roof,
+                        # the whole time step against the same peak: published
+                        # op list x measured Krylov steps / measured time
+                        step=step_roof)
         picard = None
         if world == 1 and not args.eager and not args.no_picard:
             picard = picard_sweep_figures(femp, sm, rhsd, v0, dt, device)
@@ -537,18 +651,21 @@ def main():
             import refined_bench
             refined = refined_bench.run(refine=2, nts=4*args.nts, nsteps=200,
                                         with_cpu=not args.no_cpu, Re=args.Re)
+            roofline['step_refined'] = refined.pop('roofline_step', None)
         cpu = None
         parity = None
         if not args.no_cpu and world == 1:     # rank 0 at N=1 only
+            nall = args.spinup + args.warmup + args.steps
             cpu, v_cpu, p_cpu = cpu_baseline(
-                sm, rhsd, v0, nfc, dt, conv_host, args.warmup + args.steps)
+                sm, rhsd, v0, nfc, dt, conv_host, nall)
+            cpu['other_lines'] = cpu_baseline_extras(sm, rhsd, v0, nfc, dt)
             # same steps, same nonlinear trajectory on both sides
             mn = lambda x: float(np.sqrt((x.T @ (M @ x)).item()))
             parity = dict(
                 v_rel_Mnorm=mn(v_gpu - v_cpu)/mn(v_cpu),
                 p_rel_l2=float(np.linalg.norm(p_gpu - p_cpu)
                                / np.linalg.norm(p_cpu)),
-                steps=args.warmup + args.steps)
+                steps=args.spinup + args.warmup + args.steps)
         out = dict(
             metric='timesteps/sec, 2D cylinder wake Re={0:g} (CNAB step: device '
                    'convection + rhs SpMV + preconditioned Krylov saddle solve '
@@ -560,8 +677,17 @@ def main():
             dtype='f64', data='synthetic',
             config=dict(workload='cylinderwake N={0} Re={1:g} CNAB dt=1/{2} '
                         'Taylor-Hood NV={3} NP={4}; convection N(v)v '
-                        'evaluated on the device every step'
-                        .format(args.level, args.Re, args.nts, NV, NP),
+                        'evaluated on the device every step; state: Stokes '
+                        'solution advanced {5} untimed spin-up steps'
+                        .format(args.level, args.Re, args.nts, NV, NP,
+                                args.spinup),
+                        spinup_steps=args.spinup,
+                        early_transient=dict(
+                            steps_per_s=world*args.steps/wall_et,
+                            krylov_iters_per_step=iters_et/float(args.steps),
+                            what='the same window with no spin-up (steps '
+                            '{0}..{1} behind the impulsive start)'.format(
+                                args.warmup, args.warmup + args.steps)),
                         parallelism=mode, collectives=None,
                         row_partitioned=partitioned,
                         row_partitioned_refined=partitioned_refined,
@@ -575,6 +701,7 @@ def main():
                         krylov_iters_per_step_frozen=(
                             iters_fr/float(args.steps)),
                         true_relres_last=last['true_relres'],
+                        timed_run_record=last['run_record'],
                         newton_picard_sweeps=picard,
                         refined_mesh=refined,
                         device_ms_per_step=1e3*dev_s/args.steps,

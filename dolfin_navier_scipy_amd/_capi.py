@@ -110,6 +110,9 @@ SIGNATURES = {
     'dns_saddle_apply': (ct.c_int, [_VP, c_double_p, c_double_p]),
     'dns_saddle_apply_precond': (ct.c_int, [_VP, c_double_p, c_double_p]),
     'dns_saddle_cheb_bounds': (ct.c_int, [_VP, c_double_p, c_double_p]),
+    'dns_saddle_precond_info': (ct.c_int, [_VP, ct.c_int32,
+                                           ct.POINTER(ct.c_int64),
+                                           c_int32_p]),
     'dns_saddle_probe': (ct.c_int, [_VP, ct.c_int32, ct.c_int32, ct.c_int32,
                                     c_double_p]),
     'dns_comm_unique_id': (ct.c_int, [ct.c_char_p]),
@@ -144,6 +147,8 @@ SIGNATURES = {
                                 ct.POINTER(ct.c_int64)]),
     'dns_imex_get_state': (ct.c_int, [_VP, c_double_p, c_double_p]),
     'dns_imex_vnorm': (ct.c_int, [_VP, c_double_p]),
+    'dns_imex_run_info': (ct.c_int, [_VP, c_int32_p, c_int32_p, c_int32_p,
+                                     c_int32_p]),
     'dns_conv_create_p2': (ct.c_int, [ct.c_int, ct.c_int32, c_int32_p,
                                       c_double_p, c_double_p, ct.c_int32,
                                       ct.c_int32, c_int32_p, ct.c_int32,

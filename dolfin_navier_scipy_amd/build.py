@@ -1,5 +1,6 @@
 """Build the in-tree gfx950 shared library with hipcc (cross-compiles without
 a GPU).  `python -m dolfin_navier_scipy_amd.build`"""
+import glob
 import os
 import shutil
 import subprocess
@@ -8,11 +9,19 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['dns_amd.hip']
-HEADERS = ['common.hpp', 'kernels.hpp', 'bicgstab_kernels.hpp', 'solver.hpp',
-           'hostcsr.hpp', 'gmres_kernels.hpp', 'comm.hpp',
-           'imex.hpp', 'imex_capi.inc', 'convection.hpp', 'conv_capi.inc',
-           os.path.join('..', '..', 'include', 'dns_amd.h')]
 LIB = os.path.join(CSRC, 'libdnsamd.so')
+
+
+def dependencies():
+    """every file the translation unit can include: all headers / .inc files
+    next to it and the public header (derived, not hand-kept: a stale list once
+    let an edit of trap_capi.inc ship an old library)"""
+    deps = sorted(glob.glob(os.path.join(CSRC, '*.hpp'))
+                  + glob.glob(os.path.join(CSRC, '*.inc'))
+                  + glob.glob(os.path.join(CSRC, '*.hip')))
+    deps.append(os.path.normpath(os.path.join(CSRC, '..', '..', 'include',
+                                              'dns_amd.h')))
+    return deps
 
 
 def _hipcc():
@@ -26,8 +35,8 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     libtime = os.path.getmtime(LIB)
-    for name in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, name)) > libtime:
+    for path in dependencies():
+        if os.path.getmtime(path) > libtime:
             return True
     return False
 

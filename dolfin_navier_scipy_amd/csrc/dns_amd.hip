@@ -840,6 +840,7 @@ void dns_saddle::drop_graphs() {
         if (g.graph) (void)hipGraphDestroy(g.graph);
     }
     graphs.clear();
+    graph_generation++;
 }
 
 // Run `body` (which only enqueues work on `stream`) either eagerly or as a
@@ -848,13 +849,13 @@ void dns_saddle::drop_graphs() {
 // the host's launch rate.
 template <typename Body>
 int dns_saddle::run_cached(const std::vector<uint64_t> &key, bool use_graph,
-                           Body body) {
+                           Body body, bool launch) {
     // inside an enclosing capture (several time steps in one graph) the body
     // is simply enqueued into that capture
     if (!use_graph || capturing) return body();
     for (auto &g : graphs)
         if (g.key == key) {
-            DNS_HIP(hipGraphLaunch(g.exec, stream));
+            if (launch) DNS_HIP(hipGraphLaunch(g.exec, stream));
             return DNS_OK;
         }
     GraphEntry ge;
@@ -872,9 +873,10 @@ int dns_saddle::run_cached(const std::vector<uint64_t> &key, bool use_graph,
         return fail(DNS_ERR_HIP, "hipStreamEndCapture: %s",
                     hipGetErrorString(e));
     DNS_HIP(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
-    if (graphs.size() > 64) drop_graphs();
+    graph_captures++;
+    if (graphs.size() > 256) drop_graphs();
     graphs.push_back(ge);
-    DNS_HIP(hipGraphLaunch(ge.exec, stream));
+    if (launch) DNS_HIP(hipGraphLaunch(ge.exec, stream));
     return DNS_OK;
 }
 
@@ -1090,9 +1092,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     return DNS_OK;
 }
 
-int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
-                      dns_solve_stats *st, const std::function<int()> &prologue,
-                      uint64_t prologue_key, bool prologue_has_resid) {
+int dns_saddle::ensure_solver_buffers(const dns_solve_opts *o) {
     const int m = std::max(1, std::min(o->restart, kMaxRestart));
     DNS_TRY(ensure_workspace(m));
     const size_t need_hist = (size_t)o->maxiter + 2 * kMaxRestart + 8;
@@ -1102,6 +1102,14 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
         DNS_TRY(histdev.alloc(need_hist));
     }
     hist_cap = histdev.n;
+    return DNS_OK;
+}
+
+int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
+                      dns_solve_stats *st, const std::function<int()> &prologue,
+                      uint64_t prologue_key, bool prologue_has_resid) {
+    const int m = std::max(1, std::min(o->restart, kMaxRestart));
+    DNS_TRY(ensure_solver_buffers(o));
     // RCCL calls are issued eagerly between the kernels (no graph capture)
     const bool graph = o->use_graph != 0 && !dist();
     // first cycle length: what the previous solve needed plus slack (time
@@ -1725,6 +1733,33 @@ int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi) {
     if (!h || !lo || !hi) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     *lo = h->lam_lo;
     *hi = h->lam_hi;
+    return DNS_OK;
+}
+
+int dns_saddle_precond_info(dns_saddle *h, int32_t cap, int64_t *out,
+                            int32_t *count) {
+    if (!h || !count) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    if (!h->precond_ready)
+        return fail(DNS_ERR_NOT_READY, "preconditioner not set up");
+    std::vector<int64_t> v = {h->K.nnz,
+                              h->fhat_explicit ? h->Gc.nnz : 0,
+                              h->have_jg ? h->JG.nnz : 0,
+                              (int64_t)h->np,
+                              (int64_t)h->fp32_store,
+                              (int64_t)h->popts.cheb_degree,
+                              (int64_t)h->popts.schur};
+    const int L = (h->popts.schur == DNS_SCHUR_MG) ? (int)h->mg.size() : 0;
+    v.push_back(L);
+    v.push_back(h->mg_nu);
+    for (int l = 0; l < L; ++l) {
+        v.push_back(h->mg[l].n);
+        v.push_back(l + 1 < L ? h->mg[l].S.nnz : 0);
+        v.push_back(l + 1 < L ? h->mg[l].P.nnz : 0);
+    }
+    *count = (int32_t)v.size();
+    if (out)
+        for (int32_t i = 0; i < std::min<int32_t>(cap, *count); ++i)
+            out[i] = v[i];
     return DNS_OK;
 }
 

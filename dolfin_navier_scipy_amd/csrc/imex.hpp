@@ -33,6 +33,38 @@ struct dns_imex {
     dns_conv *conv = nullptr;      // device convection: nfc_c = scale*N(v_c)v_c
     double conv_scale = -1.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    // pipelined batches: what the last batch learnt is kept across
+    // dns_imex_run calls (a run is then 100 % graph replays from its first
+    // step on -- the driver's 20-step window sees what a 400-step window sees)
+    int cpred = -1;                // predicted cycle length of a batch
+    bool noslack = false;
+    int noslack_hold = 1;
+    int batch_len = 8;             // steps per batch: 8 -> 16 -> 32 while the
+                                   // predictions hold
+    uint64_t prepared_sig = 0;     // configuration the graphs were captured for
+    // record of the last dns_imex_run (dns_imex_run_info)
+    int run_unconverged = 0, run_first_bad = -1, run_replayed = 0;
+    int run_captures = 0;          // graphs captured inside the last run
+    // knobs read ONCE, when the stepper is created
+    bool env_step_history = false, env_debug = false, env_slack_adapt = true;
+    int env_group = 4;
+    struct HostState {
+        int cur, prev, pprev, p3, p4, work, nsol, nc, no;
+        long steps_enqueued;
+    };
+    HostState host_state() const {
+        return {cur, prev, pprev, p3, p4, work, nsol, nc, no, steps_enqueued};
+    }
+    void set_host_state(const HostState &s) {
+        cur = s.cur; prev = s.prev; pprev = s.pprev; p3 = s.p3; p4 = s.p4;
+        work = s.work; nsol = s.nsol; nc = s.nc; no = s.no;
+        steps_enqueued = s.steps_enqueued;
+    }
+    std::vector<uint64_t> group_key(const dns_imex_coeffs *cf,
+                                    const dns_solve_opts *o, int group) const;
+    int enqueue_group(const dns_imex_coeffs *cf, const dns_solve_opts *o,
+                      int group, bool launch);
+    int prepare_graphs(const dns_imex_coeffs *cf, const dns_solve_opts *o);
     ~dns_imex() {
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);

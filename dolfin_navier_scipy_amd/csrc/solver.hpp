@@ -337,9 +337,17 @@ struct dns_saddle {
     int enqueue_cycle(const double *b, double *x, int c,
                       const dns_solve_opts *o, int first, bool have_resid);
     // run `body` eagerly or as a cached graph identified by `key`
+    // launch == false: capture + instantiate only (set-up time), nothing runs
     template <typename Body>
     int run_cached(const std::vector<uint64_t> &key, bool use_graph,
-                   Body body);
+                   Body body, bool launch = true);
+    bool have_graph(const std::vector<uint64_t> &key) const {
+        for (const auto &g : graphs)
+            if (g.key == key) return true;
+        return false;
+    }
+    int64_t graph_captures = 0;       // captures + instantiations so far
+    int64_t graph_generation = 0;     // bumped whenever the cache is dropped
     void drop_graphs();
 
     ~dns_saddle();
@@ -351,6 +359,7 @@ struct dns_saddle {
     int build_jacobi_schur();
     int invert_dense(double *a, int nn);
     int ensure_workspace(int m);
+    int ensure_solver_buffers(const dns_solve_opts *o);   // basis + history
     // z = P^-1 r (device pointers); `xacc` != null: also x += z
     int apply_precond(const double *rvec, double *zout, const int *guard,
                       double *xacc);

@@ -47,11 +47,27 @@ def clear_cache():
     del _cache_order[:]
 
 
-def _pattern_key(amat, jmat):
+def _pattern_key(amat, jmat, jmatT=None, prolongations=None):
+    """pattern of `amat` (its values may change under a cached system) and
+    everything that is uploaded ONCE per resident system -- pattern AND values
+    of `jmat`, of a user-supplied `jmatT` and of the prolongations: the same
+    pattern with a different `J` (rescaled divergence block, moved geometry)
+    is a different system, as it is for the reference's `lau`, which always
+    uses the matrices handed to it"""
     hsh = hashlib.blake2b(digest_size=16)
     for arr in (amat.indptr, amat.indices, jmat.indptr, jmat.indices):
         hsh.update(np.ascontiguousarray(arr, dtype=np.int32).tobytes())
-    return (amat.shape, jmat.shape, amat.nnz, jmat.nnz, hsh.hexdigest())
+    hsh.update(np.ascontiguousarray(jmat.data, dtype=np.float64).tobytes())
+    extra = [] if jmatT is None else [jmatT]
+    extra += list(prolongations or [])
+    for mat in extra:
+        mat = sps.csr_matrix(mat)
+        hsh.update(np.ascontiguousarray(mat.indptr, dtype=np.int32).tobytes())
+        hsh.update(np.ascontiguousarray(mat.indices,
+                                        dtype=np.int32).tobytes())
+        hsh.update(np.ascontiguousarray(mat.data, dtype=np.float64).tobytes())
+    return (amat.shape, jmat.shape, amat.nnz, jmat.nnz, jmatT is not None,
+            len(extra), hsh.hexdigest())
 
 
 def _canonical(mat):
@@ -81,16 +97,17 @@ def _get_system(amat, jmat, jmatT, krplsprms):
     values and keeps the preconditioner unless the diagonal moved by more
     than `refresh_tol`"""
     amat, jmat = _canonical(amat), _canonical(jmat)
-    key = _pattern_key(amat, jmat)
+    prols = (krplsprms or {}).get('prolongations')
+    key = _pattern_key(amat, jmat, jmatT, prols)
     pkw = _precond_kwargs(jmat.shape[0], krplsprms, NV=jmat.shape[1])
+    if prols is not None:           # nested pressure spaces: multigrid Schur
+        pkw['schur'] = 'mg'
     diag = amat.diagonal()
     ent = _cache.get(key)
     if ent is None:
         system = SaddleSystem(amat, jmat, JT=jmatT, device=DEFAULTS['device'])
-        prols = (krplsprms or {}).get('prolongations')
-        if prols is not None:       # nested pressure spaces: multigrid Schur
+        if prols is not None:
             system.set_schur_mg(prols)
-            pkw['schur'] = 'mg'
         system.setup_precond(**pkw)
         ent = _Entry(system, diag, pkw)
         _cache[key] = ent

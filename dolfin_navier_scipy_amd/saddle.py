@@ -114,6 +114,23 @@ class SaddleSystem(object):
                                                 ct.byref(hi)))
         return lo.value, hi.value
 
+    def precond_info(self):
+        """sizes of the resident preconditioner (bench.py's byte counts)"""
+        buf = (ct.c_int64*64)()
+        cnt = ct.c_int32(0)
+        C.check(self.lib.dns_saddle_precond_info(self._h, 64, buf,
+                                                 ct.byref(cnt)))
+        v = list(buf[:cnt.value])
+        out = dict(nnz_K=v[0], nnz_Gc=v[1], nnz_JG=v[2], NP=v[3],
+                   fp32_store=bool(v[4]), cheb_degree=v[5],
+                   schur={0: 'dense', 1: 'jacobi', 2: 'mg'}[v[6]],
+                   NV=self.NV, nnz_F=int(self._f.data.size),
+                   nnz_J=int(self._j.data.size), mg_nu=v[8], mg_levels=[])
+        for l in range(v[7]):
+            n, nnzs, nnzp = v[9 + 3*l:12 + 3*l]
+            out['mg_levels'].append(dict(n=n, nnz_S=nnzs, nnz_P=nnzp))
+        return out
+
     def solve(self, rhsv, rhsp=None, x0=None, raise_on_fail=True, **kw):
         """returns `[v; p~]` as a 1-D array of length NV+NP"""
         o = kw.pop('opts', None)
@@ -232,17 +249,31 @@ class ImexStepper(object):
                                  '{0}'.format(self.last_stats))
         return self.last_stats
 
-    def run(self, nsteps, cf, opts=None):
-        """`nsteps` steps with frozen convection history; returns
-        `(device_seconds, total_iters, last_stats)`"""
+    def run(self, nsteps, cf, opts=None, raise_on_fail=True):
+        """`nsteps` steps without host callbacks (device convection if
+        attached, else the convection history stays frozen); returns
+        `(device_seconds, total_iters, last_stats)`.  `last_run` then holds the
+        record of the call: time steps whose solve ended at `maxiter`
+        (`unconverged`, `first_bad`), steps repeated after a mispredicted
+        batch (`replayed`) and graphs captured inside the call (`captures`).
+        Raises `NotConverged` if any step did not converge, like `step()`."""
         o = solve_opts() if opts is None else opts
         st = C.dns_solve_stats()
         secs = ct.c_double(0.)
         its = ct.c_int64(0)
-        C.check(self.lib.dns_imex_run(self._h, int(nsteps), ct.byref(cf),
-                                      ct.byref(o), ct.byref(st),
-                                      ct.byref(secs), ct.byref(its)))
+        status = self.lib.dns_imex_run(self._h, int(nsteps), ct.byref(cf),
+                                       ct.byref(o), ct.byref(st),
+                                       ct.byref(secs), ct.byref(its))
+        if status != C.DNS_NOT_CONVERGED:
+            C.check(status)
         self.last_stats = st.asdict()
+        vals = [ct.c_int32(0) for _ in range(4)]
+        C.check(self.lib.dns_imex_run_info(self._h,
+                                           *[ct.byref(v) for v in vals]))
+        self.last_run = dict(zip(('unconverged', 'first_bad', 'replayed',
+                                  'captures'), [v.value for v in vals]))
+        if status == C.DNS_NOT_CONVERGED and raise_on_fail:
+            C.check(status)
         return secs.value, its.value, self.last_stats
 
     def get_state(self):

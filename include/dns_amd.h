@@ -174,6 +174,14 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                      int32_t reps, double *us_per_launch);
 /* eigenvalue bounds used by the Chebyshev iteration */
 int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi);
+/* sizes of what the preconditioner keeps resident (for the published
+ * per-step byte counts of bench.py): out[0..] = nnz(K), nnz(Gc) (0: recurrence
+ * form), nnz(J Fh^-1) (0: triangular form), NP, fp32_store, cheb_degree,
+ * schur kind, L = multigrid levels, smoothing steps, then per level l < L: n_l,
+ * nnz(S_l), nnz(P_l) (0 on the coarsest).  `count` = entries available; at most `cap`
+ * are written */
+int dns_saddle_precond_info(dns_saddle *h, int32_t cap, int64_t *out,
+                            int32_t *count);
 void dns_default_precond_opts(dns_precond_opts *o);
 void dns_default_solve_opts(dns_solve_opts *o);
 
@@ -252,11 +260,24 @@ int dns_imex_set_rhs(dns_imex *st, const double *gvec, const double *rhs_p);
 int dns_imex_step(dns_imex *st, const double *nfc_new,
                   const dns_imex_coeffs *cf, const dns_solve_opts *opts,
                   dns_solve_stats *stats);
-/* `nsteps` steps back to back with the convection history frozen (the linear
- * algebra of the step alone); total HIP-event time on the handle's stream */
+/* `nsteps` steps back to back without host callbacks (convection evaluated on
+ * the device if an operator is attached, else its history stays frozen); HIP-
+ * event time of the stepping loop on the handle's stream.  With GMRES and
+ * `use_graph` the steps are pipelined: a fresh stepper first does up to four
+ * synchronous steps (extrapolation history), then every graph the loop can ask
+ * for is captured (six ring states x cycle lengths), then batches of steps are
+ * replayed without host synchronisation; the ring, the predicted cycle length
+ * and the graphs persist across calls, so a later call starts replaying at
+ * once.  Returns DNS_NOT_CONVERGED (state advanced, outputs filled) if some
+ * step ended at `maxiter`: see dns_imex_run_info. */
 int dns_imex_run(dns_imex *st, int32_t nsteps, const dns_imex_coeffs *cf,
                  const dns_solve_opts *opts, dns_solve_stats *last_stats,
                  double *device_seconds, int64_t *total_iters);
+/* record of the last dns_imex_run: steps that did not converge and the first
+ * of them (index within the run, -1: none), steps that were repeated because
+ * a batch mispredicted its cycle length, graphs captured inside the call */
+int dns_imex_run_info(dns_imex *st, int32_t *unconverged, int32_t *first_bad,
+                      int32_t *replayed, int32_t *captures);
 /* v (NV) and p = pscale*p~ (NP) of the current state */
 int dns_imex_get_state(dns_imex *st, double *v, double *p);
 /* ||v||_2 of the current velocity (blow-up guard, tiu:94-103) */

@@ -61,7 +61,11 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True):
     _capi.device_synchronize(0)
     wall = time.perf_counter() - t0
     v_gpu, p_gpu = stp.get_state()
-    out = dict(refine=refine, NV=int(NV), NP=int(NP), n=int(NV + NP), dt=dt,
+    from dolfin_navier_scipy_amd import perfmodel
+    roof = perfmodel.step_roofline(system.precond_info(), int(R1.nnz),
+                                   int(th.mesh.ncells), its/float(nsteps),
+                                   1e3*wall/nsteps)
+    out = dict(refine=refine, roofline_step=roof, NV=int(NV), NP=int(NP), n=int(NV + NP), dt=dt,
                steps=nsteps, gpu_steps_per_s=nsteps/wall,
                gpu_ms_per_step=1e3*wall/nsteps,
                krylov_iters_per_step=its/float(nsteps),

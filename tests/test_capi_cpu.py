@@ -156,3 +156,31 @@ def test_pressure_prolongations_of_a_refined_mesh():
         xf = np.empty(fs.pdim)
         xf[fs.vert_pdof] = 2*fs.mesh.verts[:, 0] - fs.mesh.verts[:, 1] + 3
         assert np.abs(P @ xc - xf).max() < 1e-12
+
+
+def test_build_dependencies_cover_every_include():
+    """`needs_build()` must see every file the translation unit includes
+    (a hand-kept list once missed trap.hpp / trap_capi.inc)"""
+    from dolfin_navier_scipy_amd import build
+    deps = set(os.path.realpath(p) for p in build.dependencies())
+    seen, todo = set(), [os.path.join(build.CSRC, s) for s in build.SOURCES]
+    while todo:
+        path = os.path.realpath(todo.pop())
+        if path in seen:
+            continue
+        seen.add(path)
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(path).read()):
+            todo.append(os.path.join(os.path.dirname(path), inc))
+    assert len(seen) > 10
+    missing = seen - deps
+    assert not missing, missing
+
+
+def test_spawn_retry_only_for_rendezvous_errors():
+    import spawn_util
+    assert spawn_util.is_rendezvous_error(
+        RuntimeError('The server socket has failed to bind to [::]:29500 '
+                     '(errno: 98 - Address already in use)'))
+    assert not spawn_util.is_rendezvous_error(
+        RuntimeError('process 1 terminated with signal SIGABRT'))
+    assert not spawn_util.is_rendezvous_error(AssertionError('1e-3 > 1e-9'))

@@ -95,13 +95,6 @@ def _worker(rank, world, port, outdir):
 
 
 def test_world2_partition_collectives_and_model(tmp_path):
-    import torch.multiprocessing as mp
-    for attempt in range(2):         # one retry: a rendezvous port can race
-        try:
-            mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2,
-                     join=True)
-            break
-        except Exception:
-            if attempt == 1:
-                raise
+    from spawn_util import spawn_ranks
+    spawn_ranks(_worker, 2, str(tmp_path))
     assert os.path.exists(tmp_path / 'ok0') and os.path.exists(tmp_path / 'ok1')

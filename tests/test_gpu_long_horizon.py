@@ -1,0 +1,145 @@
+"""Long-horizon parity: BASELINE config 2 as the reference script runs it
+(`tests/time_dep_nse_expnonl.py:57-58`: cylinder wake N=2, Re=80, tE=1,
+Nts=512, Taylor-Hood, explicit nonlinearity) -- ALL 512 steps, device
+convection, against the CPU oracle's factor-once CNAB loop (tiu:104-143).
+
+A Krylov solve stopped at `rtol` leaves a per-step error of one sign, so the
+distance to the direct-solve trajectory grows linearly with the number of
+steps; the test pins the horizon the default settings are good for:
+velocities 1e-8 in the M-norm, pressures 1e-6 (p = -p~/dt amplifies by 1/dt).
+"""
+import numpy as np
+import pytest
+
+import scenarios
+from oracle import imex_oracle, saddle_oracle
+
+pytestmark = pytest.mark.gpu
+
+VTOL, PTOL = 1e-8, 1e-6
+NTS = 512
+
+
+@pytest.fixture(scope='module')
+def wake():
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    from dolfin_navier_scipy_amd import _capi
+    assert _capi.device_count() > 0, 'HIP device required for -m gpu tests'
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=80)
+    th, inv = femp['V'], femp['invinds']
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    vp0 = saddle_oracle.solve_sadpnt_smw(amat=A, jmat=J, rhsv=rhsd['fv'],
+                                         rhsp=rhsd['fp'])     # snu:903-907
+    inivel, inip = vp0[:NV], -vp0[NV:]
+    dbcinds, dbcvals = femp['dbcinds'], femp['dbcvals']
+
+    def appnd(vvec, bcs):
+        full = np.full((th.vdim, 1), np.nan)
+        full[inv] = vvec
+        full[dbcinds, 0] = dbcvals
+        return full
+
+    def f_vdp(vf):
+        return -th.convection_vec(vf)[inv, :]
+
+    def make_kw(rec, nts=NTS):
+        return dict(trange=np.linspace(0, 1., NTS + 1)[:nts + 1],
+                    inivel=inivel, inip=inip, bcs_ini=[], M=M, A=A, J=J,
+                    f_vdp=f_vdp, f_tdp=lambda t: rhsd['fv'],
+                    g_tdp=lambda t: rhsd['fp'], scalep=-1.,
+                    getbcs=lambda t, v, p, mode=None: [],
+                    applybcs=lambda b: (0., 0., 0.), appndbcs=appnd,
+                    savevp=rec, check_ff_maxv=1e8, verbose=False)
+    ro = scenarios.Recorder()
+    vo, po, _ = imex_oracle.cnab(**make_kw(ro))
+    return dict(femp=femp, sm=sm, rhsd=rhsd, make_kw=make_kw, vo=vo, po=po,
+                ro=ro, inivel=inivel, f_vdp=f_vdp, appnd=appnd)
+
+
+def _mnorm(M, x):
+    return float(np.sqrt((x.T @ (M @ x)).item()))
+
+
+def test_cnab_512_steps_default_settings(wake):
+    """the drop-in `time_int_utils.cnab` with `SOLVER` untouched"""
+    from dolfin_navier_scipy_amd import time_int_utils as gtiu
+    from dolfin_navier_scipy_amd import convection
+    femp, M = wake['femp'], wake['sm']['M']
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+    rg = scenarios.Recorder()
+    kw = wake['make_kw'](rg)
+    kw.pop('f_vdp')
+    vg, pg, ff = gtiu.cnab(device_convection=cvop, invinds=femp['invinds'],
+                           **kw)
+    cvop.close()
+    assert ff == 0
+    ev = _mnorm(M, vg - wake['vo'])/_mnorm(M, wake['vo'])
+    ep = np.linalg.norm(pg - wake['po'])/np.linalg.norm(wake['po'])
+    print('cnab 512 steps (SOLVER defaults): v', ev, 'p', ep)
+    assert ev <= VTOL, ev
+    assert ep <= PTOL, ep
+    # and along the way (every 64th saved step)
+    to, vso, pso = wake['ro'].arrays()
+    tg, vsg, psg = rg.arrays()
+    assert np.array_equal(to, tg)
+    inv = femp['invinds']
+    for k in range(64, NTS + 1, 64):
+        d = (vsg[k] - vso[k])[inv].reshape((-1, 1))
+        r = vso[k][inv].reshape((-1, 1))
+        assert _mnorm(M, d) <= VTOL*_mnorm(M, r), k
+
+
+def test_pipelined_run_512_steps_bench_settings(wake):
+    """the resident loop as `bench.py` drives it (`ImexStepper.run`, pipelined
+    graph batches, bench.py's solver defaults) over the same 512 steps"""
+    import bench
+    from dolfin_navier_scipy_amd import saddle, convection
+    femp, sm, rhsd = wake['femp'], wake['sm'], wake['rhsd']
+    M, A, J = sm['M'], sm['A'], sm['J']
+    dt = 1./NTS
+    dflt = bench.DEFAULTS
+    # Heun start with the oracle (one step), then 511 resident steps
+    ro = scenarios.Recorder()
+    kw = wake['make_kw'](ro, nts=2)
+    (v1, p1, _, _, _, _, _, nfc0, nfc1, _, _) = imex_oracle.heun_start(
+        vc=kw['inivel'], pc=kw['inip'], tc=0., tn=dt, M=M, A=A, J=J,
+        scalep=-1., dfv_c=0., dynamic_rhs=lambda t, vc=None, memory={},
+        mode=None: (np.zeros_like(kw['inivel']), memory), drm={}, bcs_c=[],
+        applybcs=kw['applybcs'], appndbcs=kw['appndbcs'], getbcs=kw['getbcs'],
+        f_tdp=kw['f_tdp'], f_vdp=kw['f_vdp'], g_tdp=kw['g_tdp'])
+    system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    system.setup_precond(cheb_degree=dflt['cheb'], schur='dense',
+                         fp32_store=bool(dflt['fp32']), drop_tol=dflt['drop'],
+                         factorization=dflt['fact'])
+    stp = saddle.ImexStepper(system, (M - .5*dt*A).tocsr())
+    # nfc_c = N(v_0): the first resident step evaluates N(v_1) itself
+    stp.set_state(v1, ptilde_c=-dt*p1, nfc_c=nfc0)
+    stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+    stp.set_convection(cvop, scale=-1.0)
+    cf = saddle.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                   pscale=-1./dt, extrapolate=dflt['extrap'])
+    opts = saddle.solve_opts(method='gmres', rtol=dflt['rtol'], maxiter=400,
+                             restart=60, check_every=2, use_graph=True,
+                             reorth=dflt['reorth'])
+    # in three calls: the ring, the prediction and the graphs persist
+    total = 0
+    for n in (5, 20, NTS - 1 - 25):
+        _, its, last = stp.run(n, cf, opts)
+        total += its
+        if n == 20:
+            assert stp.last_run['captures'] == 0, stp.last_run
+    vg, pg = stp.get_state()
+    print('run 511 steps (bench defaults): iters/step', total/float(NTS - 1),
+          stp.last_run)
+    stp.close()
+    cvop.close()
+    system.close()
+    ev = _mnorm(M, vg - wake['vo'])/_mnorm(M, wake['vo'])
+    ep = np.linalg.norm(pg - wake['po'])/np.linalg.norm(wake['po'])
+    print('pipelined 512 steps: v', ev, 'p', ep)
+    assert ev <= VTOL, ev
+    assert ep <= PTOL, ep

@@ -138,17 +138,10 @@ def _worker(rank, world, port, outdir):
 
 
 def test_two_ranks_one_gpu_gloo_staged(tmp_path):
-    import torch.multiprocessing as mp
     from dolfin_navier_scipy_amd import saddle
     from oracle import saddle_oracle
-    for attempt in range(2):         # one retry: a rendezvous port can race
-        try:
-            mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2,
-                     join=True)
-            break
-        except Exception:
-            if attempt == 1:
-                raise
+    from spawn_util import spawn_ranks
+    spawn_ranks(_worker, 2, str(tmp_path))
     r0 = np.load(tmp_path / 'rank0.npz')
     r1 = np.load(tmp_path / 'rank1.npz')
     pr = _problem()
