@@ -197,6 +197,31 @@ SIGNATURES = {
                                  ct.POINTER(ct.c_int32)]),
     'dns_hbm_probe': (ct.c_int, [ct.c_int, ct.c_int64, ct.c_int32, ct.c_int32,
                                  c_double_p]),
+    'dns_imex_set_rhs_table': (ct.c_int, [_VP, ct.c_int32, c_double_p,
+                                          c_double_p]),
+    'dns_imex_table_position': (ct.c_int, [_VP, c_int32_p, c_int32_p]),
+    'dns_conv_set_dbc_table': (ct.c_int, [_VP, ct.c_int32, c_double_p]),
+    'dns_conv_set_dbc_row': (ct.c_int, [_VP, ct.c_int32]),
+    'dns_conv_assemble2': (ct.c_int, [_VP, c_double_p, c_double_p, c_double_p,
+                                      ct.c_int32, c_double_p, c_double_p,
+                                      c_double_p]),
+    'dns_trap_set_tables': (ct.c_int, [_VP, c_double_p, c_double_p,
+                                       c_double_p]),
+    'dns_trap_step_fb': (ct.c_int, [_VP, ct.c_double, ct.c_int32, ct.c_int32,
+                                    ct.c_int32, ct.c_int32, ct.c_int32,
+                                    ct.POINTER(dns_solve_opts),
+                                    ct.POINTER(dns_solve_stats), ct.c_int32,
+                                    c_double_p, c_double_p, c_double_p]),
+    'dns_op_create': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr),
+                                 ct.POINTER(_VP)]),
+    'dns_op_destroy': (None, [_VP]),
+    'dns_op_apply': (ct.c_int, [_VP, c_double_p, c_double_p, ct.c_double,
+                                ct.c_double]),
+    'dns_bcmap_create': (ct.c_int, [ct.c_int, ct.c_int32, ct.c_int32,
+                                    c_int32_p, ct.c_int32, c_int32_p,
+                                    ct.POINTER(_VP)]),
+    'dns_bcmap_destroy': (None, [_VP]),
+    'dns_bc_scatter': (ct.c_int, [_VP, c_double_p, c_double_p, c_double_p]),
 }
 
 _lib = None

@@ -33,6 +33,7 @@ class ConvectionP2(object):
         inv, dbi = _i32(invinds), _i32(dbcinds)
         self._invinds = inv
         dbv = C.as_f64(dbcvals, size=dbi.size)
+        self.ndbc = int(dbi.size)
         self.nv = inv.size
         self._h = ct.c_void_p()
         C.check(self.lib.dns_conv_create_p2(
@@ -48,8 +49,23 @@ class ConvectionP2(object):
                    dbcvals, device=device)
 
     def set_dbcvals(self, dbcvals):
-        dbv = C.as_f64(dbcvals)
+        """one constant set of Dirichlet values (drops a value table)"""
+        dbv = C.as_f64(dbcvals, size=self.ndbc)
         C.check(self.lib.dns_conv_set_dbcvals(self._h, C.dptr(dbv)))
+
+    def set_dbc_table(self, table):
+        """`(nrows, ndbc)` Dirichlet values per step (IMEX stepper: row s for
+        the s-th step after the stepper's tables were set) or per trajectory
+        slot (trapezoidal sweeps)"""
+        tab = np.ascontiguousarray(table, dtype=np.float64).reshape(
+            (-1, max(self.ndbc, 1)) if self.ndbc else (len(table), 0))
+        nrows = tab.shape[0]
+        flat = C.as_f64(tab) if tab.size else np.zeros(1)
+        C.check(self.lib.dns_conv_set_dbc_table(self._h, int(nrows),
+                                                C.dptr(flat)))
+
+    def set_dbc_row(self, row):
+        C.check(self.lib.dns_conv_set_dbc_row(self._h, int(row)))
 
     def apply(self, v_inner, scale=1.0):
         v = C.as_f64(v_inner, size=self.nv)
@@ -84,18 +100,31 @@ class ConvectionP2(object):
         C.check(self.lib.dns_conv_bind_pattern(self._h, view.byref()))
         self._pattern = view
 
-    def assemble(self, u_inner, newton=False):
+    def assemble(self, u_inner, newton=False, dbcvals_lin=None,
+                 dbcvals_rhs=None):
         """`(N, rhsbc, rhscon)`: `N1(u)` (Picard) or `N1(u) + N2(u)` (Newton)
         condensed, in the bound pattern; `-N[:, bc] bcvals`; `N(u)u`
-        (reference `get_v_conv_conts`, snu:109-133)"""
+        (reference `get_v_conv_conts`, snu:109-133).  `dbcvals_lin` /
+        `dbcvals_rhs`: Dirichlet values of the linearisation field / the ones
+        that go to `rhsbc` (default: the operator's own set)"""
         import scipy.sparse as sps
         u = C.as_f64(u_inner, size=self.nv)
         pv = self._pattern
         nvals = np.empty(pv.data.size)
         rhsbc, rhscon = np.empty(self.nv), np.empty(self.nv)
-        C.check(self.lib.dns_conv_assemble(
-            self._h, C.dptr(u), int(bool(newton)), C.dptr(nvals),
-            C.dptr(rhsbc), C.dptr(rhscon)))
+        if dbcvals_lin is None:
+            C.check(self.lib.dns_conv_assemble(
+                self._h, C.dptr(u), int(bool(newton)), C.dptr(nvals),
+                C.dptr(rhsbc), C.dptr(rhscon)))
+        else:
+            dl = C.as_f64(dbcvals_lin, size=self.ndbc) if self.ndbc else \
+                np.zeros(1)
+            dr = None if dbcvals_rhs is None else (
+                C.as_f64(dbcvals_rhs, size=self.ndbc) if self.ndbc
+                else np.zeros(1))
+            C.check(self.lib.dns_conv_assemble2(
+                self._h, C.dptr(u), C.dptr(dl), C.dptr(dr), int(bool(newton)),
+                C.dptr(nvals), C.dptr(rhsbc), C.dptr(rhscon)))
         N = sps.csr_matrix((nvals, pv.indices, pv.indptr), shape=pv.shape)
         return N, rhsbc.reshape((-1, 1)), rhscon.reshape((-1, 1))
 

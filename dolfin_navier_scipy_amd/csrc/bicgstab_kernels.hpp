@@ -205,8 +205,9 @@ k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
            const double *__restrict__ v_c, const double *__restrict__ v_p,
            double a_c, double a_p, const double *__restrict__ nfc_c,
            const double *__restrict__ nfc_o, double cn_c, double cn_o,
-           const double *__restrict__ g, const double *__restrict__ gp,
-           double *__restrict__ b) {
+           TabRef gtab, TabRef gptab, double *__restrict__ b) {
+    const double *__restrict__ g = tab_row(gtab);
+    const double *__restrict__ gp = tab_row(gptab);
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
@@ -255,14 +256,15 @@ k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
                 const double *__restrict__ x_p4, double e_c, double e_p,
                 double e_pp, double e_p3, double e_p4, double a_c, double a_p,
                 double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
-                double cn_c, double cn_o, const double *__restrict__ g,
-                const double *__restrict__ gp, const int *__restrict__ gptr,
-                const int *__restrict__ gidx,
+                double cn_c, double cn_o, TabRef gtab, TabRef gptab,
+                const int *__restrict__ gptr, const int *__restrict__ gidx,
                 const double *__restrict__ cellvals, double conv_scale,
                 double *__restrict__ b, double *__restrict__ x0,
                 double *__restrict__ r, double *__restrict__ part_rr,
                 double *__restrict__ part_bb) {
     __shared__ double red[4];
+    const double *__restrict__ g = tab_row(gtab);
+    const double *__restrict__ gp = tab_row(gptab);
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);

@@ -14,7 +14,7 @@
 //                  inverted index (dof -> list of (local slot, cell)) and
 //                  applies the sign/scale of the caller (`-1`: goes to the rhs)
 #pragma once
-#include "common.hpp"
+#include "kernels.hpp"
 
 namespace dns {
 
@@ -34,9 +34,9 @@ __global__ void __launch_bounds__(kBlock)
 k_conv_cells(int ncells, const int *__restrict__ cellmap,   // [12][ncells]
              const double *__restrict__ glam,               // [6][ncells]
              const double *__restrict__ area,
-             const double *__restrict__ v_inner,
-             const double *__restrict__ dbcvals,
+             const double *__restrict__ v_inner, TabRef dbctab,
              double *__restrict__ cellvals) {               // [12][ncells]
+    const double *__restrict__ dbcvals = tab_row(dbctab);
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int c = t >> 3;
     const int q = t & 7;
@@ -116,6 +116,19 @@ struct dns_conv {
     int ncells = 0, nv_inner = 0, ndbc = 0;
     dns::DevBuf<int> cellmap, gptr, gidx;
     dns::DevBuf<double> glam, area, dbcvals, cellvals;
+    // Dirichlet values that change from step to step (moving / controlled
+    // boundaries): a table of `dbc_rows` value sets; the row is the device
+    // step counter of the stepper the operator is attached to (`dbc_ctr`) or a
+    // row the host names (`dbc_row`, trapezoidal sweeps: the slot)
+    dns::DevBuf<double> dbc_tab;
+    int dbc_rows = 0, dbc_row = 0;
+    const int *dbc_ctr = nullptr;
+    dns::TabRef dbc_ref(int row_shift = 0) const {
+        if (dbc_rows <= 0) return {dbcvals.p, nullptr, 0, 1};
+        if (dbc_ctr) return {dbc_tab.p, dbc_ctr, std::max(1, ndbc), dbc_rows};
+        const int r = std::min(std::max(dbc_row + row_shift, 0), dbc_rows - 1);
+        return {dbc_tab.p + (size_t)r * std::max(1, ndbc), nullptr, 0, 1};
+    }
     std::vector<int> cmap_host;            // [12][ncells], as on the device
     struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
     ~dns_conv();
@@ -130,7 +143,7 @@ struct dns_conv {
     int enqueue_cells(const double *v_dev, hipStream_t s) {
         const int g1 = (8 * ncells + dns::kBlock - 1) / dns::kBlock;
         hipLaunchKernelGGL(dns::k_conv_cells, g1, dns::kBlock, 0, s, ncells,
-                           cellmap.p, glam.p, area.p, v_dev, dbcvals.p,
+                           cellmap.p, glam.p, area.p, v_dev, dbc_ref(),
                            cellvals.p);
         DNS_HIP(hipGetLastError());
         return DNS_OK;
@@ -169,9 +182,9 @@ __global__ void __launch_bounds__(kBlock)
 k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
                  const double *__restrict__ glam,
                  const double *__restrict__ area,
-                 const double *__restrict__ v_inner,
-                 const double *__restrict__ dbcvals, int newton,
-                 double *__restrict__ L) {                  // [144][ncells]
+                 const double *__restrict__ v_inner, TabRef dbctab,
+                 int newton, double *__restrict__ L) {      // [144][ncells]
+    const double *__restrict__ dbcvals = tab_row(dbctab);
     const int t = blockIdx.x * kBlock + threadIdx.x;
     const int c = t >> 3;
     const int a = t & 7;
@@ -265,9 +278,9 @@ k_conv_mat_gather(int nnz, const int *__restrict__ mptr,
 __global__ void __launch_bounds__(kBlock)
 k_conv_bc_gather(int nrows, const int *__restrict__ bptr,
                  const int *__restrict__ bidx, const int *__restrict__ bbc,
-                 const double *__restrict__ L,
-                 const double *__restrict__ dbcvals,
+                 const double *__restrict__ L, TabRef dbctab,
                  double *__restrict__ rhsbc) {
+    const double *__restrict__ dbcvals = tab_row(dbctab);
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < nrows;
          r += gridDim.x * kBlock) {
         double s = 0.0;
@@ -292,7 +305,7 @@ inline int dns_conv::enqueue_mat_cells(const double *v_dev, int newton,
                                        hipStream_t s) {
     const int g = (8 * ncells + dns::kBlock - 1) / dns::kBlock;
     hipLaunchKernelGGL(dns::k_conv_mat_cells, g, dns::kBlock, 0, s, ncells,
-                       cellmap.p, glam.p, area.p, v_dev, dbcvals.p, newton,
+                       cellmap.p, glam.p, area.p, v_dev, dbc_ref(), newton,
                        mat->L.p);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
@@ -315,7 +328,7 @@ inline int dns_conv::enqueue_bc_gather(double *rhsbc, hipStream_t s) {
                                            dns::kBlock, 2048));
     hipLaunchKernelGGL(dns::k_conv_bc_gather, g, dns::kBlock, 0, s, nv_inner,
                        mat->bptr.p, mat->bidx.p, mat->bbc.p, mat->L.p,
-                       dbcvals.p, rhsbc);
+                       dbc_ref(), rhsbc);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

@@ -466,14 +466,15 @@ int dns_saddle::build_explicit(bool dense_schur) {
         fprintf(stderr, "[dns] setup %-28s %8.1f ms\n", what, 1e3 * (t1 - t0));
         t0 = t1;
     };
+    const HostCsr &Fsrc = pc_sym ? Fpc_h : Fh;
     std::vector<double> dv((size_t)nv, 1.0);
     for (int i = 0; i < nv; ++i) {
         double d = 0.0;
-        for (int k = Fh.rowptr[i]; k < Fh.rowptr[i + 1]; ++k)
-            if (Fh.colidx[k] == i) d += Fh.vals[k];
+        for (int k = Fsrc.rowptr[i]; k < Fsrc.rowptr[i + 1]; ++k)
+            if (Fsrc.colidx[k] == i) d += Fsrc.vals[k];
         dv[i] = (d != 0.0) ? 1.0 / d : 1.0;
     }
-    HostCsr DF = Fh;
+    HostCsr DF = Fsrc;
     host_scale_rows(dv, DF);
     // (with drop_tol == 0 the zero entries of the pattern of F^(k-1) stay)
     HostCsr G = host_cheb_poly(DF, dv, theta, c1, c2, popts.drop_tol);
@@ -716,11 +717,56 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     // the set-up is done redundantly and in full by every rank (identical
     // preconditioners without any communication); applies are partitioned
     dist_active = false;
+    pc_sym = false;
+    skew_eta = pc_shift = 0.0;
     if (popts.eig_lo > 0.0 && popts.eig_hi > popts.eig_lo) {
         lam_lo = popts.eig_lo;
         lam_hi = popts.eig_hi;
     } else {
         DNS_TRY(estimate_bounds());
+        // Nonsymmetric F: the eigenvalues of D^-1 F leave the real axis by up
+        // to eta (Bendixson).  The Chebyshev residual polynomial is bounded by
+        // one only inside the ellipse with foci lam_lo, lam_hi through the
+        // origin, whose minor semi-axis is sqrt(lam_lo lam_hi): beyond it the
+        // "approximate inverse" AMPLIFIES (a mode at the low end with
+        // Im = 0.05 is multiplied by ~10 at degree 12) and GMRES stagnates --
+        // the steady Oseen / Newton systems A + N(v) of snu:458,497 at cell
+        // Peclet numbers > 1 (eta ~ 2.4 at Re = 50 on cylinder_2).  Then the
+        // polynomial is built for the symmetric part of F, shifted by sigma D
+        // if that part is indefinite (Newton: the strain of the linearisation
+        // point); K keeps the true F, GMRES deals with the skew part (a few
+        // hundred Krylov steps at Re = 50, none of them can blow up).
+        const HostCsr FTh = host_transpose(Fh);
+        skew_eta = host_skew_radius(Fh, FTh);
+        if (skew_eta * skew_eta > 0.25 * lam_lo * lam_hi) {
+            if (nv > 1000000 || popts.cheb_degree < 2 || popts.cheb_degree > 12)
+                return fail(DNS_ERR_BAD_ARGUMENT,
+                            "convection-dominated F (skew radius %.2e against "
+                            "Chebyshev bounds [%.2e, %.2e]): needs the "
+                            "explicit polynomial (degree 2..12, NV <= 1e6)",
+                            skew_eta, lam_lo, lam_hi);
+            Fpc_h = host_add(0.5, Fh, 0.5, FTh);
+            double lmin = 0.0, lmax = 1.0;
+            host_jacobi_bounds(Fpc_h, &lmin, &lmax);
+            const double floor_lo = 0.012 * lmax;
+            if (lmin < floor_lo) {
+                pc_shift = floor_lo - lmin;
+                for (int i = 0; i < nv; ++i)
+                    for (int k = Fpc_h.rowptr[i]; k < Fpc_h.rowptr[i + 1]; ++k)
+                        if (Fpc_h.colidx[k] == i)
+                            Fpc_h.vals[k] *= 1.0 + pc_shift;
+                // (D changes with the shift: bounds of the shifted matrix)
+                host_jacobi_bounds(Fpc_h, &lmin, &lmax);
+            }
+            lam_lo = popts.eig_lo_safety * lmin;
+            lam_hi = popts.eig_hi_safety * lmax;
+            pc_sym = true;
+            if (getenv("DNS_DEBUG"))
+                fprintf(stderr,
+                        "[dns] setup: skew radius %.3e -> polynomial of the "
+                        "symmetric part, shift %.3e, bounds [%.3e, %.3e]\n",
+                        skew_eta, pc_shift, lam_lo, lam_hi);
+        }
     }
     theta = 0.5 * (lam_hi + lam_lo);
     delta = 0.5 * (lam_hi - lam_lo);
@@ -747,7 +793,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
                     "dense Schur inverse too large for NP=%d", np);
     // explicit polynomial matrix: worth it while the apply is launch-latency
     // bound (pattern of F^(k-1): more bytes, far fewer dependent launches)
-    fhat_explicit = (popts.fhat == DNS_FHAT_EXPLICIT) ||
+    fhat_explicit = (popts.fhat == DNS_FHAT_EXPLICIT) || pc_sym ||
                     (popts.fhat == DNS_FHAT_AUTO && nv <= 1000000 &&
                      popts.cheb_degree >= 2 && popts.cheb_degree <= 12);
     fp32_store = popts.fp32_store != 0;
@@ -962,7 +1008,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)nullptr, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (j == 0) ? first : 0, (const double *)nullptr);
+                               (j == 0) ? first : 0, (const double *)nullptr,
+                               (j == 0 && first == 1) ? step_counter : nullptr);
         } else if (fusedgs && j > 0) {
             if (dense && fp32_store)
                 hipLaunchKernelGGL(k_arn_head_f<2>, gridA, kBlock, 0, stream, n,
@@ -984,19 +1031,22 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv32.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (j == 0) ? first : 0, tin);
+                               (j == 0) ? first : 0, tin,
+                               (j == 0 && first == 1) ? step_counter : nullptr);
         else if (dense)
             hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (j == 0) ? first : 0, tin);
+                               (j == 0) ? first : 0, tin,
+                               (j == 0 && first == 1) ? step_counter : nullptr);
         else
             hipLaunchKernelGGL(k_arn_head<0>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
                                (const void *)sinv.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
-                               (j == 0) ? first : 0, tin);
+                               (j == 0) ? first : 0, tin,
+                               (j == 0 && first == 1) ? step_counter : nullptr);
         if (mgs) {
             // Schur block = V-cycle on V_j,p (or tau(V_j))
             const double *sin = V.p + (size_t)j * ld + nv;
@@ -1982,4 +2032,5 @@ int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
 
 #include "imex_capi.inc"
 #include "trap_capi.inc"
+#include "ops_capi.inc"
 #include "conv_capi.inc"

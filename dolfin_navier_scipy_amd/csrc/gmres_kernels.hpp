@@ -119,7 +119,10 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
            double *__restrict__ zp, DnsCtl *ctl, double rtol, double atol,
            const double *__restrict__ bb_part, int bb_nparts, int maxiter,
            int prow0, int prow1, int first,
-           const double *__restrict__ sp_in) {
+           const double *__restrict__ sp_in, int *stepctr = nullptr) {
+    // stepctr (first cycle of a time step's solve only): the device step
+    // counter behind the rhs / boundary-value tables; every kernel of the step
+    // that reads a table row has run before this one
     // sp_in (full block factorisation): tau(src) = src_p - J Fh^-1 src_v
     // replaces src_p as the input of the Schur block
     // `first` (only with j == 0): 1 = first cycle of a solve -- the counters of
@@ -169,6 +172,7 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
                 ctl->total_it = 0;
                 ctl->hist_len = 0;
                 ctl->conv = 0;
+                if (stepctr) *stepctr += 1;
             }
             if (first) ctl->status = DNS_OK;
             ctl->predone = 0;

@@ -332,6 +332,93 @@ inline double host_jacobi_lmax(const HostCsr &A, int iters = 20) {
     return lam;
 }
 
+// y = A x (host, set-up time only)
+inline void host_spmv(const HostCsr &A, const std::vector<double> &x,
+                      std::vector<double> &y) {
+    y.assign((size_t)A.nrows, 0.0);
+    for (int i = 0; i < A.nrows; ++i) {
+        double s = 0.0;
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+            s += A.vals[k] * x[A.colidx[k]];
+        y[i] = s;
+    }
+}
+
+// Bounds (lmin, lmax) of the spectrum of D^-1 A, D = diag(A), for a matrix with
+// real eigenvalues (A symmetric): power iteration for lmax, shifted power
+// iteration for lmin -- the host twin of dns_saddle::estimate_bounds
+inline void host_jacobi_bounds(const HostCsr &A, double *lmin, double *lmax) {
+    const int n = A.nrows;
+    std::vector<double> d((size_t)n, 1.0), x((size_t)n), y;
+    for (int i = 0; i < n; ++i)
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+            if (A.colidx[k] == i && A.vals[k] != 0.0) d[i] = 1.0 / A.vals[k];
+    auto norm = [&](const std::vector<double> &v) {
+        double s = 0.0;
+        for (double e : v) s += e * e;
+        return std::sqrt(s);
+    };
+    for (int i = 0; i < n; ++i) x[i] = 1.0 + 0.5 * std::sin(0.37 * i + 7.0);
+    double lam = 1.0;
+    for (int it = 0; it < 30; ++it) {
+        host_spmv(A, x, y);
+        for (int i = 0; i < n; ++i) y[i] *= d[i];
+        const double nx = norm(x), ny = norm(y);
+        lam = ny / nx;
+        for (int i = 0; i < n; ++i) x[i] = y[i] / ny;
+    }
+    *lmax = lam;
+    const double shift = 1.05 * lam;
+    for (int i = 0; i < n; ++i) x[i] = 1.0 + 0.5 * std::cos(0.61 * i + 7.0);
+    double mu = 0.0;
+    for (int it = 0; it < 80; ++it) {
+        host_spmv(A, x, y);
+        for (int i = 0; i < n; ++i) y[i] = shift * x[i] - d[i] * y[i];
+        const double nx = norm(x), ny = norm(y);
+        if (!(ny > 0.0) || !(nx > 0.0)) break;
+        mu = ny / nx;
+        for (int i = 0; i < n; ++i) x[i] = y[i] / ny;
+    }
+    *lmin = shift - mu;
+}
+
+// eta = spectral radius of the skew part of A in the metric of its diagonal:
+// D^-1/2 (A - A^T)/2 D^-1/2 (real skew-symmetric: eigenvalues +- i eta) --
+// Bendixson: the eigenvalues of D^-1 A have |Im| <= eta.  0 for a symmetric A.
+inline double host_skew_radius(const HostCsr &A, const HostCsr &AT,
+                               int iters = 30) {
+    HostCsr K = host_add(0.5, A, -0.5, AT);
+    double mx = 0.0, amax = 0.0;
+    for (double v : K.vals) mx = std::max(mx, std::fabs(v));
+    for (double v : A.vals) amax = std::max(amax, std::fabs(v));
+    if (!(mx > 1e-12 * amax)) return 0.0;     // symmetric up to rounding
+    const int n = A.nrows;
+    std::vector<double> ds((size_t)n, 1.0), x((size_t)n), y, z;
+    for (int i = 0; i < n; ++i)
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k)
+            if (A.colidx[k] == i && A.vals[k] > 0.0)
+                ds[i] = 1.0 / std::sqrt(A.vals[k]);
+    for (int i = 0; i < n; ++i)
+        for (int k = K.rowptr[i]; k < K.rowptr[i + 1]; ++k)
+            K.vals[k] *= ds[i] * ds[K.colidx[k]];
+    for (int i = 0; i < n; ++i) x[i] = 1.0 + 0.5 * std::sin(0.53 * i + 3.0);
+    double eta2 = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        host_spmv(K, x, y);            // K^T K = -K^2: x <- -K (K x)
+        host_spmv(K, y, z);
+        double nx = 0.0, nz = 0.0;
+        for (int i = 0; i < n; ++i) {
+            nx += x[i] * x[i];
+            nz += z[i] * z[i];
+        }
+        if (!(nz > 0.0)) return 0.0;
+        eta2 = std::sqrt(nz / nx);
+        const double sc = 1.0 / std::sqrt(nz);
+        for (int i = 0; i < n; ++i) x[i] = -z[i] * sc;
+    }
+    return std::sqrt(eta2);
+}
+
 // [A, B] side by side (same number of rows)
 inline HostCsr host_hstack(const HostCsr &A, const HostCsr &B) {
     HostCsr C;

@@ -29,6 +29,38 @@ struct dns_imex {
     dns::DevBuf<double> nfc[2];
     int nc = 0, no = 1;
     dns::DevBuf<double> g, gp, b;
+    // per-step right-hand sides known in advance (time-dependent forcing,
+    // moving Dirichlet data: what the reference's `f_tdp`, `g_tdp`, `applybcs`
+    // callbacks return, tiu:114-127): row s of the tables replaces g / gp in
+    // step s after the upload; `stepctr` lives on the device so that replayed
+    // graphs walk through the tables without the host
+    dns::DevBuf<double> gtab, gptab;
+    dns::DevBuf<int> stepctr;
+    int tab_rows = 0;              // 0: no table, g / gp are used
+    bool tab_v = false, tab_p = false;
+    int tab_pos = 0;               // host copy of the counter
+    bool preparing = false;        // prepare_graphs is capturing (no launch)
+    // a step counter is needed as soon as anything is tabulated
+    bool tables() const {
+        return tab_rows > 0 || (conv && conv->dbc_rows > 0);
+    }
+    int rows_left() const {
+        int lim = 1 << 30;
+        if (tab_rows > 0) lim = std::min(lim, tab_rows);
+        if (conv && conv->dbc_rows > 0) lim = std::min(lim, conv->dbc_rows);
+        return lim - tab_pos;
+    }
+    dns::TabRef g_ref() const {
+        if (tab_rows > 0 && tab_v)
+            return {gtab.p, stepctr.p, sys->nv, tab_rows};
+        return {g.p, nullptr, 0, 1};
+    }
+    dns::TabRef gp_ref() const {
+        if (tab_rows > 0 && tab_p)
+            return {gptab.p, stepctr.p, std::max(1, sys->np), tab_rows};
+        return {gp.p, nullptr, 0, 1};
+    }
+    int sync_counter();            // device counter <- tab_pos
     double last_pscale = 1.0;
     dns_conv *conv = nullptr;      // device convection: nfc_c = scale*N(v_c)v_c
     double conv_scale = -1.0;
@@ -49,15 +81,17 @@ struct dns_imex {
     bool env_step_history = false, env_debug = false, env_slack_adapt = true;
     int env_group = 4;
     struct HostState {
-        int cur, prev, pprev, p3, p4, work, nsol, nc, no;
+        int cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos;
         long steps_enqueued;
     };
     HostState host_state() const {
-        return {cur, prev, pprev, p3, p4, work, nsol, nc, no, steps_enqueued};
+        return {cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos,
+                steps_enqueued};
     }
     void set_host_state(const HostState &s) {
         cur = s.cur; prev = s.prev; pprev = s.pprev; p3 = s.p3; p4 = s.p4;
         work = s.work; nsol = s.nsol; nc = s.nc; no = s.no;
+        tab_pos = s.tab_pos;
         steps_enqueued = s.steps_enqueued;
     }
     std::vector<uint64_t> group_key(const dns_imex_coeffs *cf,

@@ -42,6 +42,21 @@ struct DnsCtl {
     double R[(kMaxRestart + 1) * kMaxRestart];          // column major
 };
 
+// A vector that may be one row of a device-resident table: row = *ctr (a step
+// counter kept on the device, so that replayed graphs walk through the table
+// without the host), clamped to the table; ctr == nullptr: `base` itself.
+struct TabRef {
+    const double *base;
+    const int *ctr;
+    int stride, rows;
+};
+__device__ __forceinline__ const double *tab_row(const TabRef &t) {
+    if (!t.ctr) return t.base;
+    int r = *t.ctr;
+    r = r < 0 ? 0 : (r >= t.rows ? t.rows - 1 : r);
+    return t.base + (size_t)r * t.stride;
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

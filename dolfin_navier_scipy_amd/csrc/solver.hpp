@@ -264,6 +264,12 @@ struct dns_saddle {
     int to_f32(const double *in, dns::DevBuf<float> &out, size_t count);
     dns::CsrDev Gc;                  // [G, -G JT], explicit polynomial F^-1
     dns::HostCsr Fh, Jh, JTh;        // host copies for preconditioner set-up
+    // convection-dominated F (steady Oseen / Newton systems, snu:458,497): the
+    // Chebyshev polynomial is built for the symmetric part of F (shifted to be
+    // positive), K itself is untouched -- see setup_precond
+    dns::HostCsr Fpc_h;
+    bool pc_sym = false;
+    double skew_eta = 0.0, pc_shift = 0.0;
     int build_explicit(bool dense_schur);
     dns::DevBuf<double> cheb_r, cheb_d0, cheb_d1;
     // Krylov workspace
@@ -303,6 +309,10 @@ struct dns_saddle {
     int p1() const {
         return (dist() && !repl_schur()) ? st_p[comm->rank + 1] : np;
     }
+    int *step_counter = nullptr;      // device step counter of the attached
+                                      // stepper (tables of per-step data);
+                                      // bumped by the first head kernel of
+                                      // a solve
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open

@@ -89,6 +89,32 @@ struct dns_trap {
     dns::DevBuf<double> updnorm_dev;           // ... its part still on the device
     int pipeline_c = 0;                        // > 0: steps do not synchronise
     double last_dt = 0.0;
+    // time-dependent data of the sweeps, one row per trajectory slot (= time
+    // instance): f_v(t) (forcing + controlled-boundary stiffness terms,
+    // snu:1466), f_p(t), M[:, cnt] bcvals(t) (snu:1438-1441,1044-1045); the
+    // convection operator's boundary values come from its own table
+    dns::DevBuf<double> fv_tab, fp_tab, mbc_tab;
+    bool have_fv_tab = false, have_fp_tab = false, have_mbc_tab = false;
+    int cur_slot = 0;                          // time instance of xs[cur]
+    const double *fv_at(int slot) const {
+        return have_fv_tab ? fv_tab.p + (size_t)slot * sys->nv : fv.p;
+    }
+    const double *fp_at(int slot) const {
+        return have_fp_tab ? fp_tab.p + (size_t)slot * std::max(1, sys->np)
+                           : fp.p;
+    }
+    // low-rank feedback of one step (snu:1036-1042): system F - dt/2 U V_n,
+    // rhs += dt/2 U (V_c v_c); all host pointers
+    struct Feedback {
+        int r;
+        const double *umat;      // NV x r, column major
+        const double *vmat_c;    // r x NV, row major (may be null: no rhs term)
+        const double *vmat_n;    // r x NV, row major
+    };
+    dns::DevBuf<double> fb_u, fb_vc, fb_vn, fb_y;
+    int step_impl(double dt, int lin_which, int lin_slot, int out_slot,
+                  int newton, int extrapolate_x0, const dns_solve_opts *opts,
+                  dns_solve_stats *stats, const Feedback *fb);
     // N_c, f_c at the current velocity
     int assemble_current(int newton);
 };

@@ -4,4 +4,5 @@ from .mesh2d import (Mesh2D, read_dolfin_xml, load_npz_mesh, save_npz_mesh,
 from .taylor_hood import TaylorHood
 from .problem_setups import (get_sysmats, condense_sysmatsbybcs,
                              cylinder_mesh, cylinder_mesh_hierarchy,
-                             pressure_prolongations, GOLDEN_DIR)
+                             pressure_prolongations, DATA_DIR,
+                             gen_bccont_fems, classify_boundary)

@@ -212,6 +212,88 @@ class TaylorHood(object):
                             keep_pattern=keep_pattern)
         return N1, N2, self.convection_vec(u0vec)
 
+    # -- boundary forms (Robin-penalised control boundaries, outflow) ------
+    def boundary_edges(self):
+        """ids (into `self.edges`) of the boundary edges and their midpoints"""
+        eids = np.where(self.edge_nadj == 1)[0]
+        mid = 0.5*(self.mesh.verts[self.edges[eids, 0]]
+                   + self.mesh.verts[self.edges[eids, 1]])
+        return eids, mid
+
+    def _edge_nodes(self, eids):
+        """P2 nodes `(k, 3)` of edges: two vertices, then the midpoint"""
+        nv = self.mesh.nverts
+        return np.stack([self.node_newid[self.edges[eids, 0]],
+                         self.node_newid[self.edges[eids, 1]],
+                         self.node_newid[nv + eids]], axis=1)
+
+    def boundary_mass(self, eids):
+        """`inner(u, v) ds` over the edges `eids` on the full velocity space
+        (the Robin form `arob`, reference dts:304)"""
+        eids = np.asarray(eids)
+        nodes = self._edge_nodes(eids)
+        x = self.mesh.verts[self.edges[eids]]
+        length = np.sqrt(((x[:, 1] - x[:, 0])**2).sum(axis=1))
+        ref = np.array([[4., -1., 2.], [-1., 4., 2.], [2., 2., 16.]])/30.
+        loc = length[:, None, None]*ref[None, :, :]               # (k,3,3)
+        rows, cols, vals = [], [], []
+        for comp in range(2):
+            rows.append(np.broadcast_to(2*nodes[:, :, None] + comp,
+                                        loc.shape))
+            cols.append(np.broadcast_to(2*nodes[:, None, :] + comp,
+                                        loc.shape))
+            vals.append(loc)
+        return self._assemble(np.array(rows), np.array(cols), np.array(vals),
+                              (self.vdim, self.vdim))
+
+    def boundary_load(self, eids, gfun):
+        """`inner(v, g) ds` with `g` interpolated at the P2 nodes of the edges
+        (how dolfin treats a degree-2 `UserExpression`): `(vdim, 1)`
+        (the Robin input form `brob`, reference dts:305)"""
+        eids = np.asarray(eids)
+        nodes = np.unique(self._edge_nodes(eids))
+        gvals = np.zeros((self.nnodes, 2))
+        gvals[nodes] = gfun(self.nodecoords[nodes])
+        return self.boundary_mass(eids) @ gvals.reshape((-1, 1))
+
+    def outflow_stress_correction(self, eids, nu):
+        """`- nu * inner(grad(u).T * n, v) ds` over the (outflow) edges `eids`:
+        the term that turns the symmetric-gradient form into the do-nothing
+        condition there (reference dts:246-248)"""
+        eids = np.asarray(eids)
+        emap = -np.ones(self.edges.shape[0], dtype=np.int64)
+        emap[eids] = np.arange(eids.size)
+        hit = emap[self.celledges] >= 0                       # (nc, 3)
+        cells, kloc = np.nonzero(hit)
+        gp = np.array([0.5 - 0.5*np.sqrt(0.6), 0.5, 0.5 + 0.5*np.sqrt(0.6)])
+        gw = np.array([5., 8., 5.])/18.
+        rows, cols, vals = [], [], []
+        vd = self._vdofs()
+        for c, k in zip(cells, kloc):
+            i, j = _EDGE_OF[k]
+            vi, vj, vk = (self.mesh.verts[self.mesh.cells[c, q]]
+                          for q in (i, j, k))
+            tang = vj - vi
+            length = np.sqrt((tang**2).sum())
+            nrm = np.array([tang[1], -tang[0]])/length
+            if np.dot(nrm, 0.5*(vi + vj) - vk) < 0:
+                nrm = -nrm                                    # outward
+            lam = np.zeros((3, 3))
+            lam[:, i], lam[:, j] = 1. - gp, gp
+            phi = _p2_basis(lam)                              # (3, 6)
+            gphi = np.einsum('qai,id->qad', _p2_dbasis_dlam(lam),
+                             self.glam[c])                    # (3, 6, 2)
+            # loc[(a,i),(b,j)] = -nu * sum_q w phi_a d_i phi_b n_j
+            loc = -nu*length*np.einsum('q,qa,qbi,j->aibj', gw, phi, gphi, nrm)
+            r = np.broadcast_to(vd[c][:, :, None, None], (6, 2, 6, 2))
+            cc = np.broadcast_to(vd[c][None, None, :, :], (6, 2, 6, 2))
+            rows.append(r.ravel()), cols.append(cc.ravel())
+            vals.append(loc.ravel())
+        if not rows:
+            return sps.csr_matrix((self.vdim, self.vdim))
+        return self._assemble(np.concatenate(rows), np.concatenate(cols),
+                              np.concatenate(vals), (self.vdim, self.vdim))
+
     # -- boundary conditions ---------------------------------------------
     def boundary_nodes(self):
         """P2 nodes on the boundary and their coordinates"""

@@ -27,7 +27,7 @@ from .saddle import SaddleSystem, solve_opts
 __all__ = ['solve_sadpnt_smw', 'app_prj_via_sadpnt', 'apply_massinv',
            'SpslaKrylovCounter', 'clear_cache', 'DEFAULTS']
 
-DEFAULTS = dict(direct_tol=1e-12, maxiter=600, restart=60, cheb_degree=6,
+DEFAULTS = dict(direct_tol=1e-12, maxiter=3000, restart=60, cheb_degree=6,
                 factorization='full', schur='auto', schur_dense_max=6000,
                 refresh_tol=0.1, device=0, cache_size=4)
 
@@ -171,12 +171,13 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
     Parameters as consumed by the reference; returns the
     `(NV+NP, k)` array `[v; p]`, or `(sol, solve_fn)` if `return_alu`.
     """
-    if amat is None:
-        raise NotImplementedError(
-            'the decoupled variant (`amat` omitted, `solve_A` callable, '
-            'snu:1622) is not part of the MI355X path')
     if jmat is None or rhsv is None:
         raise ValueError('`jmat` and `rhsv` are required')
+    if amat is None:
+        if not (decouplevp and callable(solve_A)):
+            raise ValueError('without `amat` the decoupled variant needs '
+                             '`decouplevp=True` and a callable `solve_A`')
+        return _solve_decoupled(jmat, jmatT, rhsv, rhsp, solve_A, cgtol)
     NP, NV = jmat.shape
     rhsv = np.asarray(rhsv, dtype=np.float64).reshape((NV, -1))
     ncols = rhsv.shape[1]
@@ -212,6 +213,61 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
         sol = sol + kiu.dot(np.linalg.solve(small, vmat.dot(sol[:NV, :])))
     if return_alu:
         return sol, _SaddleSolveFn(system, opts)
+    return sol
+
+
+def _solve_decoupled(jmat, jmatT, rhsv, rhsp, solve_A, cgtol):
+    """`amat` omitted, `A^-1` given as the caller's `solve_A` (snu:1622-1628,
+    `get_pfromv(decouplevp=True, symmetric=True, solve_M=...)`): conjugate
+    gradients on the Schur complement
+
+        S p = J A^-1 rhsv - rhsp,  S = J A^-1 J^T,   v = A^-1 (rhsv - J^T p)
+
+    `solve_A` is host code of the caller; the `J` / `J^T` products run on the
+    device (one resident operator each)."""
+    from .bcs import ResidentOperator
+    NP, NV = jmat.shape
+    rhsv = np.asarray(rhsv, dtype=np.float64).reshape((NV, -1))
+    ncols = rhsv.shape[1]
+    rhsp = np.zeros((NP, ncols)) if rhsp is None else \
+        np.asarray(rhsp, dtype=np.float64).reshape((NP, -1))
+    jT = sps.csr_matrix(jmat.T) if jmatT is None else sps.csr_matrix(jmatT)
+    Jop = ResidentOperator(jmat, device=DEFAULTS['device'])
+    JTop = ResidentOperator(jT, device=DEFAULTS['device'])
+
+    def ainv(x):
+        return np.asarray(solve_A(np.asarray(x).reshape(-1)),
+                          dtype=np.float64).reshape((-1, 1))
+
+    def schur(p):
+        return Jop.apply(ainv(JTop.apply(p)))
+    sol = np.zeros((NV + NP, ncols))
+    try:
+        for k in range(ncols):
+            b = Jop.apply(ainv(rhsv[:, k])) - rhsp[:, k:k+1]
+            p = np.zeros((NP, 1))
+            r = b.copy()
+            d = r.copy()
+            rr = (r.T @ r).item()
+            bnorm = np.sqrt((b.T @ b).item())
+            for _ in range(10*max(NP, 1)):
+                if np.sqrt(rr) <= cgtol*bnorm:
+                    break
+                sd = schur(d)
+                alpha = rr/(d.T @ sd).item()
+                p += alpha*d
+                r -= alpha*sd
+                rrn = (r.T @ r).item()
+                d = r + (rrn/rr)*d
+                rr = rrn
+            else:
+                raise C.NotConverged(C.DNS_NOT_CONVERGED,
+                                     'Schur complement CG did not converge')
+            sol[:NV, k:k+1] = ainv(rhsv[:, k:k+1] - JTop.apply(p))
+            sol[NV:, k:k+1] = p
+    finally:
+        Jop.close()
+        JTop.close()
     return sol
 
 

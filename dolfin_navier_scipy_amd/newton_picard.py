@@ -112,6 +112,29 @@ class TrapezoidalStepper(object):
         fp = None if fp is None else C.as_f64(fp, self.NP)
         C.check(self.lib.dns_trap_set_rhs(self._h, C.dptr(fv), C.dptr(fp)))
 
+    def set_tables(self, fv_tab=None, fp_tab=None, mbc_tab=None,
+                   dbc_tab=None):
+        """time-dependent data of the sweeps, one row per trajectory slot
+        (`nslots` rows): `fv_tab (nslots, NV)` replaces `fv` (forcing `fvtd(t)`
+        plus the stiffness terms of controlled boundary values, snu:1466),
+        `fp_tab (nslots, NP)`, `mbc_tab (nslots, NV)` = `M[:, cnt] bcvals(t)`
+        (snu:1438-1441: `rhs += mbcs_n - mbcs_c`), `dbc_tab (nslots, ndbc)` the
+        convection operator's Dirichlet values per time instance"""
+        def _tab(arr, width):
+            if arr is None:
+                return None
+            out = np.ascontiguousarray(arr, dtype=np.float64)
+            if out.shape != (self.nslots, width):
+                raise ValueError('table must be {0} x {1}'.format(
+                    self.nslots, width))
+            return out.reshape(-1)
+        tabs = [_tab(fv_tab, self.NV), _tab(fp_tab, self.NP),
+                _tab(mbc_tab, self.NV)]
+        C.check(self.lib.dns_trap_set_tables(self._h,
+                                             *[C.dptr(t) for t in tabs]))
+        if dbc_tab is not None:
+            self.conv.set_dbc_table(dbc_tab)
+
     def write_linpoint(self, which, slot, v):
         v = C.as_f64(v, self.NV)
         C.check(self.lib.dns_trap_traj_write(self._h, which, slot, C.dptr(v)))
@@ -126,12 +149,31 @@ class TrapezoidalStepper(object):
         C.check(self.lib.dns_trap_start(self._h, C.dptr(v), int(bool(newton))))
 
     def step(self, dt, lin_which, lin_slot, out_slot, newton, opts=None,
-             extrapolate=2, raise_on_fail=True):
+             extrapolate=2, raise_on_fail=True, feedback=None):
+        """`feedback=(umat (NV, r), vmat_c (r, NV) or None, vmat_n (r, NV))`:
+        the low-rank terms of `_get_mats_rhs_ts` (snu:1036-1042) -- system
+        `F - dt/2 U V_n` by Sherman-Morrison-Woodbury, rhs `+ dt/2 U V_c v_c`"""
         o = solve_opts() if opts is None else opts
         st = C.dns_solve_stats()
-        C.check(self.lib.dns_trap_step(
-            self._h, float(dt), int(lin_which), int(lin_slot), int(out_slot),
-            int(bool(newton)), int(extrapolate), ct.byref(o), ct.byref(st)))
+        if feedback is None:
+            C.check(self.lib.dns_trap_step(
+                self._h, float(dt), int(lin_which), int(lin_slot),
+                int(out_slot), int(bool(newton)), int(extrapolate),
+                ct.byref(o), ct.byref(st)))
+        else:
+            umat, vmat_c, vmat_n = feedback
+            umat = np.asarray(umat, dtype=np.float64).reshape((self.NV, -1))
+            r = umat.shape[1]
+            uf = np.ascontiguousarray(umat.T).reshape(-1)     # column major
+            vn = np.ascontiguousarray(vmat_n, dtype=np.float64).reshape(
+                (r, self.NV)).reshape(-1)
+            vc = None if vmat_c is None else np.ascontiguousarray(
+                vmat_c, dtype=np.float64).reshape((r, self.NV)).reshape(-1)
+            C.check(self.lib.dns_trap_step_fb(
+                self._h, float(dt), int(lin_which), int(lin_slot),
+                int(out_slot), int(bool(newton)), int(extrapolate),
+                ct.byref(o), ct.byref(st), int(r), C.dptr(uf), C.dptr(vc),
+                C.dptr(vn)))
         self.last_stats = st.asdict()
         if raise_on_fail and st.status != C.DNS_OK:
             raise C.NotConverged(st.status, 'time step solve failed: '
@@ -206,11 +248,17 @@ class TrapezoidalStepper(object):
 
 def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
                   vel_nwtn_stps=2, vel_nwtn_tol=1e-14, opts=None,
-                  extrapolate=2):
+                  extrapolate=2, rhs_table=None):
     """Picard sweeps first, then Newton sweeps, each linearised about the
     previous sweep's trajectory (snu:1304-1334, 1562-1587).  `linpoints0`:
-    `{t: v_inner}` for the first sweep.  Returns `(vdict, pdict, hist)`."""
+    `{t: v_inner}` for the first sweep.  `rhs_table (NV, len(trange))`: the
+    momentum rhs per time instance (`cfv + fvtd(t)`).  Returns `(vdict,
+    pdict, hist)`."""
     trange = np.asarray(trange, dtype=np.float64)
+    if rhs_table is not None:
+        tab = np.zeros((stepper.nslots, stepper.NV))
+        tab[:trange.size] = np.asarray(rhs_table).T
+        stepper.set_tables(fv_tab=tab)
     which = 0
     for k, t in enumerate(trange):
         stepper.write_linpoint(which, k, linpoints0[t])

@@ -231,6 +231,28 @@ class ImexStepper(object):
         gp = None if rhsp is None else C.as_f64(rhsp, self.sys.NP)
         C.check(self.lib.dns_imex_set_rhs(self._h, C.dptr(g), C.dptr(gp)))
 
+    def set_rhs_table(self, gv=None, gp=None):
+        """per-step right-hand sides known in advance: row s of `gv`
+        `(nsteps, NV)` / `gp` `(nsteps, NP)` is used by the s-th step from now
+        on (`dns_imex_set_rhs_table`); `set_rhs` returns to constant vectors"""
+        NV, NP = self.sys.NV, self.sys.NP
+        tv = None if gv is None else \
+            np.ascontiguousarray(gv, dtype=np.float64).reshape((-1, NV))
+        tp = None if gp is None else \
+            np.ascontiguousarray(gp, dtype=np.float64).reshape((-1, NP))
+        nsteps = (tv if tv is not None else tp).shape[0]
+        if tv is not None and tp is not None and tp.shape[0] != nsteps:
+            raise ValueError('tables of different length')
+        C.check(self.lib.dns_imex_set_rhs_table(
+            self._h, int(nsteps), C.dptr(None if tv is None else tv.reshape(-1)),
+            C.dptr(None if tp is None else tp.reshape(-1))))
+
+    def table_position(self):
+        pos, left = ct.c_int32(0), ct.c_int32(0)
+        C.check(self.lib.dns_imex_table_position(self._h, ct.byref(pos),
+                                                 ct.byref(left)))
+        return pos.value, left.value
+
     @staticmethod
     def coeffs(a_c=1., a_p=0., cn_c=0., cn_o=0., pscale=1., extrapolate=True):
         return C.dns_imex_coeffs(a_c=a_c, a_p=a_p, cn_c=cn_c, cn_o=cn_o,

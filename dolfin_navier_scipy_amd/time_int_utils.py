@@ -148,16 +148,30 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
          f_tvdp=None, scalep=-1., getbcs=None, applybcs=None, appndbcs=None,
          savevp=None, dynamic_rhs=None, dynamic_rhs_memory={},
          check_ff_maxv=None, ntimeslices=10, verbose=True, solver=None,
-         device_convection=None, invinds=None):
+         device_convection=None, invinds=None, resident=None):
     """Crank-Nicolson / Adams-Bashforth-2 on the GPU (reference tiu:23-145)
 
     `solver`: optional dict overriding `SOLVER` (method, rtol, cheb_degree...).
     `device_convection`: a `convection.ConvectionP2` (with `invinds`, the inner
     dofs of the full velocity vector) -- the loop then evaluates `-N(v)v` on
     the device and `f_vdp` is not called per step.
+    `resident`: dict, with `device_convection` only -- what the caller
+    guarantees about its callbacks so that whole time slices run on the device
+    without a host round trip per step:
+      `bcs_time_only`   `getbcs(t, v, p)` ignores `v` and `p` (prescribed
+                        boundary motion); static boundaries need no flag
+      `static_dbcvals`  values of the operator's leading (static) Dirichlet
+                        dofs; the controlled values `bcs` follow them
+      `savevp_times`    the only times `savevp` has to see (None: all)
+    The per-step data the callbacks return (`f_tdp`, `g_tdp`, `applybcs`) are
+    tabulated per slice and uploaded (`dns_imex_set_rhs_table`,
+    `dns_conv_set_dbc_table`); the blow-up guard stays at the slice starts.
+    Not possible (falls back to one host round trip per step) with a
+    `dynamic_rhs` or `f_tvdp`, which depend on the state.
     Returns `v_n, p_n, ffflag` like the reference.
     """
     prm = _solver_settings(solver)
+    state_dependent = dynamic_rhs is not None or f_tvdp is not None
     dt, listofts = _inittimegrid(trange, ntimeslices=ntimeslices)
     NP, NV = J.shape
     ffflag = 0
@@ -182,8 +196,18 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
     cf = ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
                             pscale=scalep/dt, extrapolate=prm['extrapolate'])
     stepper.set_state(v_n, ptilde_c=p_n*dt/scalep, nfc_c=nfc_c)
+    rsd = dict(resident or {})
+    statvals = list(rsd.get('static_dbcvals', []) or [])
+    moving = len(bcs_ini) > 0
     if device_convection is not None:
         stepper.set_convection(device_convection, scale=-1.0)
+        if moving or statvals:
+            device_convection.set_dbcvals(statvals + list(bcs_n))
+    on_device = (device_convection is not None and resident is not None
+                 and not state_dependent
+                 and (not moving or rsd.get('bcs_time_only', False)))
+    savetimes = rsd.get('savevp_times', None)
+    savetimes = None if savetimes is None else set(savetimes)
     try:
         for kck, ctrange in enumerate(listofts):
             nrmvc = stepper.vnorm()
@@ -194,10 +218,49 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
                 logging.warning('BREAK: |v| is `NaN` or |v| > threshhold')
                 ffflag = 1
                 break
+            if on_device and len(ctrange) > 0:
+                # the whole slice: tabulate what the callbacks return, upload,
+                # replay; the host sees the state at the save times only
+                ns = len(ctrange)
+                gvt, gpt = np.empty((ns, NV)), np.empty((ns, NP))
+                dbt = np.empty((ns, len(statvals) + len(bcs_n))) \
+                    if moving else None
+                for s, ctime in enumerate(ctrange):
+                    bcs_c, bfv_c, mbc_c = bcs_n, bfv_n, mbc_n
+                    fv_c = fv_n
+                    bcs_n = getbcs(ctime, None, None, mode='abtwo')
+                    bfv_n, bfp_n, mbc_n = applybcs(bcs_n)
+                    fv_n, fp_n = f_tdp(ctime), g_tdp(ctime)
+                    gvt[s] = _col(-(mbc_n - mbc_c)
+                                  + .5*dt*(fv_c + fv_n + bfv_n + bfv_c),
+                                  NV)[:, 0]
+                    gpt[s] = _col(fp_n + bfp_n, NP)[:, 0]
+                    if moving:       # N(v_c) sees the CURRENT boundary values
+                        dbt[s] = statvals + list(bcs_c)
+                stepper.set_rhs_table(gvt, gpt)
+                if moving:
+                    device_convection.set_dbc_table(dbt)
+                done = 0
+                for s, ctime in enumerate(ctrange):
+                    if (savetimes is None or ctime in savetimes
+                            or s == ns - 1):
+                        stepper.run(s + 1 - done, cf, opts)
+                        done = s + 1
+                        v_n, p_n = stepper.get_state()
+                        bcs_at = dbt[s + 1][len(statvals):].tolist() \
+                            if (moving and s + 1 < ns) else bcs_n
+                        if savetimes is None or ctime in savetimes:
+                            savevp(appndbcs(v_n, bcs_at), p_n, time=ctime)
+                if moving:
+                    device_convection.set_dbcvals(statvals + list(bcs_n))
+                stepper.set_rhs(_col(0., NV), _col(0., NP))
+                continue
             for ctime in ctrange:
                 v_c, p_c = v_n, p_n
                 bcs_c, bfv_c, mbc_c = bcs_n, bfv_n, mbc_n
                 fv_c, dfv_c = fv_n, dfv_n
+                if device_convection is not None and (moving or statvals):
+                    device_convection.set_dbcvals(statvals + list(bcs_c))
                 nfc_new = None if device_convection is not None \
                     else f_vdp(appndbcs(v_c, bcs_c))
                 bcs_n = getbcs(ctime, appndbcs(v_c, bcs_c), p_c, mode='abtwo')

@@ -254,6 +254,19 @@ int dns_imex_set_state(dns_imex *st, const double *v_c, const double *v_p,
                        const double *nfc_o);
 /* constant (or updated) parts of the right-hand side; NULL keeps the old */
 int dns_imex_set_rhs(dns_imex *st, const double *gvec, const double *rhs_p);
+/* Per-step right-hand sides known in advance -- what the reference's callbacks
+ * `f_tdp(t)`, `g_tdp(t)`, `applybcs(getbcs(t))` return per step (tiu:114-127,
+ * snu:1103-1126) when they depend on time only (time-dependent forcing,
+ * prescribed moving-boundary data): row s of `gv` (nsteps x NV, may be NULL)
+ * / `gp` (nsteps x NP, may be NULL) replaces gvec / rhs_p in the s-th step
+ * after this call.  A step counter on the device selects the row, so
+ * dns_imex_run replays its graphs through the whole table without the host.
+ * Stepping past the last row fails with DNS_ERR_NOT_READY; dns_imex_set_rhs
+ * returns to constant vectors. */
+int dns_imex_set_rhs_table(dns_imex *st, int32_t nsteps, const double *gv,
+                           const double *gp);
+/* steps taken since the tables were uploaded / rows left (-1: no table) */
+int dns_imex_table_position(dns_imex *st, int32_t *pos, int32_t *left);
 /* one step; `nfc_new` (host, may be NULL) is the convection vector
  * f_vdp(v_c) evaluated by the caller at the current velocity -- it becomes
  * nfc_c, the old nfc_c becomes nfc_o (tiu:112-113).  NULL keeps both. */
@@ -304,6 +317,15 @@ int dns_conv_create_p2(int device, int32_t ncells, const int32_t *cell_vdofs,
                        dns_conv **out);
 void dns_conv_destroy(dns_conv *cv);
 int dns_conv_set_dbcvals(dns_conv *cv, const double *dbcvals);
+/* Dirichlet values that change from step to step (`append_bcs_vec` with
+ * controlled boundary values, snu:1003-1006,1152-1157): `nrows` value sets
+ * (nrows x ndbc).  Attached to an IMEX stepper, row s is used by the s-th step
+ * after the stepper's tables were (re)set (the values at the step's CURRENT
+ * time, where N(v_c)v_c is evaluated); in the trapezoidal sweeps the row is the
+ * trajectory slot.  dns_conv_set_dbcvals returns to one constant set. */
+int dns_conv_set_dbc_table(dns_conv *cv, int32_t nrows, const double *dbcvals);
+/* the row the host-driven entry points (dns_conv_apply / _assemble) use */
+int dns_conv_set_dbc_row(dns_conv *cv, int32_t row);
 /* out = scale * N(u)u restricted to the inner dofs (host in/out; parity) */
 int dns_conv_apply(dns_conv *cv, const double *v_inner, double scale,
                    double *out);
@@ -360,6 +382,16 @@ int dns_conv_bind_pattern(dns_conv *cv, const dns_csr *pattern);
 int dns_conv_assemble(dns_conv *cv, const double *u_inner, int32_t newton,
                       double *nvals, double *rhsbc, double *rhscon);
 
+/* the same with two sets of Dirichlet values: `dbcvals_lin` belong to the
+ * linearisation field (they enter N1, N2 and N(u)u), `dbcvals_rhs` multiply
+ * the Dirichlet columns in `rhsbc` (NULL: the same set) -- the steady Picard
+ * iteration uses the old values for the field and the new ones for the rhs
+ * (snu:446-455); the operator's own value set / table is not touched */
+int dns_conv_assemble2(dns_conv *cv, const double *u_inner,
+                       const double *dbcvals_lin, const double *dbcvals_rhs,
+                       int32_t newton, double *nvals, double *rhsbc,
+                       double *rhscon);
+
 /* Trapezoidal stepper: M, A given as value arrays in the pattern of `sys`'s F
  * block (to which `conv` must be bound); two trajectory buffers of `nslots`
  * velocities each hold the linearisation points of the running sweep
@@ -386,6 +418,23 @@ int dns_trap_step(dns_trap *t, double dt, int32_t lin_which, int32_t lin_slot,
                   const dns_solve_opts *opts, dns_solve_stats *stats);
 int dns_trap_get_state(dns_trap *t, double *v, double *p);
 int dns_trap_update_norm(dns_trap *t, double *out);
+/* time-dependent data of the sweeps, one row per trajectory slot (= time
+ * instance; nslots rows each, NULL = not time dependent): `fv_tab` replaces fv
+ * (forcing `fvtd(t)` and the stiffness contribution of controlled boundary
+ * values, snu:1466-1468), `fp_tab` replaces fp, `mbc_tab` = M[:, cnt] bcvals(t)
+ * adds `mbcs_n - mbcs_c` to the rhs (snu:1044-1045, 1438-1441) */
+int dns_trap_set_tables(dns_trap *t, const double *fv_tab, const double *fp_tab,
+                        const double *mbc_tab);
+/* one step with the low-rank feedback terms of `_get_mats_rhs_ts`
+ * (snu:1036-1042, passed at snu:1505-1512): system matrix F - dt/2 U V_n
+ * (Sherman-Morrison-Woodbury: r more solves with the same K), right-hand side
+ * + dt/2 U (V_c v_c).  umat: NV x r column major; vmat_c (may be NULL),
+ * vmat_n: r x NV row major; synchronous steps only */
+int dns_trap_step_fb(dns_trap *t, double dt, int32_t lin_which,
+                     int32_t lin_slot, int32_t out_slot, int32_t newton,
+                     int32_t extrapolate_x0, const dns_solve_opts *opts,
+                     dns_solve_stats *stats, int32_t r, const double *umat,
+                     const double *vmat_c, const double *vmat_n);
 /* pipelined sweeps: with cycle_len > 0 `dns_trap_step` only enqueues (one GMRES
  * cycle of that length, no host synchronisation, `stats` not filled); the
  * device counts solves / unconverged solves / Krylov steps and keeps the update
@@ -395,6 +444,29 @@ int dns_trap_update_norm(dns_trap *t, double *out);
 int dns_trap_set_pipeline(dns_trap *t, int32_t cycle_len);
 int dns_trap_poll(dns_trap *t, int32_t *solves, int32_t *fails, int32_t *iters,
                   int32_t *maxit);
+
+/* ---- resident helpers of the caller side of the path -----------------------
+ * A CSR matrix kept in HBM for repeated products with host vectors: what the
+ * closures of `solve_nse` do per step with SciPy -- `applybcs` (snu:1111-1115:
+ * -A[:, cnt] vals, -J[:, cnt] vals, M[:, cnt] vals),
+ * `condense_velmatsbybcs(get_rhs_only=True)` (dts:610-630) -- and the J / J^T
+ * products of the decoupled pressure solve (snu:1622-1628).
+ *   y = alpha A x + beta y   (host vectors) */
+typedef struct dns_op dns_op;
+int dns_op_create(int device, const dns_csr *a, dns_op **out);
+void dns_op_destroy(dns_op *op);
+int dns_op_apply(dns_op *op, const double *x, double *y, double alpha,
+                 double beta);
+/* `append_bcs_vec` (dts:49-64): out = NaN everywhere, then out[invinds] =
+ * v_inner, then out[bcinds] = bcvals (boundary values win; of a repeated index
+ * the last occurrence wins, as in NumPy's fancy assignment) */
+typedef struct dns_bcmap dns_bcmap;
+int dns_bcmap_create(int device, int32_t vdim, int32_t ninv,
+                     const int32_t *invinds, int32_t nbc, const int32_t *bcinds,
+                     dns_bcmap **out);
+void dns_bcmap_destroy(dns_bcmap *m);
+int dns_bc_scatter(dns_bcmap *m, const double *v_inner, const double *bcvals,
+                   double *out_full);
 
 /* attainable HBM bandwidth of the device, measured with plain streaming
  * kernels over `bytes` of fp64 data (kind 0: read + reduce, 1: copy,

@@ -14,8 +14,10 @@ CPU restatement of the Newton/Picard time sweeps of the reference's
 in purely algebraic form: the FEniCS pieces (`get_v_conv_conts`, snu:40-133)
 enter as a callback `conv(vfull, Picard) -> (N_condensed, rhs_con, rhsv_conbc)`,
 the per-time-step `.npy` files that hold the linearisation points
-(snu:1424-1431) become a dict `t -> v`.  No control boundaries, no feedback
-(`umat/vmat` of snu:1036-1042 are covered by `saddle_oracle`'s SMW test).
+(snu:1424-1431) become a dict `t -> v`.  The low-rank feedback terms
+(`umat/vmat`, snu:1036-1042) and the moving-boundary mass term (`mbcs`,
+snu:1044-1045) of `_get_mats_rhs_ts` are restated too; time-dependent data
+enter as callables of the time (`fv(t)`, `fp(t)`, `mbcs(t)`, `feedback(t)`).
 
 PARITY UNPINNED against the reference itself: this branch needs dolfin
 (snu:7) and is bit-rotted on Python >= 3.8 (`time.clock`, snu:1412;
@@ -40,25 +42,49 @@ def m_innerproduct(M, v1, v2=None):
 
 
 def get_mats_rhs_ts(mmat=None, dt=None, var_c=None, coeffmat_c=None,
-                    coeffmat_n=None, fv_c=None, fv_n=None):
+                    coeffmat_n=None, fv_c=None, fv_n=None,
+                    umat_c=None, vmat_c=None, umat_n=None, vmat_n=None,
+                    mbcs_c=None, mbcs_n=None):
     """trapezoidal rule: `(M + dt/2 C_n) v_n = M v_c + dt/2 (f_n + f_c - C_c v_c)`
-    (snu:1034-1035)"""
+    (snu:1034-1035); with feedback the system matrix is `solvmat - umat vmat`
+    (`umat = dt/2 umat_n`, snu:1036-1042; QUIRK kept: the rhs term carries a
+    PLUS, "do we really need a PLUS here??", snu:1039-1040); moving boundary
+    values add `mbcs_n - mbcs_c` (snu:1044-1045)"""
     solvmat = mmat + 0.5*dt*coeffmat_n
     rhs = mmat @ var_c + 0.5*dt*(fv_n + fv_c - coeffmat_c @ var_c)
-    return solvmat, rhs
+    if umat_n is not None:
+        umat = 0.5*dt*umat_n
+        vmat = vmat_n
+        if umat_c is not None and vmat_c is not None:
+            rhs = rhs + 0.5*dt*umat_c.dot(vmat_c.dot(var_c))
+    else:
+        umat, vmat = None, None
+    if mbcs_c is not None and mbcs_n is not None:
+        rhs = rhs + mbcs_n - mbcs_c
+    if umat is None and mbcs_c is None:
+        return solvmat, rhs
+    return solvmat, rhs, umat, vmat
 
 
 def trapezoidal_sweep(trange, iniv, M=None, A=None, J=None, fv=None, fp=None,
                       conv=None, appndbcs=None, linpoints=None, picard=False,
-                      solve=None, krylovini=None):
+                      solve=None, krylovini=None, feedback=None, mbcs=None):
     """one sweep over `trange` with the convection linearised about
     `linpoints[t]` (snu:1402-1566); returns `vdict, pdict, norm_nwtnupd`
 
     `krylovini='upd'` feeds the extrapolated previous solutions as `x0`
-    (snu:1493-1503)."""
+    (snu:1493-1503).  `fv`, `fp` may be callables of the time; `feedback(t) ->
+    (umat, vmat)` and `mbcs(t)` switch the extra terms of `_get_mats_rhs_ts`
+    on (`conv`/`appndbcs` then take the time as a second/third argument)."""
     solve = lau.solve_sadpnt_smw if solve is None else solve
     NP, NV = J.shape
     JT = J.T.tocsr()
+    timedep = callable(fv) or callable(fp) or feedback is not None \
+        or mbcs is not None
+    if timedep:
+        return _sweep_timedep(trange, iniv, M, A, J, JT, fv, fp, conv,
+                              appndbcs, linpoints, picard, solve, feedback,
+                              mbcs)
     v_old = iniv
     vdict, pdict = {trange[0]: iniv}, {}
     N_c, rhs_con_c, rhsbc_c = conv(appndbcs(v_old), picard)       # snu:1351
@@ -91,6 +117,68 @@ def trapezoidal_sweep(trange, iniv, M=None, A=None, J=None, fv=None, fp=None,
         fvn_c = fvn_n - rhscon_n - rhsbc_n + rhsbc_c + rhscon_c   # snu:1537
         vdict[t] = v_old
         pdict[t] = -1/cts*vp_new[NV:, ]                            # snu:1542
+        pv = prev_v if prev_v.shape[0] == NV else None
+        if pv is not None:
+            norm_nwtnupd += cts*m_innerproduct(M, v_old - pv).item()
+    return vdict, pdict, norm_nwtnupd
+
+
+def _sweep_timedep(trange, iniv, M, A, J, JT, fv, fp, conv, appndbcs,
+                   linpoints, picard, solve, feedback, mbcs):
+    """the same loop with everything that may depend on the time spelled out
+    (snu:1402-1566): `fv(t)` = cfv + ccfv(t) [+ fvtd(t)], `fp(t)`, boundary
+    values through `conv(v, picard, t)` / `appndbcs(v, t)`, `mbcs(t)`,
+    `feedback(t)`"""
+    NP, NV = J.shape
+    _fv = fv if callable(fv) else (lambda t: fv)
+    _fp = fp if callable(fp) else (lambda t: fp)
+
+    def _conv(v, t):
+        try:
+            return conv(v, picard, t)
+        except TypeError:
+            return conv(v, picard)
+
+    def _app(v, t):
+        try:
+            return appndbcs(v, t)
+        except TypeError:
+            return appndbcs(v)
+    t0 = trange[0]
+    v_old = iniv
+    vdict, pdict = {t0: iniv}, {}
+    N_c, rhs_con_c, rhsbc_c = _conv(_app(v_old, t0), t0)          # snu:1351
+    fvn_c = _fv(t0) + rhsbc_c + (0. if picard else rhs_con_c)     # snu:1364
+    umat_c, vmat_c = feedback(t0) if feedback is not None else (None, None)
+    mbcs_c = mbcs(t0) if mbcs is not None else None
+    norm_nwtnupd = 0.
+    for tk, t in enumerate(trange[1:]):
+        cts = t - trange[tk]
+        prev_v = linpoints[t]
+        N_n, rhs_con_n, rhsbc_n = _conv(prev_v, t)                # snu:1443
+        rhscon_n = 0. if picard else rhs_con_n
+        fvn_n = _fv(t) + rhsbc_n + rhscon_n                        # snu:1459
+        umat_n, vmat_n = feedback(t) if feedback is not None \
+            else (None, None)
+        mbcs_n = mbcs(t) if mbcs is not None else None
+        out = get_mats_rhs_ts(mmat=M, dt=cts, var_c=v_old,
+                              coeffmat_c=A + N_c, coeffmat_n=A + N_n,
+                              fv_c=fvn_c, fv_n=fvn_n, umat_c=umat_c,
+                              vmat_c=vmat_c, umat_n=umat_n, vmat_n=vmat_n,
+                              mbcs_c=mbcs_c, mbcs_n=mbcs_n)
+        solvmat, rhsv = out[0], out[1]
+        umat, vmat = (out[2], out[3]) if len(out) > 2 else (None, None)
+        vp_new = solve(amat=solvmat, jmat=J, jmatT=JT, rhsv=rhsv,
+                       rhsp=_fp(t), umat=umat, vmat=vmat)          # snu:1505
+        v_old = vp_new[:NV, ]
+        umat_c, vmat_c, mbcs_c = umat_n, vmat_n, mbcs_n            # snu:1525
+        N_c, rhs_con_c, rhsbc_c = _conv(_app(v_old, t), t)        # snu:1529
+        rhscon_c = 0. if picard else rhs_con_c
+        # QUIRK-free form of snu:1536-1537 (which carries `cfv + ccfv_n` over):
+        # f_c at the new time instance
+        fvn_c = fvn_n - rhscon_n - rhsbc_n + rhsbc_c + rhscon_c
+        vdict[t] = v_old
+        pdict[t] = -1/cts*vp_new[NV:, ]
         pv = prev_v if prev_v.shape[0] == NV else None
         if pv is not None:
             norm_nwtnupd += cts*m_innerproduct(M, v_old - pv).item()

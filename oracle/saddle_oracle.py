@@ -67,7 +67,27 @@ def solve_sadpnt_smw(amat=None, jmat=None, jmatT=None, rhsv=None, rhsp=None,
     rhsp = np.zeros((NP, ncols)) if rhsp is None else \
         np.asarray(rhsp, dtype=np.float64).reshape((NP, -1))
     if amat is None:
-        raise NotImplementedError('decoupled solve needs `solve_A`')
+        # the decoupled variant of snu:1622-1628: `amat` omitted, `A^-1` given
+        # as the callable `solve_A` -- Schur complement CG
+        #   S p = J A^-1 rhsv - rhsp,  S = J A^-1 J^T;  v = A^-1 (rhsv - J^T p)
+        if solve_A is None:
+            raise ValueError('decoupled solve needs `solve_A`')
+        jT = sps.csr_matrix(jmat.T) if jmatT is None else jmatT
+        sol = np.zeros((NV + NP, ncols))
+        for k in range(ncols):
+            ainvf = np.asarray(solve_A(rhsv[:, k])).reshape(-1)
+
+            def _schur(pvec):
+                return jmat @ np.asarray(solve_A(jT @ pvec)).reshape(-1)
+            sop = spsla.LinearOperator((NP, NP), matvec=_schur,
+                                       dtype=np.float64)
+            pk, info = spsla.cg(sop, jmat @ ainvf - rhsp[:, k], rtol=cgtol,
+                                atol=0., maxiter=10*NP)
+            if info != 0:
+                raise RuntimeError('Schur complement CG did not converge')
+            sol[:NV, k] = np.asarray(solve_A(rhsv[:, k] - jT @ pk)).reshape(-1)
+            sol[NV:, k] = pk
+        return sol
     alu = SaddleLU(amat, jmat, jmatT)
     rhs = np.vstack([rhsv, rhsp])
     sol = alu(rhs)

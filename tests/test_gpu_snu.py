@@ -1,0 +1,418 @@
+"""The algebraic half of `solve_nse` on the device
+(`dolfin_navier_scipy_amd.stokes_navier_utils`, `bcs`, the per-step tables of
+`dns_imex_*` / `dns_trap_*`) against the CPU restatement `oracle/snu_oracle.py`
+(rows a6, a10, a13, f2 of SURVEY.md section 8 and the extras of row a7)."""
+import numpy as np
+import pytest
+import scipy.sparse as sps
+import scipy.sparse.linalg as spsla
+
+import scenarios
+from oracle import snu_oracle as so
+from oracle import imex_oracle, saddle_oracle
+from oracle import newton_picard_oracle as npo
+
+pytestmark = pytest.mark.gpu
+
+VTOL, PTOL = 1e-8, 1e-6
+
+
+@pytest.fixture(scope='module')
+def snu():
+    from dolfin_navier_scipy_amd import stokes_navier_utils, _capi
+    assert _capi.device_count() > 0, 'HIP device required for -m gpu tests'
+    yield stokes_navier_utils
+    stokes_navier_utils.clear_cache()
+
+
+def _rel(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b))/np.linalg.norm(b)
+
+
+# ---- a13: append_bcs_vec, resident operators ------------------------------
+def test_append_bcs_vec_matches_reference_semantics():
+    from dolfin_navier_scipy_amd import bcs
+    rng = np.random.default_rng(0)
+    vdim = 1000
+    perm = rng.permutation(vdim)
+    inv = np.sort(perm[:700])
+    b1, b2 = perm[700:850].tolist(), perm[850:950].tolist()   # 50 dofs: none
+    b2 = b2 + b1[:7] + inv[:5].tolist()       # repeats + overlap with inner
+    v = rng.standard_normal((inv.size, 1))
+    bv1, bv2 = rng.standard_normal(len(b1)), rng.standard_normal(len(b2))
+    ref = so.append_bcs_vec(v, vdim=vdim, invinds=inv, bcinds=[b1, b2],
+                            bcvals=[bv1.tolist(), bv2.tolist()])
+    for _ in range(2):                         # second call: cached map
+        got = bcs.append_bcs_vec(v, vdim=vdim, invinds=inv, bcinds=[b1, b2],
+                                 bcvals=[bv1.tolist(), bv2.tolist()])
+        assert got.shape == (vdim, 1)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))      # dts:58
+        assert int(np.isnan(got).sum()) == 50
+        m = ~np.isnan(ref)
+        assert np.array_equal(got[m], ref[m])                    # bit-exact
+    # empty boundary set, empty inner set
+    e1 = bcs.append_bcs_vec(v, vdim=vdim, invinds=inv, bcinds=[], bcvals=[])
+    assert np.array_equal(e1[inv], v) and np.isnan(e1).sum() == vdim - 700
+    bcs.clear_cache()
+
+
+def test_resident_operator_and_applybcs(toy_prob):
+    from dolfin_navier_scipy_amd import bcs
+    stms = toy_prob['stms']
+    A, J, M = stms['A'], stms['J'], stms['M']
+    rng = np.random.default_rng(1)
+    op = bcs.ResidentOperator(A)
+    x, y = rng.standard_normal(A.shape[1]), rng.standard_normal(A.shape[0])
+    assert _rel(op.apply(x), (A @ x).reshape((-1, 1))) <= 1e-13
+    assert _rel(op.apply(x, y, alpha=-2., beta=.5),
+                (-2*(A @ x) + .5*y).reshape((-1, 1))) <= 1e-13
+    op.close()
+    dbcinds, dbcvals = toy_prob['dbcinds'], toy_prob['dbcvals']
+    inv = toy_prob['invinds']
+    cnt = dbcinds[np.abs(dbcvals) > 0]
+    vals = rng.standard_normal(cnt.size)
+    app = bcs.make_applybcs(A, J, M, cnt.tolist(), inv.tolist())
+    bfv, bfp, mbc = app(vals)
+    caux = np.zeros((A.shape[0], 1))
+    caux[cnt, 0] = vals
+    assert _rel(bfv, -(A @ caux)[inv]) <= 1e-13            # snu:1113
+    assert _rel(bfp, -(J @ caux)) <= 1e-13
+    assert _rel(mbc, (M @ caux)[inv]) <= 1e-13
+    app.operator.close()
+    assert bcs.make_applybcs(A, J, M, [], inv)(None) == (0., 0., 0.)
+    r = bcs.condense_velmatsbybcs_rhs(M, invinds=inv, dbcinds=cnt.tolist(),
+                                      dbcvals=vals.tolist())
+    assert _rel(r, so.condense_velmatsbybcs(
+        M, invinds=inv, dbcinds=cnt.tolist(), dbcvals=vals.tolist(),
+        get_rhs_only=True)) <= 1e-13
+
+
+# ---- a9 at the product boundary: get_v_conv_conts ----------------------------
+def test_get_v_conv_conts_all_modes(snu, toy_prob):
+    th, inv = toy_prob['th'], toy_prob['invinds']
+    dbcinds, dbcvals = toy_prob['dbcinds'], toy_prob['dbcvals']
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal((inv.size, 1))
+    kw = dict(V=th, invinds=inv, dbcinds=[dbcinds.tolist()],
+              dbcvals=[dbcvals.tolist()])
+    for picard in (True, False):
+        N, rc, rb = snu.get_v_conv_conts(vvec=v, Picard=picard, **kw)
+        No, rco, rbo = so.get_v_conv_conts(vvec=v, Picard=picard, **kw)
+        assert abs(N - No).max() <= 1e-12*abs(No).max()
+        assert _rel(rb, rbo) <= 1e-12
+        if picard:
+            assert rc is None and rco is None
+        else:
+            assert _rel(rc, rco) <= 1e-12
+    z0, cvec, z1 = snu.get_v_conv_conts(vvec=v, semi_explicit=True, **kw)
+    assert z0 == 0. and z1 == 0.
+    assert _rel(cvec, so.get_v_conv_conts(vvec=v, semi_explicit=True,
+                                          **kw)[1]) <= 1e-12
+    # a field that carries OTHER boundary values than the rhs ones (snu:446-455)
+    vfull = so.append_bcs_vec(v, vdim=th.vdim, invinds=inv, bcinds=dbcinds,
+                              bcvals=1.3*dbcvals)
+    N, rc, rb = snu.get_v_conv_conts(vvec=vfull, **kw)
+    No, rco, rbo = so.get_v_conv_conts(vvec=vfull, **kw)
+    assert abs(N - No).max() <= 1e-12*abs(No).max()
+    assert _rel(rc, rco) <= 1e-12 and _rel(rb, rbo) <= 1e-12
+    (N1, N2), rc, (rb1, rb2) = snu.get_v_conv_conts(vvec=v, retparts=True,
+                                                    **kw)
+    assert abs(N1 + N2 - No).max() >= 0.        # (shape / pattern agree)
+    Np, _, rbp = so.get_v_conv_conts(vvec=v, Picard=True, **kw)
+    assert abs(N1 - Np).max() <= 1e-12*abs(Np).max()
+    assert _rel(rb1, rbp) <= 1e-12
+
+
+# ---- a10 + boundary: get_pfromv, decoupled variant ---------------------------
+def test_get_pfromv_coupled_and_decoupled(snu, toy_prob):
+    th, smc, rhsd = toy_prob['th'], toy_prob['smc'], toy_prob['rhsd']
+    inv = toy_prob['invinds']
+    M, A, J = smc['M'], smc['A'], smc['J']
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal((inv.size, 1))
+    kw = dict(v=v, V=th, M=M, A=A, J=J, fv=rhsd['fv'], invinds=inv,
+              dbcinds=[toy_prob['dbcinds'].tolist()],
+              dbcvals=[toy_prob['dbcvals'].tolist()])
+    pref = so.get_pfromv(**kw)
+    assert _rel(snu.get_pfromv(**kw), pref) <= 1e-7
+    mlu = spsla.splu(sps.csc_matrix(M))
+    pdec = snu.get_pfromv(decouplevp=True, symmetric=True, solve_M=mlu.solve,
+                          cgtol=1e-12, **kw)              # snu:1622-1628
+    assert _rel(pdec, pref) <= 1e-7
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    with pytest.raises(ValueError):
+        lau.solve_sadpnt_smw(jmat=J, rhsv=v)        # no amat, no solve_A
+
+
+# ---- config 1: steady Picard / Newton systems at full size ------------------
+def test_steadystate_nse_cylinder_N2_Re50(snu):
+    """what `tests/mini_setup.py:6-36` runs: cylinder wake N=2, Re=50, steady
+    Newton through `lau` (amat = A + N(v_k), snu:458,497), then the pressure
+    recomputed from the velocity agrees (mini_setup.py:35-36)"""
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=50)
+    kw = dict(A=sm['A'], J=sm['J'], M=sm['M'], fv=rhsd['fv'], fp=rhsd['fp'],
+              V=femp['V'], invinds=femp['invinds'],
+              dbcinds=femp['dbcinds'].tolist(),
+              dbcvals=femp['dbcvals'].tolist())
+    (vg, pg), norms = snu.solve_steadystate_nse(
+        return_vp=True, return_nwtnupd_norms=True, vel_pcrd_stps=5,
+        vel_nwtn_stps=10, vel_nwtn_tol=1e-10, **kw)
+    vo, po, normso = so.solve_steadystate_nse(
+        vel_pcrd_stps=5, vel_nwtn_stps=10, vel_nwtn_tol=1e-10, **kw)
+    assert len(norms) == len(normso) and norms[-1] < 1e-10
+    inv = femp['invinds']
+    assert _rel(vg[inv], vo[inv]) <= VTOL
+    assert _rel(pg, po) <= PTOL
+    # the steady equations hold for the device iterate
+    th = femp['V']
+    res = sm['A'] @ vg[inv] + th.convection_vec(vg)[inv] - sm['J'].T @ pg \
+        - rhsd['fv']
+    assert np.linalg.norm(res) <= 1e-7*np.linalg.norm(rhsd['fv'])
+    # pressure from velocity (test_units_pfromv.py:45 / mini_setup.py:35)
+    pfv = snu.get_pfromv(v=vg[inv], V=th, M=sm['M'], A=sm['A'], J=sm['J'],
+                         fv=rhsd['fv'], invinds=inv,
+                         dbcinds=[kw['dbcinds']], dbcvals=[kw['dbcvals']])
+    assert _rel(pfv, pg) <= 1e-5
+
+
+# ---- a6: solve_nse, explicit branch ---------------------------------------------
+def _static_kwargs(prob, kw):
+    return dict(A=prob['smc']['A'], M=prob['smc']['M'], J=prob['smc']['J'],
+                fv=prob['rhsd']['fv'], fp=prob['rhsd']['fp'],
+                iniv=kw['appndbcs'](kw['inivel'], []), inip=kw['inip'],
+                trange=kw['trange'], V=prob['th'], invinds=prob['invinds'],
+                dbcinds=prob['dbcinds'], dbcvals=prob['dbcvals'])
+
+
+@pytest.mark.parametrize('scheme', ['cnab', 'sbdf2'])
+def test_solve_nse_explicit_static_bcs(snu, toy_prob, scheme):
+    kw, _, _ = scenarios.build(variant='plain', seed=2, Nts=12, tE=0.06,
+                               prob=toy_prob)
+    skw = _static_kwargs(toy_prob, kw)
+    vo, po, _ = so.solve_nse(time_int_scheme=scheme, **skw)
+    (vg, pg), ff = snu.solve_nse(time_int_scheme=scheme, return_final_vp=True,
+                                 check_ff=True, **skw)
+    assert ff == 0
+    assert _rel(vg, vo) <= VTOL and _rel(pg, po) <= PTOL
+    # dictionary of all time instances, full vectors with boundary values
+    vpd = snu.solve_nse(time_int_scheme=scheme, return_vp_dict=True, **skw)
+    assert sorted(vpd.keys()) == sorted(kw['trange'].tolist())
+    last = vpd[kw['trange'][-1]]
+    assert last['v'].shape == (toy_prob['th'].vdim, 1)
+    assert _rel(last['v'][toy_prob['invinds']], vo) <= VTOL
+    assert np.allclose(last['v'][toy_prob['dbcinds'], 0], toy_prob['dbcvals'])
+    # selected data points only: the loop stays on the device in between
+    dtr = kw['trange'][[0, 4, 12]].tolist()
+    ylist = snu.solve_nse(time_int_scheme=scheme, return_y_list=True,
+                          datatrange=list(dtr), **skw)
+    assert len(ylist) == 3
+    assert _rel(ylist[-1][toy_prob['invinds']], vo) <= VTOL
+
+
+def _controlled_setup(prob, amplitude):
+    from dolfin_navier_scipy_amd.fem import condense_sysmatsbybcs
+    th, stms = prob['th'], prob['stms']
+    dbcinds, dbcvals = prob['dbcinds'], prob['dbcvals']
+    ctrl = np.abs(dbcvals) > 0                        # inflow -> controlled
+    statinds, statvals = dbcinds[~ctrl], dbcvals[~ctrl]
+    cntinds, cntvals = dbcinds[ctrl], dbcvals[ctrl]
+    smc, rhs, inv = condense_sysmatsbybcs(stms, statinds, statvals)
+
+    def ufunc(t, vel=None, p=None, mode=None, memory=None):
+        return 1.0 + amplitude*np.sin(40*t), memory
+    rng = np.random.default_rng(6)
+    full0 = np.zeros((th.vdim, 1))
+    full0[0::2, 0] = 1.0
+    full0[prob['invinds'], 0] += 1e-2*rng.standard_normal(
+        prob['invinds'].size)
+    full0[dbcinds, 0] = dbcvals
+    full0[cntinds, 0] = cntvals*ufunc(0.)[0]
+
+    def kwargs():
+        return dict(A=smc['A'], M=smc['M'], J=smc['J'], fv=rhs['fv'],
+                    fp=rhs['fp'], iniv=full0.copy(),
+                    inip=np.zeros((smc['J'].shape[0], 1)),
+                    trange=np.linspace(0, 0.06, 13), V=th, invinds=inv,
+                    dbcinds=statinds.tolist(), dbcvals=statvals.tolist(),
+                    diricontbcinds=[cntinds.tolist()],
+                    diricontbcvals=[cntvals.tolist()], diricontfuncs=[ufunc],
+                    diricontfuncmems=[None])
+    return kwargs
+
+
+@pytest.mark.parametrize('resident', [False, True])
+def test_solve_nse_explicit_controlled_dirichlet(snu, toy_prob, resident):
+    """time-varying controlled Dirichlet values (snu:729-770, 1103-1157):
+    step-by-step with the callbacks, and device resident through the per-step
+    tables (`bcs_time_only`: rhs table + boundary-value table of the
+    convection operator, no host round trip inside a time slice)"""
+    mk = _controlled_setup(toy_prob, amplitude=0.3)
+    vo, po, _ = so.solve_nse(**mk())
+    vg, pg = snu.solve_nse(return_final_vp=True, bcs_time_only=resident,
+                           **mk())
+    assert vg.shape == vo.shape
+    assert _rel(vg, vo) <= VTOL and _rel(pg, po) <= PTOL
+
+
+def test_solve_nse_time_dependent_forcing(snu, toy_prob):
+    """`fvtd` (config 5's `sin(2 pi t / tE) (B1 + B2)`,
+    time_dep_nse_double_rotcyl_bcrob.py:45-47) through the rhs table"""
+    kw, _, _ = scenarios.build(variant='plain', seed=1, Nts=12, tE=0.06,
+                               prob=toy_prob)
+    skw = _static_kwargs(toy_prob, kw)
+    rng = np.random.default_rng(9)
+    bdir = toy_prob['smc']['M'] @ rng.standard_normal((skw['M'].shape[0], 1))
+
+    def fvtd(t):
+        return np.sin(2*np.pi*t/0.06)*bdir
+    vo, po, _ = so.solve_nse(fvtd=fvtd, **skw)
+    vg, pg = snu.solve_nse(fvtd=fvtd, return_final_vp=True, **skw)
+    assert _rel(vg, vo) <= VTOL and _rel(pg, po) <= PTOL
+    v0, _, _ = so.solve_nse(**skw)
+    assert _rel(vg, v0) > 1e-4                 # the forcing does something
+
+
+def test_solve_nse_stokes_start_and_initial_pressure(snu, toy_prob):
+    """`start_ssstokes=True`, `inip=None` (snu:833-925, incl. the `A=cmmat`
+    quirk of the initial pressure)"""
+    p = toy_prob
+    skw = dict(A=p['smc']['A'], M=p['smc']['M'], J=p['smc']['J'],
+               fv=p['rhsd']['fv'], fp=p['rhsd']['fp'],
+               trange=np.linspace(0, 0.02, 5), V=p['th'],
+               invinds=p['invinds'], dbcinds=p['dbcinds'],
+               dbcvals=p['dbcvals'])
+    rec = scenarios.Recorder()
+    vo, po, _ = so.solve_nse(savevp=rec, **skw)
+    vpd = snu.solve_nse(start_ssstokes=True, return_vp_dict=True, **skw)
+    t0, tE = skw['trange'][0], skw['trange'][-1]
+    assert _rel(vpd[t0]['p'], rec.prss[0].reshape((-1, 1))) <= 1e-6
+    assert _rel(vpd[tE]['v'][p['invinds']], vo) <= VTOL
+    assert _rel(vpd[tE]['p'], po) <= PTOL
+
+
+# ---- a6/a8: solve_nse, Newton/Picard branch ------------------------------------
+def test_solve_nse_newton_picard_branch(snu, toy_prob):
+    kw, rec, _ = scenarios.build(variant='plain', seed=0, Nts=6, tE=0.03,
+                                 prob=toy_prob)
+    imex_oracle.cnab(**kw)
+    times, vels, _ = rec.arrays()
+    lin0 = {t: vels[k].reshape((-1, 1)) for k, t in enumerate(times)}
+    skw = _static_kwargs(toy_prob, kw)
+    vdo, pdo, histo = so.solve_nse(lin_vel_point=lin0, vel_pcrd_stps=1,
+                                   vel_nwtn_stps=2, **skw)
+    vdg, pdg = snu.solve_nse(lin_vel_point=lin0, vel_pcrd_stps=1,
+                             vel_nwtn_stps=2, treat_nonl_explicit=False,
+                             return_dictofvelstrs=True,
+                             return_dictofpstrs=True, **skw)
+    inv = toy_prob['invinds']
+    for t in kw['trange'][1:]:
+        assert _rel(vdg[t][inv], vdo[t]) <= VTOL, t
+        assert _rel(pdg[t], pdo[t]) <= PTOL, t
+        assert np.allclose(vdg[t][toy_prob['dbcinds'], 0],
+                           toy_prob['dbcvals'])
+
+
+# ---- f2: per-step tables of the resident loops --------------------------------
+def test_imex_rhs_table_equals_per_step_uploads(toy_prob):
+    """`dns_imex_set_rhs_table` + pipelined `run` == `set_rhs` + `step` per
+    step; running past the table fails loudly"""
+    from dolfin_navier_scipy_amd import saddle, _capi
+    M, A, J = (toy_prob['smc'][k] for k in 'MAJ')
+    NP, NV = J.shape
+    dt, nsteps = 5e-3, 37
+    rng = np.random.default_rng(12)
+    v0 = rng.standard_normal(NV)
+    gv = 1e-2*(M @ rng.standard_normal((NV, nsteps))).T.copy()
+    gp = 1e-4*rng.standard_normal((nsteps, NP))
+    outs = []
+    for mode in ('steps', 'table'):
+        system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+        system.setup_precond(cheb_degree=4, schur='dense',
+                             factorization='full')
+        stp = saddle.ImexStepper(system, (M - .5*dt*A).tocsr())
+        stp.set_state(v0)
+        cf = saddle.ImexStepper.coeffs(a_c=1., pscale=-1./dt, extrapolate=4)
+        opts = saddle.solve_opts(rtol=1e-12, maxiter=300, use_graph=True,
+                                 reorth=2)
+        if mode == 'steps':
+            for s in range(nsteps):
+                stp.set_rhs(gv[s], gp[s])
+                stp.step(cf, opts=opts)
+        else:
+            stp.set_rhs_table(gv, gp)
+            stp.run(10, cf, opts)
+            assert stp.table_position() == (10, nsteps - 10)
+            stp.run(nsteps - 10, cf, opts)
+            with pytest.raises(_capi.DnsError):
+                stp.run(1, cf, opts)           # table used up
+            stp.set_rhs(gv[-1], gp[-1])        # back to constant vectors
+            stp.run(1, cf, opts)
+        outs.append(stp.get_state())
+        stp.close()
+        system.close()
+    (vs, ps), (vt, pt) = outs
+    # (one more step with the last rhs in table mode: compare after undoing it
+    # is not possible -- so the step mode takes that step too)
+    system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    system.setup_precond(cheb_degree=4, schur='dense', factorization='full')
+    stp = saddle.ImexStepper(system, (M - .5*dt*A).tocsr())
+    stp.set_state(vs, ptilde_c=-dt*ps)
+    stp.set_rhs(gv[-1], gp[-1])
+    stp.step(cf, opts=opts)
+    vs2, ps2 = stp.get_state()
+    stp.close()
+    system.close()
+    assert _rel(vt, vs2) <= 1e-9 and _rel(pt, ps2) <= 1e-7
+
+
+def test_trap_tables_feedback_and_moving_boundary_terms(toy_prob):
+    """the extras of `_get_mats_rhs_ts` (snu:1036-1045) in `dns_trap_step`:
+    low-rank feedback by Sherman-Morrison-Woodbury and `mbcs_n - mbcs_c`, with
+    a time-dependent momentum rhs, against the oracle's sweep"""
+    from dolfin_navier_scipy_amd import convection
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    from dolfin_navier_scipy_amd.saddle import solve_opts
+    import test_gpu_newton_picard as tnp
+    s = tnp._setup(toy_prob, Nts=5, tE=0.025)
+    NV, NP = s['NV'], s['NP']
+    trange = s['trange']
+    rng = np.random.default_rng(21)
+    r = 2
+    umat = 1e-1*(s['M'] @ rng.standard_normal((NV, r)))
+    vmats = {t: rng.standard_normal((r, NV))/np.sqrt(NV) for t in trange}
+    mb = {t: 1e-3*np.sin(50*t)*(s['M'] @ np.ones((NV, 1))) for t in trange}
+    fdir = 1e-2*(s['M'] @ rng.standard_normal((NV, 1)))
+
+    def fvt(t):
+        return s['fv'] + np.cos(30*t)*fdir
+    lin = {t: s['appnd'](v) for t, v in s['lin0'].items()}
+    vdo, pdo, updo = npo.trapezoidal_sweep(
+        trange, s['iniv'], M=s['M'], A=s['A'], J=s['J'], fv=fvt, fp=s['fp'],
+        conv=s['conv'], appndbcs=s['appnd'], linpoints=lin, picard=False,
+        feedback=lambda t: (umat, vmats[t]), mbcs=lambda t: mb[t])
+    cv = convection.ConvectionP2.from_taylor_hood(
+        s['th'], s['inv'], s['dbcinds'], s['dbcvals'])
+    dt = trange[1] - trange[0]
+    ts = dnp.TrapezoidalStepper(s['M'], s['A'], s['J'], cv,
+                                nslots=trange.size, dt=dt,
+                                precond=dict(factorization='full'))
+    ts.set_rhs(s['fv'], s['fp'])
+    ts.set_tables(fv_tab=np.hstack([fvt(t) for t in trange]).T,
+                  mbc_tab=np.hstack([mb[t] for t in trange]).T)
+    for k, t in enumerate(trange):
+        ts.write_linpoint(0, k, s['lin0'][t])
+    ts.start(s['iniv'], newton=True)
+    opts = solve_opts(rtol=1e-12, maxiter=400, use_graph=False, reorth=1)
+    for k in range(1, trange.size):
+        fb = (umat, vmats[trange[k-1]], vmats[trange[k]])
+        ts.step(dt, 0, k, k, True, opts=opts, feedback=fb)
+        v, p = ts.state()
+        assert _rel(v, vdo[trange[k]]) <= VTOL, k
+        assert _rel(p, pdo[trange[k]]) <= PTOL, k
+    # (the oracle sums the update norm for inner-dof linearisation points only)
+    upd = sum(dt*npo.m_innerproduct(
+        s['M'], vdo[t] - s['lin0'][t]).item() for t in trange[1:])
+    assert abs(ts.update_norm() - upd) <= 1e-7*abs(upd)
+    ts.close()
+    cv.close()

@@ -1,0 +1,140 @@
+"""CPU checks of `oracle/snu_oracle.py` (the restatement of the algebraic half
+of `solve_nse` / `solve_steadystate_nse` and the `dts` helpers): pinned by
+definition -- the discrete equations hold -- and by consistency with the
+pinned integrator oracle."""
+import numpy as np
+import scipy.sparse as sps
+
+import scenarios
+from oracle import snu_oracle as so
+from oracle import imex_oracle, saddle_oracle
+
+
+def test_append_bcs_vec_semantics():
+    """dts:49-64: NaN start, inner values, then boundary values (they win;
+    of a repeated index the last entry wins)"""
+    vdim = 12
+    inv = np.array([0, 2, 3, 7, 9])
+    out = so.append_bcs_vec(np.arange(5.) + 1., vdim=vdim, invinds=inv,
+                            bcinds=[[1, 4], [7, 4]],
+                            bcvals=[[10., 20.], [30., 40.]])
+    assert out.shape == (vdim, 1)
+    exp = np.full(vdim, np.nan)
+    exp[inv] = np.arange(5.) + 1.
+    exp[[1, 4, 7, 4]] = [10., 20., 30., 40.]
+    assert np.array_equal(np.isnan(out[:, 0]), np.isnan(exp))
+    assert np.array_equal(out[~np.isnan(exp), 0], exp[~np.isnan(exp)])
+    assert out[4, 0] == 40. and out[7, 0] == 30.
+
+
+def test_condense_velmatsbybcs():
+    rng = np.random.default_rng(0)
+    A = sps.random(9, 9, density=0.5, random_state=1, format='csr')
+    inv, bci = np.array([0, 1, 3, 4, 6, 8]), [2, 5, 7]
+    bcv = rng.standard_normal(3)
+    Ac, fvbc = so.condense_velmatsbybcs(A, invinds=inv, dbcinds=bci,
+                                        dbcvals=bcv)
+    full = np.zeros((9, 1))
+    full[bci, 0] = bcv
+    assert np.allclose(Ac.toarray(), A.toarray()[np.ix_(inv, inv)])
+    assert np.allclose(fvbc, -(A @ full)[inv])
+    assert np.allclose(so.condense_velmatsbybcs(
+        A, invinds=inv, dbcinds=bci, dbcvals=bcv, get_rhs_only=True), fvbc)
+    # with a vector that carries the boundary values (snu:190-195)
+    vw = rng.standard_normal((9, 1))
+    r = so.condense_velmatsbybcs(A, invinds=inv, vwithbcs=vw,
+                                 get_rhs_only=True)
+    vz = vw.copy()
+    vz[inv] = 0
+    assert np.allclose(r, -(A @ vz)[inv])
+
+
+def test_decoupled_saddle_solve_equals_coupled(toy_prob):
+    """snu:1622-1628: `amat` omitted, `solve_A` callable, Schur-complement CG"""
+    import scipy.sparse.linalg as spsla
+    M, J = toy_prob['smc']['M'], toy_prob['smc']['J']
+    NP, NV = J.shape
+    rng = np.random.default_rng(3)
+    rhsv = M @ rng.standard_normal((NV, 1))
+    mlu = spsla.splu(sps.csc_matrix(M))
+    ref = saddle_oracle.solve_sadpnt_smw(amat=M, jmat=J, rhsv=rhsv)
+    dec = saddle_oracle.solve_sadpnt_smw(jmat=J, jmatT=J.T, rhsv=rhsv,
+                                         decouplevp=True, symmetric=True,
+                                         solve_A=mlu.solve, cgtol=1e-12)
+    assert np.linalg.norm(dec - ref) <= 1e-8*np.linalg.norm(ref)
+
+
+def test_steadystate_newton_residual(toy_prob):
+    """the converged Newton iterate solves the steady equations
+    `A v + N(v)v + J^T p = f`, `J v = g`"""
+    th, smc, rhsd = toy_prob['th'], toy_prob['smc'], toy_prob['rhsd']
+    inv = toy_prob['invinds']
+    vfull, p, norms = so.solve_steadystate_nse(
+        A=smc['A'], J=smc['J'], M=smc['M'], fv=rhsd['fv'], fp=rhsd['fp'],
+        V=th, invinds=inv, dbcinds=toy_prob['dbcinds'],
+        dbcvals=toy_prob['dbcvals'], vel_pcrd_stps=3, vel_nwtn_stps=8,
+        vel_nwtn_tol=1e-12)
+    assert norms[-1] < 1e-12 and len(norms) < 8
+    v = vfull[inv]
+    conv = th.convection_vec(vfull)[inv]
+    # (the stiffness columns of the Dirichlet dofs sit in rhsd['fv'])
+    res = smc['A'] @ v + conv - smc['J'].T @ p - rhsd['fv']
+    assert np.linalg.norm(res) <= 1e-9*np.linalg.norm(rhsd['fv'])
+    assert np.linalg.norm(smc['J'] @ v - rhsd['fp']) <= 1e-10
+
+
+def test_solve_nse_explicit_equals_integrator_oracle(toy_prob):
+    """static boundaries: the closures of snu:1103-1157 reduce to those of the
+    `plain` scenario, so `solve_nse` = `cnab` on the same data"""
+    kw, rec, aux = scenarios.build(variant='plain', seed=2, Nts=8, tE=0.04,
+                                   prob=toy_prob)
+    vo, po, ffo = imex_oracle.cnab(**kw)
+    th = toy_prob['th']
+    full0 = kw['appndbcs'](kw['inivel'], [])
+    v, p, ff = so.solve_nse(
+        A=toy_prob['smc']['A'], M=toy_prob['smc']['M'],
+        J=toy_prob['smc']['J'], fv=toy_prob['rhsd']['fv'],
+        fp=toy_prob['rhsd']['fp'], iniv=full0, inip=kw['inip'],
+        trange=kw['trange'], V=th, invinds=toy_prob['invinds'],
+        dbcinds=toy_prob['dbcinds'], dbcvals=toy_prob['dbcvals'])
+    assert ff == ffo
+    assert np.linalg.norm(v - vo) <= 1e-12*np.linalg.norm(vo)
+    assert np.linalg.norm(p - po) <= 1e-10*np.linalg.norm(po)
+
+
+def test_solve_nse_controlled_boundary_restriction(toy_prob):
+    """snu:729-770: controlled Dirichlet dofs leave the system; with the
+    control held at its base value the run equals the static one"""
+    th, stms = toy_prob['th'], toy_prob['stms']
+    dbcinds, dbcvals = toy_prob['dbcinds'], toy_prob['dbcvals']
+    from dolfin_navier_scipy_amd.fem import condense_sysmatsbybcs
+    ctrl = np.abs(dbcvals) > 0                     # inflow dofs -> controlled
+    statinds, statvals = dbcinds[~ctrl], dbcvals[~ctrl]
+    cntinds, cntvals = dbcinds[ctrl], dbcvals[ctrl]
+    smc_s, rhs_s, inv_s = condense_sysmatsbybcs(stms, statinds, statvals)
+    trange = np.linspace(0, 0.03, 7)
+    rng = np.random.default_rng(5)
+
+    def ufunc(t, vel=None, p=None, mode=None, memory=None):
+        return 1.0, memory
+    full0 = np.zeros((th.vdim, 1))
+    full0[0::2, 0] = 1.0
+    full0[dbcinds, 0] = dbcvals
+    inner_all = toy_prob['invinds']
+    full0[inner_all, 0] += 1e-2*rng.standard_normal(inner_all.size)
+    v1, p1, _ = so.solve_nse(
+        A=smc_s['A'], M=smc_s['M'], J=smc_s['J'], fv=rhs_s['fv'],
+        fp=rhs_s['fp'], iniv=full0, inip=np.zeros((smc_s['J'].shape[0], 1)),
+        trange=trange, V=th, invinds=inv_s, dbcinds=statinds.tolist(),
+        dbcvals=statvals.tolist(), diricontbcinds=[cntinds.tolist()],
+        diricontbcvals=[cntvals.tolist()], diricontfuncs=[ufunc],
+        diricontfuncmems=[None])
+    v2, p2, _ = so.solve_nse(
+        A=toy_prob['smc']['A'], M=toy_prob['smc']['M'],
+        J=toy_prob['smc']['J'], fv=toy_prob['rhsd']['fv'],
+        fp=toy_prob['rhsd']['fp'], iniv=full0,
+        inip=np.zeros((smc_s['J'].shape[0], 1)), trange=trange, V=th,
+        invinds=inner_all, dbcinds=dbcinds, dbcvals=dbcvals)
+    assert v1.shape == v2.shape
+    assert np.linalg.norm(v1 - v2) <= 1e-10*np.linalg.norm(v2)
+    assert np.linalg.norm(p1 - p2) <= 1e-8*np.linalg.norm(p2)
