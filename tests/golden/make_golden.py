@@ -18,6 +18,13 @@ reference functions are then run on the seeded scenarios of
   outputs: times, velocities (with BCs), pressures of every `savevp` call,
            final `v, p`, `ffflag`; and the sequence of `f_vdp` outputs that
            were fed (so a device loop can be replayed from a table)
+
+and, in `lau_calls.npz`, every call the reference integrators made to the
+boundary itself while they ran -- `lau.solve_sadpnt_smw(amat=, jmat=, jmatT=,
+rhsv=, rhsp=)` at tiu:402,466 (Heun start) and tiu:605 (`return_alu`) -- as
+`(amat, rhsv, rhsp) -> vp` pairs ("per-call pairs for the
+boundary itself"); `tests/test_gpu_saddle.py` replays them through the drop-in
+`lin_alg_utils` on the GPU.
 """
 import importlib.util
 import os
@@ -34,8 +41,32 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 REFTIU = '/root/reference/dolfin_navier_scipy/time_int_utils.py'
 
 
-def load_reference_tiu():
+LAU_CALLS = []          # (tag, amat, rhsv, rhsp, vp) of the reference's calls
+CALL_TAG = ['']
+
+
+def recording_lau():
+    """`oracle/saddle_oracle.py` behind a stub that records what the
+    reference's integrators hand to / get from the boundary"""
     from oracle import saddle_oracle
+    mod = types.ModuleType('recording_lau')
+
+    def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, rhsp=None, **kw):
+        out = saddle_oracle.solve_sadpnt_smw(amat=amat, jmat=jmat, rhsv=rhsv,
+                                             rhsp=rhsp, **kw)
+        sol = out[0] if isinstance(out, tuple) else out
+        NP = jmat.shape[0]
+        LAU_CALLS.append((CALL_TAG[0], amat.tocsr(), np.array(rhsv),
+                          np.zeros((NP, 1)) if rhsp is None
+                          else np.array(rhsp), np.array(sol)))
+        return out
+    mod.solve_sadpnt_smw = solve_sadpnt_smw
+    mod.app_prj_via_sadpnt = saddle_oracle.app_prj_via_sadpnt
+    return mod
+
+
+def load_reference_tiu():
+    saddle_oracle = recording_lau()
     pkg = types.ModuleType('sadptprj_riclyap_adi')
     pkg.lin_alg_utils = saddle_oracle
     sys.modules['sadptprj_riclyap_adi'] = pkg
@@ -73,6 +104,7 @@ def main():
                 fed.append(out.reshape(-1).copy())
                 return out
             kw['f_vdp'] = f_vdp
+            CALL_TAG[0] = '{0}_{1}_s{2}'.format(scheme, variant, seed)
             if scheme == 'sbdf2':
                 kw.pop('f_tvdp', None)
                 v, p, ff = reftiu.sbdftwo(**kw)
@@ -96,6 +128,7 @@ def main():
 
     def rhsv(t, vvec):
         return cfv + fvdp(appnd(vvec.reshape((-1, 1)), []))
+    CALL_TAG[0] = 'sie_plain_s3'
     vlist = reftiu.semi_implicit_euler(
         iniv=kw['inivel'], jmat=kw['J'], mmat=kw['M'], amat=kw['A'],
         rhsv=rhsv, trange=trange, data_trange=data_trange, fp=aux['cfp'])
@@ -105,6 +138,21 @@ def main():
     fn = os.path.join(HERE, 'imex_sie_plain_s3.npz')
     np.savez_compressed(fn, **out)
     print(fn, out['vlist'].shape)
+
+    # the boundary calls recorded on the way (all on the toy system's J)
+    calls = {'ncalls': np.array(len(LAU_CALLS))}
+    for k, (tag, amat, rv, rp, vp) in enumerate(LAU_CALLS):
+        amat.sort_indices()
+        calls['tag_{0}'.format(k)] = np.array(tag)
+        calls['amat_data_{0}'.format(k)] = amat.data
+        calls['amat_indices_{0}'.format(k)] = amat.indices
+        calls['amat_indptr_{0}'.format(k)] = amat.indptr
+        calls['rhsv_{0}'.format(k)] = rv
+        calls['rhsp_{0}'.format(k)] = rp
+        calls['vp_{0}'.format(k)] = vp
+    fn = os.path.join(HERE, 'lau_calls.npz')
+    np.savez_compressed(fn, **calls)
+    print(fn, len(LAU_CALLS), 'calls')
 
 
 if __name__ == '__main__':

@@ -181,3 +181,29 @@ def test_pipelined_run_warm_start_orders(gtiu, order, fact):
     assert mnorm(vg - v) <= VTOL*mnorm(v)
     assert np.linalg.norm(pg + pt/dt) <= \
         PTOL*np.linalg.norm(pt/dt)
+
+
+def test_run_reports_unconverged_steps(gtiu, toy_prob):
+    """a run in which solves end at `maxiter` must not come back
+    as a clean trajectory -- `run()` raises like `step()`, the record says how
+    many steps and which one first"""
+    from dolfin_navier_scipy_amd import saddle, _capi
+    M, A, J = (toy_prob['smc'][k] for k in 'MAJ')
+    NP, NV = J.shape
+    dt = 5e-3
+    rng = np.random.default_rng(3)
+    system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    system.setup_precond(cheb_degree=2, schur='jacobi')
+    stp = saddle.ImexStepper(system, (M - .5*dt*A).tocsr())
+    stp.set_state(rng.standard_normal(NV))
+    stp.set_rhs(M @ rng.standard_normal(NV), 1e-2*rng.standard_normal(NP))
+    cf = saddle.ImexStepper.coeffs(a_c=1., pscale=-1./dt, extrapolate=0)
+    opts = saddle.solve_opts(rtol=1e-13, maxiter=3, restart=3, use_graph=True,
+                             reorth=2)
+    with pytest.raises(_capi.NotConverged):
+        stp.run(6, cf, opts)
+    assert stp.last_run['unconverged'] >= 1 and stp.last_run['first_bad'] == 0
+    _, _, last = stp.run(2, cf, opts, raise_on_fail=False)
+    assert last['status'] == _capi.DNS_NOT_CONVERGED
+    stp.close()
+    system.close()

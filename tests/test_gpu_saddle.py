@@ -333,9 +333,61 @@ def test_lau_surface(small):
     pto = saddle_oracle.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=f,
                                            transposedprj=True)
     assert np.linalg.norm(ptf - pto) <= 1e-7*np.linalg.norm(pto)
-    with pytest.raises(NotImplementedError):
-        lau.solve_sadpnt_smw(jmat=J, rhsv=rhsv, decouplevp=True,
-                             symmetric=True, solve_A=lambda x: x)
+    # the decoupled variant (`amat` omitted, snu:1622): with solve_A = identity
+    # the system is [[I, J^T], [J, 0]]
+    dec = lau.solve_sadpnt_smw(jmat=J, rhsv=rhsv[:, :1], decouplevp=True,
+                               symmetric=True, solve_A=lambda x: x,
+                               cgtol=1e-12)
+    refd = saddle_oracle.solve_sadpnt_smw(amat=sps.identity(NV, format='csr'),
+                                          jmat=J, rhsv=rhsv[:, :1])
+    assert np.linalg.norm(dec - refd) <= 1e-8*np.linalg.norm(refd)
+    lau.clear_cache()
+
+
+def test_replay_of_the_reference_integrators_boundary_calls(golden_dir):
+    """the `(amat, jmat, rhsv, rhsp) -> vp` pairs recorded at the `lau` stub
+    while the reference's own `time_int_utils` ran (tests/golden/lau_calls.npz,
+    SURVEY.md 8c), replayed through the drop-in `lin_alg_utils` on the GPU:
+    Heun predictor `M + dt A` / corrector `M` (tiu:402,466) of six scenarios
+    and the `return_alu` call of `semi_implicit_euler` (tiu:605)"""
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    from test_oracle_golden import load_lau_calls
+    J, calls = load_lau_calls(golden_dir)
+    NP, NV = J.shape
+    for tag, amat, rhsv, rhsp, vp in calls:
+        got = lau.solve_sadpnt_smw(amat=amat, jmat=J, jmatT=J.T, rhsv=rhsv,
+                                   rhsp=rhsp)
+        assert got.shape == vp.shape, tag
+        if not np.any(vp):       # tiu:605 solves with a zero right-hand side
+            assert not np.any(got), tag
+            continue
+        ev = np.linalg.norm(got[:NV] - vp[:NV])/np.linalg.norm(vp[:NV])
+        ep = np.linalg.norm(got[NV:] - vp[NV:])/np.linalg.norm(vp[NV:])
+        assert ev <= 1e-9 and ep <= 1e-7, (tag, ev, ep)
+    # the same resident system served all calls with that pattern (two
+    # patterns: `M + dt A` and `M`)
+    assert len(lau._cache) <= 2
+    lau.clear_cache()
+
+
+def test_same_pattern_different_J_is_a_different_system(small):
+    """the cache of resident systems must not serve a stale `J`"""
+    from dolfin_navier_scipy_amd import lin_alg_utils as lau
+    M, A, J = small['M'], small['A'], small['J']
+    amat = (M + 0.01*A).tocsr()
+    rhsv, rhsp = small['rhsv'], small['rhsp']
+    lau.clear_cache()
+    v1 = lau.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv, rhsp=rhsp)
+    J2 = (2.0*J).tocsr()                       # same pattern, other values
+    v2 = lau.solve_sadpnt_smw(amat=amat, jmat=J2, rhsv=rhsv, rhsp=rhsp)
+    r1 = saddle_oracle.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv,
+                                        rhsp=rhsp)
+    r2 = saddle_oracle.solve_sadpnt_smw(amat=amat, jmat=J2, rhsv=rhsv,
+                                        rhsp=rhsp)
+    assert np.linalg.norm(v1 - r1) <= 1e-8*np.linalg.norm(r1)
+    assert np.linalg.norm(v2 - r2) <= 1e-8*np.linalg.norm(r2)
+    assert np.linalg.norm(r2 - r1) > 1e-3*np.linalg.norm(r1)
+    assert len(lau._cache) == 2
     lau.clear_cache()
 
 

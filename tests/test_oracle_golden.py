@@ -131,3 +131,34 @@ def test_saddle_oracle_residual_and_smw():
     g = rng.standard_normal((NV, 1))
     pg = saddle_oracle.app_prj_via_sadpnt(amat=M, jmat=J, rhsv=g)
     assert abs((pg.T @ f - g.T @ ptf).item()) <= 1e-9*np.linalg.norm(f)
+
+
+def load_lau_calls(golden_dir):
+    """the reference integrators' own calls to the boundary, recorded while
+    `make_golden.py` ran them: list of `(tag, amat, rhsv, rhsp, vp)`"""
+    dat = np.load(os.path.join(golden_dir, 'lau_calls.npz'))
+    J = load_system(golden_dir)['J']
+    NP, NV = J.shape
+    calls = []
+    for k in range(int(dat['ncalls'])):
+        amat = sps.csr_matrix((dat['amat_data_%d' % k],
+                               dat['amat_indices_%d' % k],
+                               dat['amat_indptr_%d' % k]), shape=(NV, NV))
+        calls.append((str(dat['tag_%d' % k]), amat, dat['rhsv_%d' % k],
+                      dat['rhsp_%d' % k], dat['vp_%d' % k]))
+    return J, calls
+
+
+def test_recorded_boundary_calls_are_saddle_solutions(golden_dir):
+    """every `(amat, jmat, rhsv, rhsp) -> vp` pair the reference's `tiu` sent
+    through `lau` (tiu:402,466,605) satisfies the saddle-point system"""
+    J, calls = load_lau_calls(golden_dir)
+    assert len(calls) == 13
+    NP, NV = J.shape
+    for tag, amat, rhsv, rhsp, vp in calls:
+        K = saddle_oracle.saddle_matrix(amat, J).tocsr()
+        b = np.vstack([rhsv.reshape((NV, -1)), rhsp.reshape((NP, -1))])
+        assert np.linalg.norm(K @ vp - b) <= 1e-11*np.linalg.norm(b), tag
+        again = saddle_oracle.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv,
+                                               rhsp=rhsp)
+        assert np.array_equal(again, vp), tag
