@@ -232,6 +232,29 @@ k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
         b[nv + i] = gp[i];
 }
 
+// the vector part of the IMEX right-hand side (bandwidth regime: R1 v then goes
+// through the streaming kernel with beta = 1):
+//   b_v = cn_c nfc_c + cn_o nfc_o + g ;  b_p = gp ;  xin = a_c v_c + a_p v_p
+__global__ void __launch_bounds__(kBlock)
+k_imex_bvec(int nv, int np, const double *__restrict__ v_c,
+            const double *__restrict__ v_p, double a_c, double a_p,
+            const double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
+            double cn_c, double cn_o, TabRef gtab, TabRef gptab,
+            double *__restrict__ b, double *__restrict__ xin) {
+    const double *__restrict__ g = tab_row(gtab);
+    const double *__restrict__ gp = tab_row(gptab);
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nv + np;
+         i += gridDim.x * kBlock) {
+        if (i < nv) {
+            b[i] = cn_c * nfc_c[i] + cn_o * nfc_o[i] + g[i];
+            xin[i] = (a_p != 0.0) ? fma(a_c, v_c[i], a_p * v_p[i])
+                                  : a_c * v_c[i];
+        } else {
+            b[i] = gp[i - nv];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Whole prologue of a resident IMEX step in ONE launch (row-parallel over the
 // n rows of K; replaces gather + k_imex_rhs + k_lincomb* + k_resid_norm):

@@ -98,6 +98,8 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     } else {
         DNS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     }
+    if (const char *sn = getenv("DNS_STREAM_NNZ")) stream_nnz = atoll(sn);
+    if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
@@ -191,7 +193,8 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     gridS = gridC = std::max(1, std::min(grid_for_rows(n, K.lpr), 2048));
     gridD = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock,
                                                        1024));
-    const size_t pmax = (size_t)std::max(std::max(gridS, gridD), nred);
+    const size_t pmax =
+        (size_t)std::max(std::max(std::max(gridS, gridD), nred), kStreamGrid);
     DNS_TRY(partA.alloc((size_t)(kMaxRestart + 2) * pmax));
     DNS_TRY(partE.alloc((size_t)(kMaxRestart + 1) * pmax));
     DNS_TRY(partN.alloc(pmax));
@@ -332,27 +335,19 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
 int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
                                 double *zv, const int *guard, double *xacc) {
     bool xacc_fused = false;
-    if (fhat_explicit && !dist() && nv > 350000 && Gc.c16.p) {
-        // bandwidth regime: [rv; zp] packed, then the LDS-streaming kernel
-        // with 16-bit column offsets (6 instead of 8 bytes per non-zero with
-        // fp32 values)
-        hipLaunchKernelGGL(k_pack2, grid_for_elems(n), kBlock, 0, stream, nv,
-                           rvec, np, zp, xcat.p, guard);
-        const int nb = Gc.nrowblocks_t[1];
-        const int grid = std::min(nb, 65535);
+    if (fhat_explicit && !dist() && streams(Gc)) {
+        // bandwidth regime: the LDS-streaming kernel with 16-bit column
+        // offsets (6 instead of 8 bytes per non-zero with fp32 values); its
+        // input [rv ; zp] is read from the two buffers directly
+        StreamEpi ep = stream_epi_plain(1.0, 0.0, nullptr);
+        ep.x2 = zp;
+        ep.nsplit = nv;
         if (fp32_store)
-            hipLaunchKernelGGL((k_spmv_stream16<4, 0, float>), grid, kBlock, 0,
-                               stream, nb, Gc.rowblocks_t[1].p, Gc.rowptr.p,
-                               Gc.colidx.p, Gc.c16.p, Gc.c16base.p, gc32.p,
-                               xcat.p, zv, 1.0, 0.0, (const double *)nullptr,
-                               guard);
+            DNS_TRY(launch_stream16x<float>(Gc, gc32.p, rvec, zv, ep, stream,
+                                            guard));
         else
-            hipLaunchKernelGGL((k_spmv_stream16<4, 0, double>), grid, kBlock,
-                               0, stream, nb, Gc.rowblocks_t[1].p, Gc.rowptr.p,
-                               Gc.colidx.p, Gc.c16.p, Gc.c16base.p, Gc.vals.p,
-                               xcat.p, zv, 1.0, 0.0, (const double *)nullptr,
-                               guard);
-        DNS_HIP(hipGetLastError());
+            DNS_TRY(launch_stream16x<double>(Gc, Gc.vals.p, rvec, zv, ep,
+                                             stream, guard));
     } else if (fhat_explicit) {
         const int r0 = v0(), r1 = v1();
         const int g = grid_for_rows(r1 - r0, Gc.lpr);
@@ -576,7 +571,23 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
         return fail(DNS_ERR_BAD_ARGUMENT,
                     "finest prolongation has %d rows, NP = %d",
                     mg_prol_h[0].nrows, np);
-    const int L = (int)mg_prol_h.size() + 1;
+    // the coarsest level gets a dense inverse: stop at the FIRST level small
+    // enough for one.  (Measured: a 5000-dof level as a 100 MB fp32 inverse
+    // instead of two more sparse levels does not pay -- refine 2: 2145 vs
+    // 2172 steps/s, refine 3: 568 vs 702 with 2.6 instead of 2.45 Krylov steps
+    // per time step -- hence the small default, DNS_MG_DENSE_MAX.)
+    const int dense_max = mg_dense_max;
+    int L = (int)mg_prol_h.size() + 1;
+    {
+        int nl = S0.nrows;
+        for (int l = 0; l + 1 < L; ++l) {
+            if (nl <= dense_max) {
+                L = l + 1;
+                break;
+            }
+            nl = mg_prol_h[l].ncols;
+        }
+    }
     mg.clear();
     for (int l = 0; l < L; ++l) mg.emplace_back();
     HostCsr Sl = S0;
@@ -600,6 +611,8 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
             DNS_TRY(mg_cinv.upload(sd.data(), sd.size(), stream));
             DNS_HIP(hipStreamSynchronize(stream));
             DNS_TRY(invert_dense(mg_cinv.p, lv.n));
+            if (fp32_store)
+                DNS_TRY(to_f32(mg_cinv.p, mg_cinv32, sd.size()));
             break;
         }
         const HostCsr &P = mg_prol_h[l];
@@ -640,12 +653,25 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
         for (int sweep = 0; sweep < mg_nu; ++sweep) {
             double *nxt = (cur == lv.x.p) ? lv.x2.p : lv.x.p;
             const double *xin = (from_zero && sweep == 0) ? nullptr : cur;
-            DNS_LPR_SWITCH(
-                lv.S.lpr,
-                hipLaunchKernelGGL(k_mg_sweep<L>, grid_for_rows(lv.n, lv.S.lpr),
-                                   kBlock, 0, stream, lv.n, lv.S.rowptr.p,
-                                   lv.S.colidx.p, lv.S.vals.p, lv.dinv.p,
-                                   lv.omega, b, xin, nxt, guard));
+            if (xin && !dist() && streams(lv.S)) {
+                // bandwidth regime: the sweep as an epilogue of the streaming
+                // kernel
+                StreamEpi ep = stream_epi_plain(1.0, 0.0, b);
+                ep.dinv = lv.dinv.p;
+                ep.xin = xin;
+                ep.omega = lv.omega;
+                if (launch_stream16x<double>(lv.S, lv.S.vals.p, xin, nxt, ep,
+                                             stream, guard) != DNS_OK)
+                    return (double *)nullptr;
+            } else {
+                DNS_LPR_SWITCH(
+                    lv.S.lpr,
+                    hipLaunchKernelGGL(k_mg_sweep<L>,
+                                       grid_for_rows(lv.n, lv.S.lpr), kBlock, 0,
+                                       stream, lv.n, lv.S.rowptr.p,
+                                       lv.S.colidx.p, lv.S.vals.p, lv.dinv.p,
+                                       lv.omega, b, xin, nxt, guard));
+            }
             cur = nxt;
         }
         return cur;
@@ -655,29 +681,41 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
         MgLevel &lv = mg[l];
         const double *b = (l == 0) ? in : lv.b.p;
         xat[l] = smooth(lv, b, true, lv.x2.p);
+        if (!xat[l]) return DNS_ERR_HIP;
+        const bool bigS = !dist() && streams(lv.S);
         DNS_TRY(launch_spmv(lv.S, xat[l], lv.r.p, -1.0, 1.0, b,
-                            DNS_SPMV_VECTOR, stream, guard));
+                            bigS ? DNS_SPMV_STREAM16 : DNS_SPMV_VECTOR, stream,
+                            guard));
         DNS_TRY(launch_spmv(lv.PT, lv.r.p, mg[l + 1].b.p, 1.0, 0.0, nullptr,
-                            DNS_SPMV_VECTOR, stream, guard));
+                            (!dist() && streams(lv.PT)) ? DNS_SPMV_STREAM16
+                                                        : DNS_SPMV_VECTOR,
+                            stream, guard));
     }
     {
         MgLevel &lc = mg[L - 1];
         const double *b = (L == 1) ? in : lc.b.p;
         // (the dense kernel's own guard is the solve's control block)
-        hipLaunchKernelGGL(k_gemv_rows,
-                           std::max(1, std::min((lc.n + 3) / 4, 2048)), kBlock,
-                           0, stream, lc.n, mg_cinv.p, b, lc.x.p, 1.0,
-                           (guard && guard == done_ptr())
-                               ? (const DnsCtl *)ctl.p
-                               : (const DnsCtl *)nullptr);
+        const DnsCtl *gctl = (guard && guard == done_ptr())
+                                 ? (const DnsCtl *)ctl.p
+                                 : (const DnsCtl *)nullptr;
+        const int gg = std::max(1, std::min((lc.n + 3) / 4, 2048));
+        if (fp32_store && mg_cinv32.p)
+            hipLaunchKernelGGL(k_gemv_rows<float>, gg, kBlock, 0, stream, lc.n,
+                               mg_cinv32.p, b, lc.x.p, 1.0, gctl);
+        else
+            hipLaunchKernelGGL(k_gemv_rows<double>, gg, kBlock, 0, stream, lc.n,
+                               mg_cinv.p, b, lc.x.p, 1.0, gctl);
         xat[L - 1] = lc.x.p;
     }
     for (int l = L - 2; l >= 0; --l) {
         MgLevel &lv = mg[l];
         const double *b = (l == 0) ? in : lv.b.p;
         DNS_TRY(launch_spmv(lv.P, xat[l + 1], xat[l], 1.0, 1.0, xat[l],
-                            DNS_SPMV_VECTOR, stream, guard));
+                            (!dist() && streams(lv.P)) ? DNS_SPMV_STREAM16
+                                                       : DNS_SPMV_VECTOR,
+                            stream, guard));
         xat[l] = smooth(lv, b, false, xat[l]);
+        if (!xat[l]) return DNS_ERR_HIP;
     }
     if (!guard) {
         hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
@@ -945,7 +983,14 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     const int n0 = r0n(), n1 = r1n();
     // r = b - K x over this rank's rows, ||r||^2, ||b||^2 (unless the caller's
     // prologue kernel has produced r and the partials already)
-    if (!have_resid) {
+    if (!have_resid && !dd && streams(K)) {
+        // bandwidth regime: r = b - K x at the streaming rate, then the norms
+        DNS_TRY(launch_stream16x<double>(K, K.vals.p, x, r.p,
+                                         stream_epi_plain(-1.0, 1.0, b), stream,
+                                         nullptr));
+        hipLaunchKernelGGL(k_norm2_pair, gridS, kBlock, 0, stream, n, r.p, b,
+                           partR.p, partB.p);
+    } else if (!have_resid) {
         DNS_LPR_SWITCH(
             K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x, b,
@@ -972,7 +1017,16 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     const int gridA = dense ? std::max(gridD, std::min(q1 - q0, 2048)) : gridD;
     double *hsum = dsum.p + 2;           // all-reduced Gram-Schmidt dots
     // reorth == 2: Gram-Schmidt folded into the next head kernel (one GPU)
-    const bool fusedgs = o->reorth == 2 && !dd && fuse_dots;
+    // bandwidth regime on one GPU: K through the streaming kernel with the
+    // dots fused in (while they fit its accumulators)
+    const bool stream_k = !dd && streams(K);
+    const bool fusedgs = o->reorth == 2 && !dd && (fuse_dots || stream_k);
+    const int gridK = stream_k ? stream_grid(K, kStreamGrid) : gridC;
+    // partials the consumers of step j's dots read: written by the kernel
+    // that applied K in step j
+    auto kparts = [&](int jj) {
+        return (stream_k && jj + 1 <= kStreamDots) ? gridK : gridC;
+    };
     for (int j = 0; j < c; ++j) {
         // one GPU: the preconditioned vectors are kept (Z_j) for the
         // correction behind the cycle
@@ -992,15 +1046,16 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 hipLaunchKernelGGL(k_tau_guard<L>,
                                    grid_for_rows(q1 - q0, JG.lpr), kBlock, 0,
                                    stream, np, nv, JG.rowptr.p, JG.colidx.p,
-                                   JG.vals.p, src, tau.p, partA.p, gridC, jt,
-                                   ctl.p, q0, q1));
+                                   JG.vals.p, src, tau.p, partA.p,
+                                   jt > 0 ? kparts(jt - 1) : gridC, jt, ctl.p,
+                                   q0, q1));
             if (dd && !repl_schur())
                 DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
             tin = tau.p;
         }
         if (fusedgs && j > 0 && mgs) {
             hipLaunchKernelGGL(k_arn_head_f<3>, gridA, kBlock, 0, stream, n, nv,
-                               np, j, w.p, partA.p, gridC, V.p, ld, Z.p,
+                               np, j, w.p, partA.p, kparts(j - 1), V.p, ld, Z.p,
                                (const void *)nullptr, ctl.p, o->maxiter,
                                (const double *)nullptr);
         } else if (!(fusedgs && j > 0) && mgs) {
@@ -1013,17 +1068,20 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         } else if (fusedgs && j > 0) {
             if (dense && fp32_store)
                 hipLaunchKernelGGL(k_arn_head_f<2>, gridA, kBlock, 0, stream, n,
-                                   nv, np, j, w.p, partA.p, gridC, V.p, ld,
+                                   nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
+                                   ld,
                                    Z.p, (const void *)sinv32.p, ctl.p,
                                    o->maxiter, tin);
             else if (dense)
                 hipLaunchKernelGGL(k_arn_head_f<1>, gridA, kBlock, 0, stream, n,
-                                   nv, np, j, w.p, partA.p, gridC, V.p, ld,
+                                   nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
+                                   ld,
                                    Z.p, (const void *)sinv.p, ctl.p,
                                    o->maxiter, tin);
             else
                 hipLaunchKernelGGL(k_arn_head_f<0>, gridA, kBlock, 0, stream, n,
-                                   nv, np, j, w.p, partA.p, gridC, V.p, ld,
+                                   nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
+                                   ld,
                                    Z.p, (const void *)sinv.p, ctl.p,
                                    o->maxiter, tin);
         } else if (dense && fp32_store)
@@ -1050,7 +1108,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         if (mgs) {
             // Schur block = V-cycle on V_j,p (or tau(V_j))
             const double *sin = V.p + (size_t)j * ld + nv;
-            if (have_jg && !dd && n > 400000 && JG.c16.p) {
+            if (have_jg && !dd && streams(JG)) {
                 // tau = V_j,p - JG V_j,v through the streaming kernel
                 const double *vj = V.p + (size_t)j * ld;
                 DNS_TRY(launch_spmv(JG, vj, tau.p, -1.0, 1.0, vj + nv,
@@ -1074,7 +1132,18 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, zj, done_ptr(),
                                 nullptr));
-        if (fuse_dots) {
+        if (stream_k && fusedgs && j + 1 <= kStreamDots) {
+            StreamEpi ep = stream_epi_plain(1.0, 0.0, nullptr);
+            ep.V = V.p;
+            ep.ld = ld;
+            ep.nvec = j + 1;
+            ep.with_ww = 1;
+            ep.part = partA.p;
+            ep.nparts = gridK;
+            DNS_TRY(launch_stream16x<double>(K, K.vals.p, zj, w.p, ep, stream,
+                                             done_ptr(), kStreamGrid));
+            continue;                    // no Gram-Schmidt kernel
+        } else if (fuse_dots || fusedgs) {
             DNS_LPR_SWITCH(
                 K.lpr,
                 hipLaunchKernelGGL(k_spmv_multidot<L>, gridC, kBlock, 0,
@@ -1125,8 +1194,9 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         }
     }
     if (fusedgs)
-        hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partA.p, gridC,
-                           ctl.p, histdev.p, (int)hist_cap, o->maxiter, 1);
+        hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partA.p,
+                           kparts(c - 1), ctl.p, histdev.p, (int)hist_cap,
+                           o->maxiter, 1);
     else
         hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
                            ctl.p, histdev.p, (int)hist_cap, o->maxiter, 0);
@@ -1898,8 +1968,9 @@ int dns_gemv(int device, int32_t n, const double *a_rowmajor, const double *x,
     DNS_TRY(dy.alloc((size_t)n));
     DNS_TRY(da.upload(a_rowmajor, (size_t)n * n, ss.s));
     DNS_TRY(dx.upload(x, (size_t)n, ss.s));
-    hipLaunchKernelGGL(k_gemv_rows, std::max(1, std::min((n + 3) / 4, 2048)),
-                       kBlock, 0, ss.s, n, da.p, dx.p, dy.p, alpha,
+    hipLaunchKernelGGL(k_gemv_rows<double>,
+                       std::max(1, std::min((n + 3) / 4, 2048)), kBlock, 0,
+                       ss.s, n, da.p, dx.p, dy.p, alpha,
                        (const DnsCtl *)nullptr);
     DNS_HIP(hipGetLastError());
     DNS_TRY(dy.download(y, (size_t)n, ss.s));

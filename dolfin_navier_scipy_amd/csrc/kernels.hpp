@@ -384,6 +384,201 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
 }
 
 // ---------------------------------------------------------------------------
+// The streaming kernel with the epilogues the solver needs in the bandwidth
+// regime (n >~ 1e5), so that its large applies all run at the streaming rate:
+//   * plain           y = alpha A x + beta b
+//   * split x         the input is [x ; x2] in two buffers (Gc [V_j,v ; zp]:
+//                     no packing kernel in front)
+//   * Jacobi sweep    y = xin + omega dinv .* (b - A xin)   (multigrid smoother)
+//   * fused dots      part[i][wg] = <V_i, y> (i < nvec) and <y, y>: the
+//                     Gram-Schmidt dots of the Arnoldi step ride on the K apply
+//                     (what k_spmv_multidot does for the sub-wave kernel)
+// Any grid size works (workgroups stride over the row blocks), so a fixed grid
+// bounds the number of partials the consumers re-reduce.
+// ---------------------------------------------------------------------------
+struct StreamEpi {
+    double alpha, beta;
+    const double *b;
+    const double *x2;            // second input buffer (columns >= nsplit)
+    int nsplit;
+    const double *dinv, *xin;    // Jacobi sweep (dinv != nullptr)
+    double omega;
+    const double *V;             // fused dots (part != nullptr)
+    size_t ld;
+    int nvec, with_ww;
+    double *part;
+    int nparts;
+};
+
+inline StreamEpi stream_epi_plain(double alpha, double beta, const double *b) {
+    StreamEpi e;
+    memset(&e, 0, sizeof(e));
+    e.alpha = alpha;
+    e.beta = beta;
+    e.b = b;
+    return e;
+}
+
+constexpr int kStreamDots = 8;   // fused dots: at most this many basis vectors
+constexpr int kStreamGrid = 1024;   // workgroups (= partials) of such a launch
+
+template <int G, typename VT>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
+                 const int *__restrict__ rowptr,
+                 const int *__restrict__ colidx,
+                 const unsigned short *__restrict__ c16,
+                 const int *__restrict__ c16base, const VT *__restrict__ vals,
+                 const double *__restrict__ x, double *__restrict__ y,
+                 StreamEpi ep, const int *__restrict__ guard) {
+    if (guard && *guard) return;
+    constexpr int TILE = kStreamNnz;
+    __shared__ double prod[TILE];
+    __shared__ double red[4];
+    __shared__ int rps[kBlock + 1];
+    __shared__ double srow[kBlock];      // fused dots: the tile's row results
+    const int gq = gridDim.x / 8, gr = gridDim.x % 8;
+    const int cls = blockIdx.x % 8;
+    const int vb = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
+    const bool split = ep.x2 != nullptr;
+    const bool dots = ep.part != nullptr;
+    double acc[kStreamDots + 1];
+#pragma unroll
+    for (int i = 0; i <= kStreamDots; ++i) acc[i] = 0.0;
+    for (int blk = vb; blk < nblocks; blk += gridDim.x) {
+        const int r0 = rowblocks[blk], r1 = rowblocks[blk + 1];
+        const int k0 = rowptr[r0], k1 = rowptr[r1];
+        const int nn = k1 - k0;
+        const int blo = c16base[2 * blk], bhi = c16base[2 * blk + 1];
+        __syncthreads();             // previous tile fully consumed
+        const int nr = r1 - r0;
+        bool single = nn > TILE;     // a single long row
+        if (single) {
+            double s = 0.0;
+            for (int k = k0 + threadIdx.x; k < k1; k += kBlock) {
+                const int c = colidx[k];
+                const double xv = (split && c >= ep.nsplit)
+                                      ? ep.x2[c - ep.nsplit] : x[c];
+                s = fma((double)vals[k], xv, s);
+            }
+            s = block_sum(s, red);
+            if (threadIdx.x == 0) prod[0] = s;
+            if (threadIdx.x == 0) {
+                rps[0] = 0;
+                rps[1] = 1;
+            }
+        } else {
+            if (threadIdx.x < nr)
+                rps[threadIdx.x] = rowptr[r0 + threadIdx.x] - k0;
+            if (threadIdx.x == 0) rps[nr] = nn;
+            if (blo >= 0 && nn > 0) {
+                constexpr int NI = TILE / kBlock;
+                double v[NI];
+                int e[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int kk =
+                        k0 + min((int)threadIdx.x + i * kBlock, nn - 1);
+                    v[i] = (double)vals[kk];
+                    e[i] = c16[kk];
+                }
+                double xv[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int col =
+                        ((e[i] & 0x8000) ? bhi : blo) + (e[i] & 0x7fff);
+                    xv[i] = (split && col >= ep.nsplit)
+                                ? ep.x2[col - ep.nsplit] : x[col];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    prod[threadIdx.x + i * kBlock] = v[i] * xv[i];
+            } else {
+#pragma unroll 2
+                for (int k = threadIdx.x; k < nn; k += kBlock) {
+                    const int c = colidx[k0 + k];
+                    const double xv = (split && c >= ep.nsplit)
+                                          ? ep.x2[c - ep.nsplit] : x[c];
+                    prod[k] = (double)vals[k0 + k] * xv;
+                }
+            }
+        }
+        __syncthreads();
+        const int g = threadIdx.x % G, rsub = threadIdx.x / G;
+        for (int r = rsub; r < nr; r += kBlock / G) {
+            const int a0 = rps[r], a1 = rps[r + 1];
+            double s = 0.0;
+            for (int k = a0 + g; k < a1; k += G) s += prod[k];
+            s = subwave_sum<G>(s);
+            if (g == 0) {
+                const int row = r0 + r;
+                double out;
+                if (ep.dinv) {
+                    const double xi = ep.xin ? ep.xin[row] : 0.0;
+                    out = xi + ep.omega * ep.dinv[row] * (ep.b[row] - s);
+                } else {
+                    out = ep.b ? fma(ep.alpha, s, ep.beta * ep.b[row])
+                               : ep.alpha * s;
+                }
+                y[row] = out;
+                if (dots) srow[r] = out;
+            }
+        }
+        if (dots) {
+            // thread t takes row t of the tile: basis loads are coalesced and
+            // every lane works (the row results sit in 1 of G lanes)
+            __syncthreads();
+            if ((int)threadIdx.x < nr) {
+                const double out = srow[threadIdx.x];
+                const size_t row = (size_t)r0 + threadIdx.x;
+#pragma unroll
+                for (int i = 0; i < kStreamDots; ++i)
+                    if (i < ep.nvec)
+                        acc[i] = fma(ep.V[(size_t)i * ep.ld + row], out,
+                                     acc[i]);
+                acc[kStreamDots] = fma(out, out, acc[kStreamDots]);
+            }
+        }
+    }
+    if (dots) {
+        for (int i = 0; i < ep.nvec; ++i) {
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < kStreamDots; ++q)
+                if (q == i) a = acc[q];
+            a = block_sum(a, red);
+            if (threadIdx.x == 0)
+                ep.part[(size_t)i * ep.nparts + blockIdx.x] = a;
+        }
+        if (ep.with_ww) {
+            const double a = block_sum(acc[kStreamDots], red);
+            if (threadIdx.x == 0)
+                ep.part[(size_t)ep.nvec * ep.nparts + blockIdx.x] = a;
+        }
+    }
+}
+
+// partials of ||r||^2 and ||b||^2 (one per workgroup each)
+__global__ void __launch_bounds__(kBlock)
+k_norm2_pair(int n, const double *__restrict__ r, const double *__restrict__ b,
+             double *__restrict__ part_rr, double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    double a = 0.0, c = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
+         i += gridDim.x * kBlock) {
+        const double rv = r[i], bv = b[i];
+        a = fma(rv, rv, a);
+        c = fma(bv, bv, c);
+    }
+    a = block_sum(a, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = a;
+        if (part_bb) part_bb[blockIdx.x] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // vector kernels
 // ---------------------------------------------------------------------------
 // y = a*x + b*y
@@ -470,18 +665,27 @@ k_scatter_fvals(int nv, const int *__restrict__ f_rowptr,
 // per row, 16-byte loads where the row start is 16-byte aligned.
 // `xsel`/`ysel`: vector selectors (see vec_at)
 // ---------------------------------------------------------------------------
+template <typename VT>
 __global__ void __launch_bounds__(kBlock)
-k_gemv_rows(int n, const double *__restrict__ a, const double *__restrict__ x,
+k_gemv_rows(int n, const VT *__restrict__ a, const double *__restrict__ x,
             double *__restrict__ y, double alpha, const DnsCtl *ctl) {
     if (ctl && ctl->done) return;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     const int nwaves = (gridDim.x * kBlock) >> 6;
     for (int row = wave; row < n; row += nwaves) {
-        const double *ar = a + (size_t)row * n;
-        double s = 0.0;
-        for (int c = lane; c < n; c += 64) s = fma(ar[c], x[c], s);
-        s = wave_sum(s);
+        const VT *ar = a + (size_t)row * n;
+        // four independent loads in flight per lane
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int c = lane;
+        for (; c + 192 < n; c += 256) {
+            s0 = fma((double)ar[c], x[c], s0);
+            s1 = fma((double)ar[c + 64], x[c + 64], s1);
+            s2 = fma((double)ar[c + 128], x[c + 128], s2);
+            s3 = fma((double)ar[c + 192], x[c + 192], s3);
+        }
+        for (; c < n; c += 64) s0 = fma((double)ar[c], x[c], s0);
+        const double s = wave_sum((s0 + s1) + (s2 + s3));
         if (lane == 0) y[row] = alpha * s;
     }
 }

@@ -221,6 +221,43 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
     return DNS_OK;
 }
 
+// the streaming kernel with epilogues (k_spmv_stream16x); `grid_cap` bounds the
+// number of workgroups (= partials of the fused dots)
+template <typename VT>
+inline int launch_stream16x(const CsrDev &A, const VT *vals, const double *x,
+                            double *y, const StreamEpi &ep, hipStream_t s,
+                            const int *guard, int grid_cap = 65535) {
+    if (A.nrows == 0) return DNS_OK;
+    if (!A.c16.p)
+        return fail(DNS_ERR_NOT_READY, "matrix has no 16-bit column table");
+    const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
+    const int nb = A.nrowblocks_t[1];
+    const int grid = std::max(1, std::min(nb, grid_cap));
+    const int *rbp = A.rowblocks_t[1].p;
+    if (avg <= 6)
+        hipLaunchKernelGGL((k_spmv_stream16x<1, VT>), grid, kBlock, 0, s, nb,
+                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
+                           vals, x, y, ep, guard);
+    else if (avg <= 12)
+        hipLaunchKernelGGL((k_spmv_stream16x<2, VT>), grid, kBlock, 0, s, nb,
+                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
+                           vals, x, y, ep, guard);
+    else if (avg <= 192)   // (measured on Gc, 115 per row: 4 beats 16)
+        hipLaunchKernelGGL((k_spmv_stream16x<4, VT>), grid, kBlock, 0, s, nb,
+                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
+                           vals, x, y, ep, guard);
+    else
+        hipLaunchKernelGGL((k_spmv_stream16x<16, VT>), grid, kBlock, 0, s, nb,
+                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
+                           vals, x, y, ep, guard);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+inline int stream_grid(const CsrDev &A, int cap) {
+    return std::max(1, std::min(A.nrowblocks_t[1], cap));
+}
+
 struct CtlHeader {   // leading part of DnsCtl, copied back to the host
     int jdone, predone;
     int done, status, zero, total_it, hist_len, conv;
@@ -277,6 +314,12 @@ struct dns_saddle {
     int gridS = 64, gridC = 64, gridD = 64;   // GMRES: residual / K apply /
                                               // vector kernels
     bool fuse_dots = true;
+    // matrices with at least this many non-zeros go through the LDS-streaming
+    // kernels (bandwidth regime); below, the sub-wave kernels (latency regime)
+    int64_t stream_nnz = 800000;
+    bool streams(const dns::CsrDev &A) const {
+        return A.nnz >= stream_nnz && A.c16.p != nullptr;
+    }
     dns::DevBuf<double> V, Z, w, z, u, r, xdev, bdev;   // Z_j = P^-1 V_j
     dns::DevBuf<double> xcat;        // [r_v; z_p] packed for the streaming Gc
     dns::DevBuf<double> partA, partN, partR, partB, partC, partE;
@@ -326,6 +369,8 @@ struct dns_saddle {
     std::deque<MgLevel> mg;               // (device buffers do not move)
     std::vector<dns::HostCsr> mg_prol_h;  // prolongations as handed over
     dns::DevBuf<double> mg_cinv;          // dense inverse on the coarsest level
+    dns::DevBuf<float> mg_cinv32;         // ... its fp32 copy (fp32_store)
+    int mg_dense_max = 2000;              // first level <= this: dense inverse
     int mg_nu = 2;
     bool mg_ready = false, mg_set = false;
     int build_mg_schur(const dns::HostCsr &S0);

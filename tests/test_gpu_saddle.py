@@ -434,7 +434,10 @@ def test_multigrid_schur_block_on_a_refined_mesh(sad):
                 1e-9*np.linalg.norm(ref[:NV]), name
             assert np.linalg.norm(x[NV:] - ref[NV:]) <= \
                 1e-6*np.linalg.norm(ref[NV:]), name
-        its[name] = st['iters']
+            if reorth == 1:
+                # (the fused Gram-Schmidt may end a cold-start cycle early and
+                # go on with the explicit kernel: its count is not comparable)
+                its[name] = st['iters']
         system.close()
     assert abs(its['mg 1 level'] - its['dense']) <= 1    # (fp64 vs fp32 inverse)
     assert its['mg full'] <= 3*its['dense'] + 2
@@ -508,3 +511,70 @@ def test_stiff_penalty_entries_like_robin_control(sad, small):
         assert st['iters'] <= 60, (fact, st['iters'])
         assert np.linalg.norm(x[:NV] - ref[:NV]) <= 1e-8*np.linalg.norm(ref[:NV])
         system.close()
+
+
+def test_streaming_kernels_forced_on_small_systems(sad, monkeypatch):
+    """the bandwidth-regime kernels (`k_spmv_stream16x`: split input for Gc,
+    fused Gram-Schmidt dots on the K apply, Jacobi-sweep epilogue of the
+    multigrid smoother, streamed residual / IMEX right-hand side) normally
+    start at 8e5 non-zeros; `DNS_STREAM_NNZ=1` routes a small system through
+    all of them -- same answers as the latency-regime kernels and the oracle"""
+    from dolfin_navier_scipy_amd.fem import (
+        get_sysmats, cylinder_mesh_hierarchy, pressure_prolongations,
+        TaylorHood)
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, refine=1, Re=100)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    hier = cylinder_mesh_hierarchy(N=2, refine=1)
+    spaces = [TaylorHood(m) for m, _ in hier][::-1]
+    prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
+    dt = 1./1024
+    F, R1 = (M + .5*dt*A).tocsr(), (M - .5*dt*A).tocsr()
+    rng = np.random.default_rng(5)
+    rhsv = M @ rng.standard_normal(NV)
+    rhsp = 1e-3*(J @ rng.standard_normal(NV))
+    ref = saddle_oracle.solve_sadpnt_smw(amat=F, jmat=J, rhsv=rhsv,
+                                         rhsp=rhsp).reshape(-1)
+    v0 = ref[:NV].copy()
+    res = {}
+    for mode, thr in (('latency', '1000000000'), ('stream', '1')):
+        monkeypatch.setenv('DNS_STREAM_NNZ', thr)
+        monkeypatch.setenv('DNS_MG_DENSE_MAX', '2000')
+        system = sad.SaddleSystem(F, J)
+        system.set_schur_mg(prols)
+        system.setup_precond(cheb_degree=6, schur='mg', drop_tol=1e-3,
+                             factorization='full')
+        for reorth in (1, 2):
+            x = system.solve(rhsv, rhsp, rtol=1e-11, maxiter=400,
+                             reorth=reorth, use_graph=(reorth == 2))
+            st = system.last_stats
+            assert st['status'] == 0 and st['true_relres'] <= 2e-11, (mode, st)
+            assert np.linalg.norm(x[:NV] - ref[:NV]) <= \
+                1e-9*np.linalg.norm(ref[:NV]), mode
+            assert np.linalg.norm(x[NV:] - ref[NV:]) <= \
+                1e-6*np.linalg.norm(ref[NV:]), mode
+            if reorth == 1:
+                res[mode + '_its'] = st['iters']
+        # resident stepping: streamed rhs / residual kernels in the prologue
+        stp = sad.ImexStepper(system, R1)
+        stp.set_state(v0)
+        stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+        cf = sad.ImexStepper.coeffs(a_c=1., pscale=-1./dt, extrapolate=4)
+        opts = sad.solve_opts(rtol=1e-12, maxiter=300, use_graph=True,
+                              reorth=2)
+        stp.run(21, cf, opts)
+        res[mode] = stp.get_state()
+        stp.close()
+        system.close()
+    assert abs(res['stream_its'] - res['latency_its']) <= 1
+    (vl, pl), (vs, ps) = res['latency'], res['stream']
+    assert np.linalg.norm(vs - vl) <= 1e-9*np.linalg.norm(vl)
+    assert np.linalg.norm(ps - pl) <= 1e-7*np.linalg.norm(pl)
+    # and against the factor-once oracle loop (tiu:104-143, no convection)
+    lu = saddle_oracle.SaddleLU(F, J)
+    v = v0.reshape((-1, 1))
+    for _ in range(21):
+        vp = lu(np.vstack([R1 @ v + dt*rhsd['fv'], rhsd['fp']]))
+        v, pt = vp[:NV], vp[NV:]
+    assert np.linalg.norm(vs - v) <= 1e-8*np.linalg.norm(v)
+    assert np.linalg.norm(ps + pt/dt) <= 1e-6*np.linalg.norm(pt/dt)
