@@ -30,14 +30,14 @@ __constant__ ConvTables c_conv;
 // the twelve local sums are reduced over the eight lanes with xor shuffles and
 // lane l stores slots l and l + 8.  (One thread per cell left the kernel with
 // 18 workgroups and a serial chain of ~700 fp64 operations: ~10 us at N=2.)
-__global__ void __launch_bounds__(kBlock)
-k_conv_cells(int ncells, const int *__restrict__ cellmap,   // [12][ncells]
+__device__ __forceinline__ void
+conv_cells_block(int bid, int ncells, const int *__restrict__ cellmap,   // [12][ncells]
              const double *__restrict__ glam,               // [6][ncells]
              const double *__restrict__ area,
              const double *__restrict__ v_inner, TabRef dbctab,
              double *__restrict__ cellvals) {               // [12][ncells]
     const double *__restrict__ dbcvals = tab_row(dbctab);
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int t = bid * kBlock + threadIdx.x;
     const int c = t >> 3;
     const int q = t & 7;
     const bool live = c < ncells;        // whole 8-lane groups are live or not
@@ -94,6 +94,15 @@ k_conv_cells(int ncells, const int *__restrict__ cellmap,   // [12][ncells]
         cellvals[(size_t)q * ncells + c] = mine;
         if (q < 4) cellvals[(size_t)(q + 8) * ncells + c] = mine8;
     }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_conv_cells(int ncells, const int *__restrict__ cellmap,
+             const double *__restrict__ glam, const double *__restrict__ area,
+             const double *__restrict__ v_inner, TabRef dbctab,
+             double *__restrict__ cellvals) {
+    conv_cells_block(blockIdx.x, ncells, cellmap, glam, area, v_inner, dbctab,
+                     cellvals);
 }
 
 __global__ void __launch_bounds__(kBlock)

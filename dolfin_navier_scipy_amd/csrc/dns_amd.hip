@@ -396,7 +396,8 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
         // `rbase + nv`
         DNS_LPR_SWITCH(
             JG.lpr,
-            hipLaunchKernelGGL(k_tau_guard<L>, grid_for_rows(r1 - r0, JG.lpr),
+            hipLaunchKernelGGL(k_tau_guard<L>,
+                               grid_for_rows(r1 - r0, JG.lpr == 64 ? 128 : JG.lpr),
                                kBlock, 0, stream, np, nv, JG.rowptr.p,
                                JG.colidx.p, JG.vals.p, rvec, tau.p,
                                (const double *)nullptr, 0, 0, ctl.p, r0, r1));
@@ -999,7 +1000,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     // what the consumers of a reduction read: the per-workgroup partials on
     // one GPU; the all-reduced sums (one "partial" per scalar) across ranks
     const double *rr_part = partR.p, *bb_part = partB.p;
-    int rr_np = gridS;
+    int rr_np = (have_resid && prologue_nparts > 0) ? prologue_nparts : gridS;
     if (dd) {
         DNS_TRY(comm->allgatherv(r.p, st_n, stream));
         hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, gridS,
@@ -1014,7 +1015,9 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     const bool dense = popts.schur == DNS_SCHUR_DENSE;
     const int q0 = p0(), q1 = p1();
     // workgroups of the head kernel: one workgroup per Schur row
-    const int gridA = dense ? std::max(gridD, std::min(q1 - q0, 2048)) : gridD;
+    // (dense Schur rows: one wave each, four per workgroup)
+    const int gridA =
+        dense ? std::max(gridD, std::min((q1 - q0 + 3) / 4, 2048)) : gridD;
     double *hsum = dsum.p + 2;           // all-reduced Gram-Schmidt dots
     // reorth == 2: Gram-Schmidt folded into the next head kernel (one GPU)
     // bandwidth regime on one GPU: K through the streaming kernel with the
@@ -1044,7 +1047,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             DNS_LPR_SWITCH(
                 JG.lpr,
                 hipLaunchKernelGGL(k_tau_guard<L>,
-                                   grid_for_rows(q1 - q0, JG.lpr), kBlock, 0,
+                                   grid_for_rows(q1 - q0, JG.lpr == 64 ? 128 : JG.lpr),
+                                   kBlock, 0,
                                    stream, np, nv, JG.rowptr.p, JG.colidx.p,
                                    JG.vals.p, src, tau.p, partA.p,
                                    jt > 0 ? kparts(jt - 1) : gridC, jt, ctl.p,
@@ -1118,7 +1122,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 DNS_LPR_SWITCH(
                     JG.lpr,
                     hipLaunchKernelGGL(k_tau_guard<L>,
-                                       grid_for_rows(np, JG.lpr), kBlock, 0,
+                                       grid_for_rows(np, JG.lpr == 64 ? 128 : JG.lpr),
+                                       kBlock, 0,
                                        stream, np, nv, JG.rowptr.p,
                                        JG.colidx.p, JG.vals.p,
                                        V.p + (size_t)j * ld, tau.p,
@@ -1193,13 +1198,16 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                w.p, hpart, hnp, j, 0, partN.p, gridD, ctl.p);
         }
     }
-    if (fusedgs)
-        hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partA.p,
-                           kparts(c - 1), ctl.p, histdev.p, (int)hist_cap,
-                           o->maxiter, 1);
-    else
-        hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
-                           ctl.p, histdev.p, (int)hist_cap, o->maxiter, 0);
+    if (fusedgs) {
+        // one GPU, fused Gram-Schmidt: tail and correction in ONE launch
+        hipLaunchKernelGGL(k_arn_tail_acc, gridD, kBlock, 0, stream, c, n,
+                           partA.p, kparts(c - 1), ctl.p, histdev.p,
+                           (int)hist_cap, o->maxiter, Z.p, ld, x);
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
+    }
+    hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
+                       ctl.p, histdev.p, (int)hist_cap, o->maxiter, 0);
     if (dd) {
         hipLaunchKernelGGL(k_basis_combine, gridD, kBlock, 0, stream, n, V.p,
                            ld, ctl.p, u.p);
@@ -1735,7 +1743,8 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
     hipStream_t s = h->stream;
     const int j = 3, n = h->n, nv = h->nv, np = h->np;
     const bool dense = h->popts.schur == DNS_SCHUR_DENSE;
-    const int gridA = dense ? std::max(h->gridD, std::min(np, 2048)) : h->gridD;
+    const int gridA =
+        dense ? std::max(h->gridD, std::min((np + 3) / 4, 2048)) : h->gridD;
     double *zp = h->z.p + nv;
     auto body = [&]() -> int {
         // which == 8: the four kernels of one Arnoldi step in sequence;

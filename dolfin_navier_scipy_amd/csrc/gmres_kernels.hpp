@@ -133,7 +133,22 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     // GPU); normalisation and the control block are done by every rank alike
     if (j > 0 && ctl->done) return;
     __shared__ double sc[2];
-    __shared__ double red4[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gwave = blockIdx.x * (kBlock / 64) + wave;
+    const int nwaves = gridDim.x * (kBlock / 64);
+    const double *sp = sp_in ? sp_in : src + nv;
+    // dense Schur rows: one wave per row; the first row's loads are issued
+    // BEFORE the reduction of the norm partials (they do not depend on it)
+    double s_first = 0.0;
+    const int row_first = prow0 + gwave;
+    if ((SK == 1 || SK == 2) && row_first < prow1) {
+        if (SK == 1)
+            s_first = dense_row_wave<double>(
+                (const double *)sinv + (size_t)row_first * np, sp, np, lane);
+        else
+            s_first = dense_row_wave<float>(
+                (const float *)sinv + (size_t)row_first * np, sp, np, lane);
+    }
     reduce_partials(src_part, src_nparts, src_nparts, 1, sc);
     if (j == 0) reduce_partials(bb_part, bb_nparts, bb_nparts, 1, sc + 1);
     const double hn = sqrt(sc[0]);
@@ -152,13 +167,20 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
         for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
              e += gridDim.x * kBlock)
             vj[e] = src[e] * scale;
-        const double *sp = sp_in ? sp_in : src + nv;
-        if (SK == 1) {
-            dense_rows_block<double>((const double *)sinv, sp, np, -scale, zp,
-                                     nullptr, red4, prow0, prow1);
-        } else if (SK == 2) {
-            dense_rows_block<float>((const float *)sinv, sp, np, -scale, zp,
-                                    nullptr, red4, prow0, prow1);
+        if (SK == 1 || SK == 2) {
+            if (row_first < prow1 && lane == 0)
+                zp[row_first] = -scale * s_first;
+            for (int row = row_first + nwaves; row < prow1; row += nwaves) {
+                const double s =
+                    (SK == 1)
+                        ? dense_row_wave<double>(
+                              (const double *)sinv + (size_t)row * np, sp, np,
+                              lane)
+                        : dense_row_wave<float>(
+                              (const float *)sinv + (size_t)row * np, sp, np,
+                              lane);
+                if (lane == 0) zp[row] = -scale * s;
+            }
         } else if (SK == 0) {
             const double *sd = (const double *)sinv;
             for (int i = prow0 + blockIdx.x * kBlock + threadIdx.x; i < prow1;
@@ -279,10 +301,24 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
     // linearity argument below holds for tau as it does for the pressure part
     if (ctl->done) return;
     __shared__ double h[kMaxRestart + 2];
-    __shared__ double red4[4];
     // the tau kernel in front may have found that column j-1 converges: then
     // V_j and zp_j are never used and only the column is closed
     const bool pre = ctl->predone != 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gwave = blockIdx.x * (kBlock / 64) + wave;
+    const int nwaves = gridDim.x * (kBlock / 64);
+    const double *wp = sp_in ? sp_in : w + nv;
+    // dense Schur rows by waves; the first row's loads go out before the
+    // reduction of the Gram-Schmidt partials
+    double s_first = 0.0;
+    if ((SK == 1 || SK == 2) && gwave < np && !pre) {
+        if (SK == 1)
+            s_first = dense_row_wave<double>(
+                (const double *)sinv + (size_t)gwave * np, wp, np, lane);
+        else
+            s_first = dense_row_wave<float>(
+                (const float *)sinv + (size_t)gwave * np, wp, np, lane);
+    }
     reduce_partials(hpart, hnparts, hnparts, j + 1, h);
     const double hn = pythagoras_norm(h, j);
     if (hn < 0.0) {
@@ -308,7 +344,6 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
                 we = fma(-h[i], V[(size_t)i * ld + e], we);
             vj[e] = we * scale;
         }
-        const double *wp = sp_in ? sp_in : w + nv;
         double *zp = Z + (size_t)j * ld + nv;
         if (SK == 3) {
             // multigrid Schur block: applied to V_j,p by the kernels behind
@@ -323,32 +358,22 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
                 zp[r] = acc * scale;
             }
         } else {
-            for (int row = blockIdx.x; row < np; row += gridDim.x) {
-                // the kept zp_i first: their loads overlap the dense row's
-                double corr = 0.0;
-                if (threadIdx.x == 0)
+            for (int row = gwave; row < np; row += nwaves) {
+                double s = s_first;
+                if (row != gwave)
+                    s = (SK == 1)
+                            ? dense_row_wave<double>(
+                                  (const double *)sinv + (size_t)row * np, wp,
+                                  np, lane)
+                            : dense_row_wave<float>(
+                                  (const float *)sinv + (size_t)row * np, wp,
+                                  np, lane);
+                if (lane == 0) {
+                    double corr = 0.0;
                     for (int i = 0; i < j; ++i)
                         corr = fma(h[i], Z[(size_t)i * ld + nv + row], corr);
-                double s0 = 0.0, s1 = 0.0;
-                if (SK == 1) {
-                    const double *ar = (const double *)sinv + (size_t)row * np;
-                    int c = threadIdx.x;
-                    for (; c + kBlock < np; c += 2 * kBlock) {
-                        s0 = fma(ar[c], wp[c], s0);
-                        s1 = fma(ar[c + kBlock], wp[c + kBlock], s1);
-                    }
-                    if (c < np) s0 = fma(ar[c], wp[c], s0);
-                } else {
-                    const float *ar = (const float *)sinv + (size_t)row * np;
-                    int c = threadIdx.x;
-                    for (; c + kBlock < np; c += 2 * kBlock) {
-                        s0 = fma((double)ar[c], wp[c], s0);
-                        s1 = fma((double)ar[c + kBlock], wp[c + kBlock], s1);
-                    }
-                    if (c < np) s0 = fma((double)ar[c], wp[c], s0);
+                    zp[row] = (-s - corr) * scale;
                 }
-                const double s = block_sum(s0 + s1, red4);
-                if (threadIdx.x == 0) zp[row] = (-s - corr) * scale;
             }
         }
     }
@@ -401,6 +426,36 @@ k_tau_guard(int np, int nv, const int *__restrict__ rowptr,
         }
         __syncthreads();
         if (verdict) return;
+    }
+    if (LPR == 64) {
+        // long rows (J Fh^-1: ~270 entries): 128 lanes per row, so that a row
+        // is two rounds of loads instead of four or five dependent ones
+        __shared__ double half[kBlock / 64];
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int pair = threadIdx.x >> 7, l128 = threadIdx.x & 127;
+        for (int base = row0 + blockIdx.x * 2; base < row1;
+             base += gridDim.x * 2) {
+            const int row = base + pair;
+            double s0 = 0.0, s1 = 0.0;
+            if (row < row1) {
+                const int k1 = rowptr[row + 1];
+                int k = rowptr[row] + l128;
+                for (; k + 128 < k1; k += 256) {
+                    const int c0 = colidx[k], c1 = colidx[k + 128];
+                    const double v0 = vals[k], v1 = vals[k + 128];
+                    s0 = fma(v0, src[c0], s0);
+                    s1 = fma(v1, src[c1], s1);
+                }
+                if (k < k1) s0 = fma(vals[k], src[colidx[k]], s0);
+            }
+            const double s = wave_sum(s0 + s1);
+            __syncthreads();
+            if (lane == 0) half[wave] = s;
+            __syncthreads();
+            if (l128 == 0 && row < row1)
+                tau[row] = src[nv + row] - (half[2 * pair] + half[2 * pair + 1]);
+        }
+        return;
     }
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
@@ -581,6 +636,115 @@ k_arn_tail(int c, const double *__restrict__ norm_part, int nparts,
         if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
     }
     if (!ctl->conv) ctl->acc_fail += 1;
+}
+
+// Tail of a cycle AND the correction x += Z y in ONE launch (one GPU): every
+// workgroup repeats the tiny tail computation -- close the last column if it
+// is still open, y = R^-1 g -- in its own LDS from read-only device state, then
+// updates its share of x.  Workgroup 0 alone commits the solve's bookkeeping
+// (residual, flags, history, batch accumulators); it writes NONE of the
+// fields the other workgroups read in this launch (done, jdone, R, g, cs, sn),
+// which nobody needs after the cycle's end: the next cycle's head resets them.
+__global__ void __launch_bounds__(kBlock)
+k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
+               DnsCtl *ctl, double *__restrict__ histbuf, int hist_cap,
+               int maxiter, const double *__restrict__ Z, size_t ld,
+               double *__restrict__ x) {
+    __shared__ double sc[kMaxRestart + 2];
+    __shared__ double yl[kMaxRestart];
+    __shared__ int jl;
+    const bool open_col = !ctl->done && c > 0;
+    if (open_col) reduce_partials(norm_part, nparts, nparts, c + 1, sc);
+    if (threadIdx.x == 0) {
+        // local copies of what closing column c-1 changes
+        double gl[2] = {0.0, 0.0}, rcol[kMaxRestart + 1];
+        int jcols = ctl->jdone, status = DNS_OK, conv = 0, tot = ctl->total_it;
+        double res = ctl->resnorm;
+        bool closed = false;
+        if (open_col) {
+            const int j = c - 1;
+            const double hn = pythagoras_norm(sc, c);
+            if (hn < 0.0) {
+                status = kGsFallback;
+            } else {
+                for (int i = 0; i <= j; ++i) rcol[i] = sc[i];
+                for (int i = 0; i < j; ++i) {
+                    const double t = ctl->cs[i] * rcol[i] +
+                                     ctl->sn[i] * rcol[i + 1];
+                    rcol[i + 1] = -ctl->sn[i] * rcol[i] +
+                                  ctl->cs[i] * rcol[i + 1];
+                    rcol[i] = t;
+                }
+                const double den = hypot(rcol[j], hn);
+                double cc = 1.0, ss = 0.0;
+                if (den > 0.0) {
+                    cc = rcol[j] / den;
+                    ss = hn / den;
+                } else {
+                    status = DNS_BREAKDOWN;
+                }
+                rcol[j] = den;
+                gl[1] = -ss * ctl->g[j];
+                gl[0] = cc * ctl->g[j];
+                res = fabs(gl[1]);
+                jcols = j + 1;
+                tot += 1;
+                conv = !(res > ctl->tol);
+                closed = true;
+            }
+        }
+        // y = R^-1 g with the (possibly) locally closed last column
+        for (int i = jcols - 1; i >= 0; --i) {
+            double s = (closed && i == jcols - 1) ? gl[0] : ctl->g[i];
+            for (int k = i + 1; k < jcols; ++k) {
+                const double rik = (closed && k == jcols - 1)
+                                       ? rcol[i]
+                                       : ctl->R[(size_t)k * (kMaxRestart + 1) + i];
+                s -= rik * yl[k];
+            }
+            const double d = (closed && i == jcols - 1)
+                                 ? rcol[i]
+                                 : ctl->R[(size_t)i * (kMaxRestart + 1) + i];
+            yl[i] = (d != 0.0) ? s / d : 0.0;
+        }
+        jl = jcols;
+        if (blockIdx.x == 0) {
+            // commit (fields nobody else reads in this launch)
+            const int was_conv = ctl->conv;
+            if (closed) {
+                ctl->resnorm = res;
+                ctl->hist[jcols] = res;
+                ctl->total_it = tot;
+                if (status != DNS_OK) ctl->status = status;
+                if (conv) ctl->conv = 1;
+            } else if (status != DNS_OK) {
+                ctl->status = status;
+            }
+            const int nowconv = was_conv || conv;
+            int hl = ctl->hist_len;
+            for (int i = (hl > 0 ? 1 : 0); i <= jcols && hl < hist_cap; ++i)
+                histbuf[hl++] = (closed && i == jcols) ? res : ctl->hist[i];
+            ctl->hist_len = hl;
+            ctl->acc_solves += 1;
+            ctl->acc_iters += tot;
+            if (tot > ctl->acc_maxit) ctl->acc_maxit = tot;
+            if (nowconv && ctl->tol > 0.0) {
+                const double rel = res / ctl->tol;
+                if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
+            }
+            if (!nowconv) ctl->acc_fail += 1;
+        }
+    }
+    __syncthreads();
+    const int jcols = jl;
+    if (jcols == 0) return;
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
+         e += gridDim.x * kBlock) {
+        double s = x[e];
+        for (int i = 0; i < jcols; ++i)
+            s = fma(yl[i], Z[(size_t)i * ld + e], s);
+        x[e] = s;
+    }
 }
 
 // u = sum_{i<jdone} y_i V_i

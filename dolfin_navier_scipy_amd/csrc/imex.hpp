@@ -3,6 +3,7 @@
 #include "convection.hpp"
 #include "solver.hpp"
 #include "trap.hpp"
+#include "step_kernels.hpp"
 
 struct dns_imex {
     dns_saddle *sys = nullptr;

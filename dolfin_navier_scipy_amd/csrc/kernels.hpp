@@ -900,6 +900,34 @@ __device__ __forceinline__ void dense_rows_block(const VT *__restrict__ a,
     }
 }
 
+// one WAVE per dense row (the Arnoldi head kernels: four rows per workgroup, so
+// that a workgroup's reduction of the dot-product partials is shared by four
+// rows and the kernel has np/4 workgroups instead of np): the whole row is in
+// flight before the first use; returns the wave-reduced dot product
+template <typename VT>
+__device__ __forceinline__ double dense_row_wave(const VT *__restrict__ ar,
+                                                 const double *__restrict__ x,
+                                                 int n, int lane) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = lane;
+    for (; c + 448 < n; c += 512) {
+        const double a0 = (double)ar[c], a1 = (double)ar[c + 64];
+        const double a2 = (double)ar[c + 128], a3 = (double)ar[c + 192];
+        const double a4 = (double)ar[c + 256], a5 = (double)ar[c + 320];
+        const double a6 = (double)ar[c + 384], a7 = (double)ar[c + 448];
+        s0 = fma(a0, x[c], s0);
+        s1 = fma(a1, x[c + 64], s1);
+        s2 = fma(a2, x[c + 128], s2);
+        s3 = fma(a3, x[c + 192], s3);
+        s0 = fma(a4, x[c + 256], s0);
+        s1 = fma(a5, x[c + 320], s1);
+        s2 = fma(a6, x[c + 384], s2);
+        s3 = fma(a7, x[c + 448], s3);
+    }
+    for (; c < n; c += 64) s0 = fma((double)ar[c], x[c], s0);
+    return wave_sum((s0 + s1) + (s2 + s3));
+}
+
 // dense Schur: zp = -Sinv rp  (rp = selected vector's pressure part)
 template <typename VT>
 __global__ void __launch_bounds__(kBlock)

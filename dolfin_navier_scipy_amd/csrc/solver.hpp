@@ -316,7 +316,7 @@ struct dns_saddle {
     bool fuse_dots = true;
     // matrices with at least this many non-zeros go through the LDS-streaming
     // kernels (bandwidth regime); below, the sub-wave kernels (latency regime)
-    int64_t stream_nnz = 800000;
+    int64_t stream_nnz = 1300000;
     bool streams(const dns::CsrDev &A) const {
         return A.nnz >= stream_nnz && A.c16.p != nullptr;
     }
@@ -356,6 +356,8 @@ struct dns_saddle {
                                       // stepper (tables of per-step data);
                                       // bumped by the first head kernel of
                                       // a solve
+    int prologue_nparts = 0;          // > 0: partials of ||r||^2, ||b||^2 the
+                                      // caller's prologue kernel has written
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open

@@ -1,0 +1,166 @@
+// The front of a resident IMEX time step in the latency regime (n ~ 1e4), cut
+// along its data dependencies instead of along its operations:
+//
+//   k_step_front : [convection element kernel]  ||  [x0 = extrapolation,
+//                  kx = K x0, rs = R1 (a_c v_c + a_p v_p)]      -- ONE launch:
+//                  the first workgroups evaluate the cells, the others walk
+//                  the rows; neither half needs the other (both read v_c only)
+//   k_step_back  : nfc_c = scale * gather(cell values);  b = rs + cn_c nfc_c +
+//                  cn_o nfc_o + g;  r = b - kx;  partials of ||r||^2, ||b||^2
+//
+// Before (k_conv_cells -> k_step_prologue) the three gather chains of the
+// prologue -- 12.2 us of the ~53 us step -- waited for the 5.8 us element
+// kernel although only the (short) convection gather depends on it.
+#pragma once
+#include "convection.hpp"
+#include "kernels.hpp"
+
+namespace dns {
+
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_step_front(int nconv_blocks,
+             // --- convection half
+             int ncells, const int *__restrict__ cellmap,
+             const double *__restrict__ glam, const double *__restrict__ area,
+             TabRef dbctab, double *__restrict__ cellvals,
+             // --- row half
+             int n, int nv, const int *__restrict__ k_rowptr,
+             const int *__restrict__ k_colidx,
+             const double *__restrict__ k_vals,
+             const int *__restrict__ r_rowptr,
+             const int *__restrict__ r_colidx,
+             const double *__restrict__ r_vals,
+             const double *__restrict__ x_c, const double *__restrict__ x_p,
+             const double *__restrict__ x_pp, const double *__restrict__ x_p3,
+             const double *__restrict__ x_p4, double e_c, double e_p,
+             double e_pp, double e_p3, double e_p4, double a_c, double a_p,
+             double *__restrict__ x0, double *__restrict__ kx,
+             double *__restrict__ rs) {
+    if ((int)blockIdx.x < nconv_blocks) {
+        if (ncells > 0)
+            conv_cells_block(blockIdx.x, ncells, cellmap, glam, area, x_c,
+                             dbctab, cellvals);
+        return;
+    }
+    const int rb = blockIdx.x - nconv_blocks;
+    const int nrb = gridDim.x - nconv_blocks;
+    const int sub = (rb * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = nrb * (kBlock / LPR);
+    for (int row = sub; row < n; row += nsub) {
+        // two independent gather chains, first pass issued level by level
+        const bool isv = row < nv;
+        int kk = k_rowptr[row] + sublane;
+        const int kend = k_rowptr[row + 1];
+        int rk = 0, rend = 0;
+        if (isv) {
+            rk = r_rowptr[row] + sublane;
+            rend = r_rowptr[row + 1];
+        }
+        const bool k_on = kk < kend, r_on = rk < rend;
+        int kc = 0, rc = 0;
+        double kval = 0.0, rval = 0.0;
+        if (k_on) {
+            kc = k_colidx[kk];
+            kval = k_vals[kk];
+        }
+        if (r_on) {
+            rc = r_colidx[rk];
+            rval = r_vals[rk];
+        }
+        double ks = 0.0, rsum = 0.0;
+        if (k_on) {
+            double xv = e_c * x_c[kc];
+            if (e_p != 0.0) xv = fma(e_p, x_p[kc], xv);
+            if (e_pp != 0.0) xv = fma(e_pp, x_pp[kc], xv);
+            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[kc], xv);
+            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[kc], xv);
+            ks = kval * xv;
+        }
+        if (r_on) {
+            double vv = a_c * x_c[rc];
+            if (a_p != 0.0) vv = fma(a_p, x_p[rc], vv);
+            rsum = rval * vv;
+        }
+        for (kk += LPR; kk < kend; kk += LPR) {
+            const int c = k_colidx[kk];
+            double xv = e_c * x_c[c];
+            if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
+            if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
+            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[c], xv);
+            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[c], xv);
+            ks = fma(k_vals[kk], xv, ks);
+        }
+        for (rk += LPR; rk < rend; rk += LPR) {
+            const int c = r_colidx[rk];
+            double vv = a_c * x_c[c];
+            if (a_p != 0.0) vv = fma(a_p, x_p[c], vv);
+            rsum = fma(r_vals[rk], vv, rsum);
+        }
+        ks = subwave_sum<LPR>(ks);
+        rsum = subwave_sum<LPR>(rsum);
+        if (sublane == 0) {
+            double xv = e_c * x_c[row];
+            if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
+            if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
+            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[row], xv);
+            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[row], xv);
+            x0[row] = xv;
+            kx[row] = ks;
+            if (isv) rs[row] = rsum;
+        }
+    }
+}
+
+// LPR lanes per row (the convection list of a velocity dof has ~6-12 entries)
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_step_back(int n, int nv, double *__restrict__ nfc_c,
+            const double *__restrict__ nfc_o, double cn_c, double cn_o,
+            TabRef gtab, TabRef gptab, const int *__restrict__ gptr,
+            const int *__restrict__ gidx, const double *__restrict__ cellvals,
+            double conv_scale, double *__restrict__ b /* in: rs */,
+            double *__restrict__ r /* in: kx */, double *__restrict__ part_rr,
+            double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    const double *__restrict__ g = tab_row(gtab);
+    const double *__restrict__ gp = tab_row(gptab);
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    double arr = 0.0, abb = 0.0;
+    for (int row = sub; row < n; row += nsub) {
+        double cvs = 0.0;
+        const bool isv = row < nv;
+        if (isv && gptr) {
+            const int gend = gptr[row + 1];
+            for (int k = gptr[row] + sublane; k < gend; k += LPR)
+                cvs += cellvals[gidx[k]];
+        }
+        cvs = subwave_sum<LPR>(cvs);
+        if (sublane == 0) {
+            double bv;
+            if (isv) {
+                const double nc = gptr ? conv_scale * cvs : nfc_c[row];
+                if (gptr) nfc_c[row] = nc;
+                bv = b[row] + cn_c * nc + cn_o * nfc_o[row] + g[row];
+            } else {
+                bv = gp[row - nv];
+            }
+            const double rv = bv - r[row];
+            b[row] = bv;
+            r[row] = rv;
+            arr = fma(rv, rv, arr);
+            abb = fma(bv, bv, abb);
+        }
+    }
+    arr = block_sum(arr, red);
+    abb = block_sum(abb, red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = arr;
+        part_bb[blockIdx.x] = abb;
+    }
+}
+
+}  // namespace dns
