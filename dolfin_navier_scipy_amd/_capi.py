@@ -85,6 +85,9 @@ class dns_imex_coeffs(ct.Structure):
 # every symbol include/dns_amd.h declares: name -> (restype, argtypes)
 _VP = ct.c_void_p
 ALLREDUCE_CB = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, ct.c_int32)
+ALLTOALLV_CB = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, c_int32_p,
+                            c_int32_p, ct.c_void_p, c_int32_p, c_int32_p,
+                            ct.c_int32)
 ALLGATHERV_CB = ct.CFUNCTYPE(ct.c_int, ct.c_void_p, ct.c_void_p, c_int32_p,
                              ct.c_int32)
 UNIQUE_ID_BYTES = 128
@@ -212,6 +215,13 @@ SIGNATURES = {
                                     ct.POINTER(dns_solve_opts),
                                     ct.POINTER(dns_solve_stats), ct.c_int32,
                                     c_double_p, c_double_p, c_double_p]),
+    'dns_comm_set_alltoallv_cb': (ct.c_int, [_VP, ALLTOALLV_CB]),
+    'dns_comm_stats2': (ct.c_int, [_VP, ct.POINTER(ct.c_int64)]),
+    'dns_halo_lists': (ct.c_int, [ct.POINTER(dns_csr), ct.c_int32, ct.c_int32,
+                                  ct.c_int32, ct.c_int32, c_int32_p,
+                                  ct.c_int32, c_int32_p, c_int32_p,
+                                  ct.c_int64, ct.POINTER(ct.c_int64)]),
+    'dns_saddle_device_bytes': (ct.c_int, [_VP, ct.POINTER(ct.c_int64)]),
     'dns_op_create': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr),
                                  ct.POINTER(_VP)]),
     'dns_op_destroy': (None, [_VP]),

@@ -15,7 +15,7 @@ import numpy as np
 from . import _capi as C
 
 __all__ = ['Comm', 'partition_range', 'host_allreduce', 'host_allgatherv',
-           'rccl_unique_id']
+           'host_alltoallv', 'halo_lists', 'rccl_unique_id']
 
 
 def partition_range(n, nranks, rank):
@@ -51,6 +51,66 @@ def host_allgatherv(buf, starts, rank, group=None):
     for r in range(nranks):
         buf[starts[r]:starts[r+1]] = outs[r].numpy()[:starts[r+1]-starts[r]]
     return buf
+
+
+def host_alltoallv(send, scounts, sdispls, rcounts, rdispls, rank,
+                   group=None):
+    """the halo exchange on the host (gloo has no all-to-all on CPU tensors:
+    every rank publishes its packed send buffer and its counts, everybody
+    picks the pieces addressed to it); returns the packed receive buffer"""
+    import torch
+    import torch.distributed as dist
+    nranks = len(scounts)
+    meta = torch.tensor(list(scounts) + list(sdispls), dtype=torch.int64)
+    metas = [torch.zeros_like(meta) for _ in range(nranks)]
+    dist.all_gather(metas, meta, group=group)
+    width = torch.tensor([len(send)], dtype=torch.int64)
+    widths = [torch.zeros_like(width) for _ in range(nranks)]
+    dist.all_gather(widths, width, group=group)
+    wmax = max(1, max(int(w.item()) for w in widths))
+    mine = np.zeros(wmax)
+    mine[:len(send)] = send
+    outs = [torch.zeros(wmax, dtype=torch.float64) for _ in range(nranks)]
+    dist.all_gather(outs, torch.from_numpy(mine), group=group)
+    recv = np.zeros(max(1, int(sum(rcounts))))
+    for q in range(nranks):
+        if q == rank or rcounts[q] == 0:
+            continue
+        cnt_q = int(metas[q][rank].item())          # what q sends to me
+        dsp_q = int(metas[q][nranks + rank].item())
+        if cnt_q != rcounts[q]:
+            raise RuntimeError('halo plan mismatch between ranks {0} and {1}: '
+                               '{2} sent, {3} expected'.format(
+                                   q, rank, cnt_q, rcounts[q]))
+        recv[rdispls[q]:rdispls[q] + cnt_q] = \
+            outs[q].numpy()[dsp_q:dsp_q + cnt_q]
+    return recv
+
+
+def halo_lists(pattern, row0, row1, nranks, rank, col_starts, ncols_part):
+    """`dns_halo_lists`: for each other rank the sorted distinct columns
+    (below `ncols_part`) the rows `[row0, row1)` of `pattern` reference in
+    that rank's column range (host only, no GPU)"""
+    view = C.CsrView(pattern)
+    cs = np.ascontiguousarray(col_starts, dtype=np.int32)
+    counts = np.zeros(nranks, dtype=np.int32)
+    total = ct.c_int64(0)
+    lib = C.load_library()
+    C.check(lib.dns_halo_lists(view.byref(), row0, row1, nranks, rank,
+                               cs.ctypes.data_as(C.c_int32_p), ncols_part,
+                               counts.ctypes.data_as(C.c_int32_p), None, 0,
+                               ct.byref(total)))
+    lists = np.zeros(max(1, total.value), dtype=np.int32)
+    C.check(lib.dns_halo_lists(view.byref(), row0, row1, nranks, rank,
+                               cs.ctypes.data_as(C.c_int32_p), ncols_part,
+                               counts.ctypes.data_as(C.c_int32_p),
+                               lists.ctypes.data_as(C.c_int32_p),
+                               lists.size, ct.byref(total)))
+    out, pos = [], 0
+    for q in range(nranks):
+        out.append(lists[pos:pos + counts[q]].copy())
+        pos += counts[q]
+    return out
 
 
 def rccl_unique_id():
@@ -117,16 +177,42 @@ class Comm(object):
                 print('allgatherv callback failed:', exc)
                 return 1
 
+        def _alltoallv(ctx, send, scnt, sdsp, recv, rcnt, rdsp, nr):
+            try:
+                sc = [scnt[k] for k in range(nr)]
+                sd = [sdsp[k] for k in range(nr)]
+                rc = [rcnt[k] for k in range(nr)]
+                rd = [rdsp[k] for k in range(nr)]
+                nsend = max(sd[k] + sc[k] for k in range(nr))
+                sbuf = np.empty(max(nsend, 1))
+                if nsend:
+                    C.check(lib.dns_device_read(device, send,
+                                                sbuf.ctypes.data, 8*nsend))
+                rbuf = host_alltoallv(sbuf[:nsend], sc, sd, rc, rd, rank,
+                                      group)
+                nrecv = max(rd[k] + rc[k] for k in range(nr))
+                if nrecv:
+                    C.check(lib.dns_device_write(device, recv,
+                                                 rbuf.ctypes.data, 8*nrecv))
+                return 0
+            except Exception as exc:
+                print('alltoallv callback failed:', exc)
+                return 1
+
         ar, ag = C.ALLREDUCE_CB(_allreduce), C.ALLGATHERV_CB(_allgatherv)
+        a2a = C.ALLTOALLV_CB(_alltoallv)
         h = ct.c_void_p()
         C.check(lib.dns_comm_create_callbacks(device, nranks, rank, ar, ag,
                                               None, ct.byref(h)))
-        return cls(h, rank, nranks, keep=(ar, ag))
+        C.check(lib.dns_comm_set_alltoallv_cb(h, a2a))
+        return cls(h, rank, nranks, keep=(ar, ag, a2a))
 
     def stats(self):
-        a, b = ct.c_int64(0), ct.c_int64(0)
-        C.check(self.lib.dns_comm_stats(self._h, ct.byref(a), ct.byref(b)))
-        return dict(allreduce=a.value, allgatherv=b.value)
+        """calls and bytes SENT by this rank since the communicator exists"""
+        buf = (ct.c_int64*5)()
+        C.check(self.lib.dns_comm_stats2(self._h, buf))
+        return dict(allreduce=buf[0], allgatherv=buf[1], halo_exchange=buf[2],
+                    halo_bytes=buf[3], allgather_bytes=buf[4])
 
     def close(self):
         if self._h:

@@ -1,10 +1,14 @@
 // Communicator of the row-partitioned solve: RCCL over xGMI in production,
 // host callbacks (torch.distributed/gloo in the tests) as a stand-in where two
-// ranks have to share one GPU.  Two collectives are all the Krylov solve needs:
-//   allreduce  : sum of a few fp64 scalars (dot products, norms)
-//   allgatherv : every rank contributes its contiguous row block of a vector
-//                that all ranks keep in full ("halo = everything" form of the
-//                halo gather; exact neighbour lists are a later refinement)
+// ranks have to share one GPU.  Three collectives:
+//   allreduce  : sum of a few fp64 scalars (the dot products of an Arnoldi
+//                step, one call per step)
+//   alltoallv  : the HALO exchange -- every rank sends each neighbour exactly
+//                the vector entries that neighbour's rows reference (index
+//                lists from the column footprint of its row block): grouped
+//                ncclSend/ncclRecv over xGMI
+//   allgatherv : contiguous blocks of a vector that every rank needs in full
+//                (the pressure-sized Schur input; the velocity once per solve)
 #pragma once
 #include <rccl/rccl.h>
 
@@ -18,8 +22,44 @@ struct dns_comm {
     ncclComm_t nccl = nullptr;
     dns_allreduce_cb ar_cb = nullptr;
     dns_allgatherv_cb ag_cb = nullptr;
+    dns_alltoallv_cb a2a_cb = nullptr;
     void *ctx = nullptr;
-    int64_t n_allreduce = 0, n_allgather = 0;
+    int64_t n_allreduce = 0, n_allgather = 0, n_alltoall = 0;
+    int64_t bytes_alltoall = 0, bytes_allgather = 0;   // sent by this rank
+
+    // sendbuf/recvbuf: device; counts/displs in doubles, one entry per rank
+    int alltoallv(const double *sendbuf, const std::vector<int> &scounts,
+                  const std::vector<int> &sdispls, double *recvbuf,
+                  const std::vector<int> &rcounts,
+                  const std::vector<int> &rdispls, hipStream_t s) {
+        n_alltoall++;
+        for (int q = 0; q < nranks; ++q)
+            if (q != rank) bytes_alltoall += 8 * (int64_t)scounts[q];
+        if (nccl) {
+            ncclResult_t r = ncclGroupStart();
+            for (int q = 0; q < nranks && r == ncclSuccess; ++q) {
+                if (q == rank) continue;
+                if (scounts[q] > 0)
+                    r = ncclSend(sendbuf + sdispls[q], (size_t)scounts[q],
+                                 ncclDouble, q, nccl, s);
+                if (r == ncclSuccess && rcounts[q] > 0)
+                    r = ncclRecv(recvbuf + rdispls[q], (size_t)rcounts[q],
+                                 ncclDouble, q, nccl, s);
+            }
+            ncclResult_t e = ncclGroupEnd();
+            if (r == ncclSuccess) r = e;
+            if (r != ncclSuccess)
+                return dns::fail(DNS_ERR_COMM, "halo exchange (ncclSend/Recv): %s",
+                                 ncclGetErrorString(r));
+            return DNS_OK;
+        }
+        if (!a2a_cb) return dns::fail(DNS_ERR_COMM, "no alltoallv backend");
+        DNS_HIP(hipStreamSynchronize(s));
+        if (a2a_cb(ctx, sendbuf, scounts.data(), sdispls.data(), recvbuf,
+                   rcounts.data(), rdispls.data(), nranks) != 0)
+            return dns::fail(DNS_ERR_COMM, "alltoallv callback failed");
+        return DNS_OK;
+    }
 
     ~dns_comm() {
         if (nccl) (void)ncclCommDestroy(nccl);
@@ -44,6 +84,7 @@ struct dns_comm {
 
     int allgatherv(double *dev, const std::vector<int> &starts, hipStream_t s) {
         n_allgather++;
+        bytes_allgather += 8 * (int64_t)(starts[rank + 1] - starts[rank]);
         if (nccl) {
             ncclResult_t r = ncclGroupStart();
             for (int q = 0; q < nranks && r == ncclSuccess; ++q) {

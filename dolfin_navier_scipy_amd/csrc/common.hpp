@@ -101,6 +101,19 @@ struct CsrDev {
     int c16_rawblocks = 0;
 
     int upload(const dns_csr *a, hipStream_t s);
+    void release_all() {
+        rowptr.release();
+        colidx.release();
+        vals.release();
+        for (int t = 0; t < 3; ++t) {
+            rowblocks_t[t].release();
+            nrowblocks_t[t] = 0;
+        }
+        c16.release();
+        c16base.release();
+        nrows = ncols = 0;
+        nnz = 0;
+    }
 };
 
 inline int pick_lpr(double avg_nnz_per_row) {

@@ -47,8 +47,12 @@ static void host_transpose(const dns_csr *a, std::vector<int> &rp,
 
 }  // namespace dns
 
+struct dns_dist_data;
+static void free_dist_data(dns_dist_data *d);
+
 dns_saddle::~dns_saddle() {
     drop_graphs();
+    free_dist_data(dd);
     if (hdr_host) (void)hipHostFree(hdr_host);
     if (scal_host) (void)hipHostFree(scal_host);
     if (ev0) (void)hipEventDestroy(ev0);
@@ -177,7 +181,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     DNS_TRY(bctl.alloc(1));
     DNS_TRY(bctl.zero(stream));
     DNS_TRY(scal.alloc(16));
-    DNS_TRY(dsum.alloc(kMaxRestart + 8));
+    DNS_TRY(dsum.alloc(2 * kMaxRestart + 16));
     DNS_TRY(cheb_r.alloc((size_t)nv));
     DNS_TRY(cheb_d0.alloc((size_t)nv));
     DNS_TRY(cheb_d1.alloc((size_t)nv));
@@ -209,6 +213,14 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
 
 int dns_saddle::update_values(const double *fvals) {
     DNS_HIP(hipSetDevice(device));
+    if (dist_sliced) {
+        // the device holds this rank's rows of K only: new values through the
+        // host copy
+        Fh.vals.assign(fvals, fvals + Fh.vals.size());
+        fh_stale = false;
+        drop_graphs();
+        return update_values_dist();
+    }
     Fh.vals.assign(fvals, fvals + F.nnz);
     fh_stale = false;
     DNS_TRY(F.vals.upload(fvals, (size_t)F.nnz, stream));
@@ -293,14 +305,13 @@ int dns_saddle::estimate_bounds() {
     return DNS_OK;
 }
 
-// Chebyshev recurrence for zv = Fh^-1 (rv - JT zp).  In the row-partitioned
-// solve a rank updates only its velocity rows; the direction vector every
-// rank needs in full for the next F apply is all-gathered after each step.
+// Chebyshev recurrence for zv = Fh^-1 (rv - JT zp)  (one GPU; the
+// row-partitioned solve uses the explicit polynomial matrix)
 static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
                       const int *jsel, const double *zp, double *zv,
                       const int *guard) {
     const int deg = h->popts.cheb_degree;
-    const int v0 = h->v0(), v1 = h->v1();
+    const int v0 = 0, v1 = h->nv;
     const int gj = grid_for_rows(v1 - v0, h->JT.lpr);
     double *d0 = (deg == 1) ? zv : h->cheb_d0.p;
     DNS_LPR_SWITCH(h->JT.lpr,
@@ -309,7 +320,6 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
                                       h->JT.vals.p, zp, rbase, ldr, jsel,
                                       h->dinv.p, 1.0 / h->theta, h->cheb_r.p,
                                       d0, guard, v0, v1));
-    if (h->dist()) DNS_TRY(h->comm->allgatherv(d0, h->st_v, h->stream));
     const int gf = grid_for_rows(v1 - v0, h->F.lpr);
     double *dbuf[2] = {h->cheb_d0.p, h->cheb_d1.p};
     for (int s = 0; s < deg - 1; ++s) {
@@ -321,9 +331,6 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
                                h->dinv.p, dbuf[s & 1], dbuf[(s + 1) & 1],
                                h->cheb_r.p, zv, h->c1[s], h->c2[s], first,
                                last, guard, v0, v1));
-        if (h->dist())
-            DNS_TRY(h->comm->allgatherv(last ? zv : dbuf[(s + 1) & 1], h->st_v,
-                                        h->stream));
         h->spmv_count++;
     }
     DNS_HIP(hipGetLastError());
@@ -335,7 +342,7 @@ static int apply_fhat(dns_saddle *h, const double *rbase, size_t ldr,
 int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
                                 double *zv, const int *guard, double *xacc) {
     bool xacc_fused = false;
-    if (fhat_explicit && !dist() && streams(Gc)) {
+    if (fhat_explicit && streams(Gc)) {
         // bandwidth regime: the LDS-streaming kernel with 16-bit column
         // offsets (6 instead of 8 bytes per non-zero with fp32 values); its
         // input [rv ; zp] is read from the two buffers directly
@@ -349,10 +356,9 @@ int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
             DNS_TRY(launch_stream16x<double>(Gc, Gc.vals.p, rvec, zv, ep,
                                              stream, guard));
     } else if (fhat_explicit) {
-        const int r0 = v0(), r1 = v1();
+        const int r0 = 0, r1 = nv;
         const int g = grid_for_rows(r1 - r0, Gc.lpr);
-        // fused correction only on one GPU (every rank needs ALL of x)
-        double *xa = dist() ? nullptr : xacc;
+        double *xa = xacc;
         xacc_fused = xa != nullptr;
         if (fp32_store) {
             DNS_LPR_SWITCH(
@@ -385,15 +391,19 @@ int dns_saddle::apply_fhat_part(const double *rvec, const double *zp,
 // z = P^-1 r for one n-vector r (device pointers); xacc != null: x += z
 int dns_saddle::apply_precond(const double *rvec, double *zout,
                               const int *guard, double *xacc) {
+    // (one GPU: BiCGStab, the parity entry and the probes; the row-partitioned
+    // solve applies the preconditioner inside enqueue_cycle_dist)
+    if (dist_sliced)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "not available on a row-partitioned handle");
     double *zp = zout + nv;
     double *xp = xacc ? xacc + nv : nullptr;
-    double *xpf = dist() ? nullptr : xp;     // fused x_p += z_p on one GPU only
-    const int r0 = p0(), r1 = p1();
+    double *xpf = xp;                        // fused x_p += z_p
+    const int r0 = 0, r1 = np;
     const double *rvec_schur = rvec;
     if (have_jg) {
-        // full block factorisation: tau = r_p - (J Fh^-1) r_v (this rank's
-        // rows, gathered) is what the Schur block sees; its kernels read
-        // `rbase + nv`
+        // full block factorisation: tau = r_p - (J Fh^-1) r_v is what the
+        // Schur block sees; its kernels read `rbase + nv`
         DNS_LPR_SWITCH(
             JG.lpr,
             hipLaunchKernelGGL(k_tau_guard<L>,
@@ -401,8 +411,6 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
                                kBlock, 0, stream, np, nv, JG.rowptr.p,
                                JG.colidx.p, JG.vals.p, rvec, tau.p,
                                (const double *)nullptr, 0, 0, ctl.p, r0, r1));
-        if (dist() && !repl_schur())
-            DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
         rvec_schur = tau.p - nv;
     }
     if (popts.schur == DNS_SCHUR_MG) {
@@ -423,14 +431,6 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
         hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(r1 - r0), kBlock, 0,
                            stream, np, sinv.p, rvec_schur, (size_t)0, zero_ptr(), nv,
                            zp, guard, xpf, r0, r1);
-    }
-    if (dist()) {
-        if (!repl_schur()) DNS_TRY(comm->allgatherv(zp, st_p, stream));
-        if (xp) {
-            hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
-                               (int64_t)np, 1.0, zp, 1.0, xp);
-            DNS_HIP(hipGetLastError());
-        }
     }
     return apply_fhat_part(rvec, zp, zout, guard, xacc);
 }
@@ -480,18 +480,25 @@ int dns_saddle::build_explicit(bool dense_schur) {
     HostCsr negGJT = GJT;
     for (auto &v : negGJT.vals) v = -v;
     HostCsr Gch = host_hstack(G, negGJT);
-    dns_csr gv = Gch.view();
-    DNS_TRY(Gc.upload(&gv, stream));
-    if (fp32_store) DNS_TRY(to_f32(Gc.vals.p, gc32, (size_t)Gc.nnz));
+    if (!comm) {
+        dns_csr gv = Gch.view();
+        DNS_TRY(Gc.upload(&gv, stream));
+        if (fp32_store) DNS_TRY(to_f32(Gc.vals.p, gc32, (size_t)Gc.nnz));
+    }
     lap("hstack + upload Gc");
+    HostCsr JGh;
     if (popts.factorization == DNS_FACT_FULL) {
-        HostCsr JGh = host_spgemm(Jh, G);
-        dns_csr jv = JGh.view();
-        DNS_TRY(JG.upload(&jv, stream));
+        JGh = host_spgemm(Jh, G);
+        if (!comm) {
+            dns_csr jv = JGh.view();
+            DNS_TRY(JG.upload(&jv, stream));
+        }
         DNS_TRY(tau.alloc((size_t)std::max(1, np)));
         have_jg = true;
         lap("J*G (full factorisation)");
-        if (dbg) fprintf(stderr, "[dns] setup nnz(JG) = %ld\n", (long)JG.nnz);
+        if (dbg)
+            fprintf(stderr, "[dns] setup nnz(JG) = %ld\n",
+                    (long)JGh.vals.size());
     }
     if (dbg)
         fprintf(stderr, "[dns] setup nnz(G) = %ld, nnz(Gc) = %ld\n",
@@ -514,6 +521,12 @@ int dns_saddle::build_explicit(bool dense_schur) {
         lap("S = J*(G*JT)");
         DNS_TRY(build_mg_schur(S));
         lap("multigrid hierarchy");
+    }
+    if (comm) {
+        // row-partitioned: setup_precond slices these once the rest of the
+        // set-up (which works on whole matrices) is through
+        tmp_Gch = std::move(Gch);
+        tmp_JGh = std::move(JGh);
     }
     return DNS_OK;
 }
@@ -748,6 +761,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
     drop_graphs();   // captured kernel arguments (coefficients, buffers)
+    DNS_TRY(restore_full_device());   // (row-partitioned handle set up again)
     if (fh_stale) {
         DNS_TRY(F.vals.download(Fh.vals.data(), (size_t)F.nnz, stream));
         DNS_HIP(hipStreamSynchronize(stream));
@@ -841,6 +855,13 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         popts.factorization != DNS_FACT_FULL)
         return fail(DNS_ERR_BAD_ARGUMENT, "unknown factorization %d",
                     popts.factorization);
+    if (comm && !fhat_explicit)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "the row-partitioned solve needs the explicit Fh^-1 (fhat "
+                    "= explicit / auto, degree 2..12, NV <= 1e6)");
+    if (comm && popts.schur == DNS_SCHUR_JACOBI &&
+        popts.factorization == DNS_FACT_FULL)
+        ;   // (fine: the diagonal Schur block is replicated like the others)
     if (popts.factorization == DNS_FACT_FULL && !fhat_explicit)
         return fail(DNS_ERR_BAD_ARGUMENT,
                     "the full block factorisation needs the explicit Fh^-1 "
@@ -848,11 +869,20 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     if (fhat_explicit) {
         DNS_TRY(build_explicit(popts.schur == DNS_SCHUR_DENSE));
         if (popts.schur == DNS_SCHUR_JACOBI) DNS_TRY(build_jacobi_schur());
-        if (fp32_store && popts.schur == DNS_SCHUR_DENSE)
+        if (fp32_store && popts.schur == DNS_SCHUR_DENSE) {
+            // (only the fp32 copy is applied from here on: the fp64 inverse,
+            // 8 NP^2 bytes, goes back to the allocator)
             DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
+            DNS_HIP(hipStreamSynchronize(stream));
+            sinv.release();
+        }
     } else if (popts.schur == DNS_SCHUR_DENSE) {
         DNS_TRY(build_dense_schur());
-        if (fp32_store) DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
+        if (fp32_store) {
+            DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
+            DNS_HIP(hipStreamSynchronize(stream));
+            sinv.release();
+        }
     } else if (popts.schur == DNS_SCHUR_JACOBI) {
         DNS_TRY(build_jacobi_schur());
     } else if (popts.schur == DNS_SCHUR_MG) {
@@ -872,6 +902,12 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
                     popts.schur);
     }
     DNS_HIP(hipStreamSynchronize(stream));
+    if (comm) {
+        // from here on this rank keeps ITS row blocks only
+        DNS_TRY(setup_dist(tmp_Gch, have_jg ? &tmp_JGh : nullptr));
+        tmp_Gch = HostCsr();
+        tmp_JGh = HostCsr();
+    }
     precond_ready = true;
     dist_active = (comm != nullptr);
     return DNS_OK;
@@ -901,14 +937,17 @@ int dns_saddle::read_header() {
 }
 
 int dns_saddle::true_residual(const double *b, const double *x, double *out) {
+    // (row-partitioned: this rank's rows, then the sum over the ranks; `x` is
+    // whole on every rank after a solve)
+    const RowMap rm = dist_sliced ? dist_rowmap() : RowMap{0, n, 0, 0};
     DNS_LPR_SWITCH(K.lpr,
                    hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x,
-                                      b, r.p, partR.p, (double *)nullptr, 0,
-                                      n));
+                                      b, r.p, partR.p, (double *)nullptr, rm));
     hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, gridS,
                        scal.p);
     DNS_HIP(hipGetLastError());
+    if (dist_sliced && comm) DNS_TRY(comm->allreduce(scal.p, 1, stream));
     DNS_HIP(hipMemcpyAsync(scal_host, scal.p, sizeof(double),
                            hipMemcpyDeviceToHost, stream));
     DNS_HIP(hipStreamSynchronize(stream));
@@ -980,11 +1019,10 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                               bool have_resid) {
     // `first`: 1 = the head kernel of this cycle resets the solve's counters,
     // 2 = only its status (going on after a Gram-Schmidt fallback)
-    const bool dd = dist();
-    const int n0 = r0n(), n1 = r1n();
-    // r = b - K x over this rank's rows, ||r||^2, ||b||^2 (unless the caller's
-    // prologue kernel has produced r and the partials already)
-    if (!have_resid && !dd && streams(K)) {
+    // (one GPU; the row-partitioned solve has its own: enqueue_cycle_dist)
+    // r = b - K x, ||r||^2, ||b||^2 (unless the caller's prologue kernel has
+    // produced r and the partials already)
+    if (!have_resid && streams(K)) {
         // bandwidth regime: r = b - K x at the streaming rate, then the norms
         DNS_TRY(launch_stream16x<double>(K, K.vals.p, x, r.p,
                                          stream_epi_plain(-1.0, 1.0, b), stream,
@@ -995,35 +1033,23 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         DNS_LPR_SWITCH(
             K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x, b,
-                                      r.p, partR.p, partB.p, n0, n1));
+                                      r.p, partR.p, partB.p,
+                                      RowMap{0, n, 0, 0}));
     }
-    // what the consumers of a reduction read: the per-workgroup partials on
-    // one GPU; the all-reduced sums (one "partial" per scalar) across ranks
+    // the consumers of a reduction read the per-workgroup partials
     const double *rr_part = partR.p, *bb_part = partB.p;
-    int rr_np = (have_resid && prologue_nparts > 0) ? prologue_nparts : gridS;
-    if (dd) {
-        DNS_TRY(comm->allgatherv(r.p, st_n, stream));
-        hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partR.p, gridS,
-                           dsum.p);
-        hipLaunchKernelGGL(k_sum_partials, 1, kBlock, 0, stream, partB.p, gridS,
-                           dsum.p + 1);
-        DNS_TRY(comm->allreduce(dsum.p, 2, stream));
-        rr_part = dsum.p;
-        bb_part = dsum.p + 1;
-        rr_np = 1;
-    }
+    const int rr_np =
+        (have_resid && prologue_nparts > 0) ? prologue_nparts : gridS;
     const bool dense = popts.schur == DNS_SCHUR_DENSE;
-    const int q0 = p0(), q1 = p1();
-    // workgroups of the head kernel: one workgroup per Schur row
+    const int q0 = 0, q1 = np;
     // (dense Schur rows: one wave each, four per workgroup)
     const int gridA =
         dense ? std::max(gridD, std::min((q1 - q0 + 3) / 4, 2048)) : gridD;
-    double *hsum = dsum.p + 2;           // all-reduced Gram-Schmidt dots
-    // reorth == 2: Gram-Schmidt folded into the next head kernel (one GPU)
-    // bandwidth regime on one GPU: K through the streaming kernel with the
-    // dots fused in (while they fit its accumulators)
-    const bool stream_k = !dd && streams(K);
-    const bool fusedgs = o->reorth == 2 && !dd && (fuse_dots || stream_k);
+    // reorth == 2: Gram-Schmidt folded into the next head kernel
+    // bandwidth regime: K through the streaming kernel with the dots fused in
+    // (while they fit its accumulators)
+    const bool stream_k = streams(K);
+    const bool fusedgs = o->reorth == 2 && (fuse_dots || stream_k);
     const int gridK = stream_k ? stream_grid(K, kStreamGrid) : gridC;
     // partials the consumers of step j's dots read: written by the kernel
     // that applied K in step j
@@ -1031,9 +1057,9 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         return (stream_k && jj + 1 <= kStreamDots) ? gridK : gridC;
     };
     for (int j = 0; j < c; ++j) {
-        // one GPU: the preconditioned vectors are kept (Z_j) for the
-        // correction behind the cycle
-        double *zj = dd ? z.p : Z.p + (size_t)j * ld;
+        // the preconditioned vectors are kept (Z_j) for the correction behind
+        // the cycle
+        double *zj = Z.p + (size_t)j * ld;
         double *zp = zj + nv;
         const double *src = (j == 0) ? r.p : w.p;
         const double *spart = (j == 0) ? rr_part : partN.p;
@@ -1053,8 +1079,6 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                    JG.vals.p, src, tau.p, partA.p,
                                    jt > 0 ? kparts(jt - 1) : gridC, jt, ctl.p,
                                    q0, q1));
-            if (dd && !repl_schur())
-                DNS_TRY(comm->allgatherv(tau.p, st_p, stream));
             tin = tau.p;
         }
         if (fusedgs && j > 0 && mgs) {
@@ -1112,7 +1136,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         if (mgs) {
             // Schur block = V-cycle on V_j,p (or tau(V_j))
             const double *sin = V.p + (size_t)j * ld + nv;
-            if (have_jg && !dd && streams(JG)) {
+            if (have_jg && streams(JG)) {
                 // tau = V_j,p - JG V_j,v through the streaming kernel
                 const double *vj = V.p + (size_t)j * ld;
                 DNS_TRY(launch_spmv(JG, vj, tau.p, -1.0, 1.0, vj + nv,
@@ -1133,8 +1157,6 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             }
             DNS_TRY(schur_mg_apply(sin, zp, nullptr, done_ptr()));
         }
-        if (dd && !repl_schur())
-            DNS_TRY(comm->allgatherv(zp, st_p, stream));
         DNS_TRY(apply_fhat_part(V.p + (size_t)j * ld, zp, zj, done_ptr(),
                                 nullptr));
         if (stream_k && fusedgs && j + 1 <= kStreamDots) {
@@ -1154,39 +1176,28 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 hipLaunchKernelGGL(k_spmv_multidot<L>, gridC, kBlock, 0,
                                    stream, n, K.rowptr.p, K.colidx.p,
                                    K.vals.p, zj, w.p, V.p, ld, j, partA.p,
-                                   gridC, ctl.p, n0, n1, fusedgs ? 1 : 0));
+                                   gridC, ctl.p, RowMap{0, n, 0, 0},
+                                   fusedgs ? 1 : 0));
             if (fusedgs) continue;       // no Gram-Schmidt kernel
         } else {
-            if (!dd && K.c16.p) {
-                // bandwidth regime on one GPU: the LDS-streaming kernel with
-                // 16-bit column offsets (the roofline kernel of bench.py)
+            if (K.c16.p) {
+                // bandwidth regime: the LDS-streaming kernel with 16-bit
+                // column offsets (the roofline kernel of bench.py)
                 DNS_TRY(launch_spmv(K, zj, w.p, 1.0, 0.0, nullptr,
                                     DNS_SPMV_STREAM16, stream, done_ptr()));
             } else {
                 DNS_LPR_SWITCH(
                     K.lpr,
                     hipLaunchKernelGGL(k_spmv_guard<L>,
-                                       grid_for_rows(n1 - n0, K.lpr), kBlock,
-                                       0, stream, n, K.rowptr.p, K.colidx.p,
-                                       K.vals.p, zj, w.p, ctl.p, n0, n1));
+                                       grid_for_rows(n, K.lpr), kBlock, 0,
+                                       stream, n, K.rowptr.p, K.colidx.p,
+                                       K.vals.p, zj, w.p, ctl.p, 0, n));
             }
-            if (dd) DNS_TRY(comm->allgatherv(w.p, st_n, stream));
-            // full-vector dots (every rank alike once w is gathered)
             hipLaunchKernelGGL(k_multidot, gridC, kBlock, 0, stream, n, V.p,
                                ld, w.p, partA.p, gridC, j, ctl.p);
         }
         const double *hpart = partA.p;
-        int hnp = gridC;
-        if (dd && fuse_dots) {
-            // dots were taken over this rank's rows only: gather w, sum the
-            // partials to j+1 scalars and all-reduce those
-            DNS_TRY(comm->allgatherv(w.p, st_n, stream));
-            hipLaunchKernelGGL(k_sum_partials_n, 1, kBlock, 0, stream, partA.p,
-                               gridC, j + 1, hsum);
-            DNS_TRY(comm->allreduce(hsum, j + 1, stream));
-            hpart = hsum;
-            hnp = 1;
-        }
+        const int hnp = gridC;
         if (o->reorth == 1) {
             hipLaunchKernelGGL(k_orth<1>, gridD, kBlock, 0, stream, n, V.p, ld,
                                w.p, hpart, hnp, j, 0, partE.p, gridD, ctl.p);
@@ -1208,14 +1219,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     }
     hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
                        ctl.p, histdev.p, (int)hist_cap, o->maxiter, 0);
-    if (dd) {
-        hipLaunchKernelGGL(k_basis_combine, gridD, kBlock, 0, stream, n, V.p,
-                           ld, ctl.p, u.p);
-        DNS_TRY(apply_precond(u.p, z.p, zero_ptr(), x));
-    } else {
-        hipLaunchKernelGGL(k_basis_combine_acc, gridD, kBlock, 0, stream, n,
-                           Z.p, ld, ctl.p, x);
-    }
+    hipLaunchKernelGGL(k_basis_combine_acc, gridD, kBlock, 0, stream, n, Z.p,
+                       ld, ctl.p, x);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }
@@ -1249,6 +1254,7 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     // dots fused into the K apply while the system is launch-latency bound
     fuse_dots = n <= 400000;
     int restarts = 0;
+    int dist_stalls = 0;
     bool first = true;          // prologue + first cycle of the solve
     int reset = 1;              // what the head kernel resets (k_arn_head)
     dns_solve_opts oo = *o;
@@ -1264,8 +1270,9 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             (uint64_t)fuse_dots};
         DNS_TRY(run_cached(key, graph, [&]() -> int {
             if (first && prologue) DNS_TRY(prologue());
+            if (dist()) return enqueue_cycle_dist(b, x, c, &oo, reset);
             return enqueue_cycle(b, x, c, &oo, reset,
-                                 first && prologue_has_resid && !dist());
+                                 first && prologue_has_resid);
         }));
         first = false;
         reset = 0;
@@ -1279,7 +1286,9 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
         DNS_TRY(read_header());
         if (hdr_host->status == kGsFallback) {
             // the fused Gram-Schmidt gave up on its norm: go on from the
-            // current iterate with the explicit kernel
+            // current iterate with the explicit kernel (row-partitioned: with
+            // a new fused cycle -- it restarts from a fresh, orthonormal basis)
+            (void)dist_stalls;
             gs_fallbacks++;
             oo.reorth = 0;
             reset = 2;
@@ -1340,7 +1349,8 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
     DNS_LPR_SWITCH(K.lpr,
                    hipLaunchKernelGGL(k_resid_norm<L>, nred, kBlock, 0, stream,
                                       n, K.rowptr.p, K.colidx.p, K.vals.p, x,
-                                      b, r.p, partR.p, partB.p, 0, n));
+                                      b, r.p, partR.p, partB.p,
+                                      RowMap{0, n, 0, 0}));
     spmv_count++;
     // <rhat, r> = <r, r> at the start: partR doubles as part_rr and part_nn
     hipLaunchKernelGGL(k_bicg_start, nred, kBlock, 0, stream, n, r.p,
@@ -1414,10 +1424,15 @@ int dns_saddle::solve_device(const double *b, double *x,
     DNS_HIP(hipEventRecord(ev0, stream));
     if (o->method == DNS_METHOD_GMRES)
         DNS_TRY(gmres(b, x, o, st));
+    else if (o->method == DNS_METHOD_BICGSTAB && dist())
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "the row-partitioned solve runs GMRES only");
     else if (o->method == DNS_METHOD_BICGSTAB)
         DNS_TRY(bicgstab(b, x, o, st));
     else
         return fail(DNS_ERR_BAD_ARGUMENT, "unknown method %d", o->method);
+    // row-partitioned: every rank gets the whole velocity once per solve
+    if (dist()) DNS_TRY(comm->allgatherv(x, st_v, stream));
     DNS_HIP(hipEventRecord(ev1, stream));
     DNS_HIP(hipEventSynchronize(ev1));
     float ms = 0.f;
@@ -1696,11 +1711,12 @@ int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather) {
 int dns_saddle_set_comm(dns_saddle *h, dns_comm *c) {
     if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "null handle");
     h->drop_graphs();
+    DNS_HIP(hipSetDevice(h->device));
+    DNS_TRY(h->restore_full_device()); // (a sliced handle gets its matrices back)
     h->comm = c;
     h->dist_active = false;
     h->precond_ready = false;          // set up (again) after attaching
     if (c) {
-        h->st_n = partition_starts(h->n, c->nranks);
         h->st_v = partition_starts(h->nv, c->nranks);
         h->st_p = partition_starts(h->np, c->nranks);
     }
@@ -1789,8 +1805,8 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            0, s, n, h->K.rowptr.p,
                                            h->K.colidx.p, h->K.vals.p, h->z.p,
                                            h->w.p, h->V.p, h->ld, j,
-                                           h->partA.p, h->gridC, h->ctl.p, 0,
-                                           n, 0));
+                                           h->partA.p, h->gridC, h->ctl.p,
+                                           RowMap{0, n, 0, 0}, 0));
                     break;
                 case 3:
                     hipLaunchKernelGGL(k_orth<0>, h->gridD, kBlock, 0, s, n,
@@ -1804,8 +1820,8 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                         hipLaunchKernelGGL(k_resid_norm<L>, h->gridS, kBlock, 0,
                                            s, n, h->K.rowptr.p, h->K.colidx.p,
                                            h->K.vals.p, h->xdev.p, h->bdev.p,
-                                           h->r.p, h->partR.p, h->partB.p, 0,
-                                           n));
+                                           h->r.p, h->partR.p, h->partB.p,
+                                           RowMap{0, n, 0, 0}));
                     break;
                 case 5:
                     hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, s, 0,
@@ -2110,6 +2126,9 @@ int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
 
 }  // extern "C"
 
+#include "dist_solve.inc"
+static void free_dist_data(dns_dist_data *d) { delete d; }
+dns::RowMap dns_saddle::dist_rowmap() const { return dd->kmap; }
 #include "imex_capi.inc"
 #include "trap_capi.inc"
 #include "ops_capi.inc"

@@ -32,17 +32,18 @@ k_resid_norm(int nrows, const int *__restrict__ rowptr,
              const int *__restrict__ colidx, const double *__restrict__ vals,
              const double *__restrict__ x, const double *__restrict__ b,
              double *__restrict__ r, double *__restrict__ part_rr,
-             double *__restrict__ part_bb, int row0, int row1) {
-    // rows [row0, row1): the whole matrix on one GPU, this rank's row block in
-    // the row-partitioned solve
+             double *__restrict__ part_bb, RowMap rm) {
+    // the whole matrix on one GPU; this rank's row slice (local CSR arrays,
+    // global columns) in the row-partitioned solve
     __shared__ double red[4];
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
     double arr = 0.0, abb = 0.0;
     (void)nrows;
-    for (int row = row0 + sub; row < row1; row += nsub) {
-        double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, row, sublane);
+    for (int li = sub; li < rm.len1 + rm.len2; li += nsub) {
+        const int row = map_row(rm, li);
+        double s = csr_row_dot<LPR>(rowptr, colidx, vals, x, li, sublane);
         if (sublane == 0) {
             const double bv = b[row];
             const double v = bv - s;
@@ -224,7 +225,7 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
                 const double *__restrict__ vals, const double *__restrict__ z,
                 double *__restrict__ w, const double *__restrict__ V, size_t ld,
                 int j, double *__restrict__ part, int nparts,
-                const DnsCtl *ctl, int row0, int row1, int with_ww) {
+                const DnsCtl *ctl, RowMap rm, int with_ww) {
     // with_ww: one more scalar, part[(j+1)*nparts + wg] = <w, w> (the norm of
     // the orthogonalised vector then follows from Pythagoras, k_arn_head_f)
     if (ctl->done) return;
@@ -238,7 +239,8 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
-    for (int row = row0 + sub; row < row1; row += nsub) {
+    for (int li = sub; li < rm.len1 + rm.len2; li += nsub) {
+        const int row = map_row(rm, li);
         // basis entries first: their loads overlap the row's own load chain
         double vq[NQ];
 #pragma unroll
@@ -246,7 +248,7 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
             const int i = q * LPR + sublane;
             vq[q] = (i < nvec) ? V[(size_t)i * ld + row] : 0.0;
         }
-        const double s = csr_row_dot<LPR>(rowptr, colidx, vals, z, row, sublane);
+        const double s = csr_row_dot<LPR>(rowptr, colidx, vals, z, li, sublane);
         if (sublane == 0) w[row] = s;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -296,9 +298,11 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
              const double *__restrict__ hpart, int hnparts,
              double *__restrict__ V, size_t ld, double *__restrict__ Z,
              const void *__restrict__ sinv, DnsCtl *ctl, int maxiter,
-             const double *__restrict__ sp_in) {
+             const double *__restrict__ sp_in, int prow0 = 0, int prow1 = -1) {
     // sp_in: tau(w) = w_p - J Fh^-1 w_v (full block factorisation); the
     // linearity argument below holds for tau as it does for the pressure part
+    // [prow0, prow1): the Schur rows this rank computes (all on one GPU)
+    if (prow1 < 0) prow1 = np;
     if (ctl->done) return;
     __shared__ double h[kMaxRestart + 2];
     // the tau kernel in front may have found that column j-1 converges: then
@@ -311,13 +315,14 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
     // dense Schur rows by waves; the first row's loads go out before the
     // reduction of the Gram-Schmidt partials
     double s_first = 0.0;
-    if ((SK == 1 || SK == 2) && gwave < np && !pre) {
+    const int row_first = prow0 + gwave;
+    if ((SK == 1 || SK == 2) && row_first < prow1 && !pre) {
         if (SK == 1)
             s_first = dense_row_wave<double>(
-                (const double *)sinv + (size_t)gwave * np, wp, np, lane);
+                (const double *)sinv + (size_t)row_first * np, wp, np, lane);
         else
             s_first = dense_row_wave<float>(
-                (const float *)sinv + (size_t)gwave * np, wp, np, lane);
+                (const float *)sinv + (size_t)row_first * np, wp, np, lane);
     }
     reduce_partials(hpart, hnparts, hnparts, j + 1, h);
     const double hn = pythagoras_norm(h, j);
@@ -350,7 +355,7 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
         } else if (SK == 0) {
             // zp_j = (-sd .* wp - sum h_i zp_i) / hn  (zp_i kept in Z_i)
             const double *sd = (const double *)sinv;
-            for (int r = blockIdx.x * kBlock + threadIdx.x; r < np;
+            for (int r = prow0 + blockIdx.x * kBlock + threadIdx.x; r < prow1;
                  r += gridDim.x * kBlock) {
                 double acc = -sd[r] * wp[r];
                 for (int i = 0; i < j; ++i)
@@ -358,9 +363,9 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
                 zp[r] = acc * scale;
             }
         } else {
-            for (int row = gwave; row < np; row += nwaves) {
+            for (int row = row_first; row < prow1; row += nwaves) {
                 double s = s_first;
-                if (row != gwave)
+                if (row != row_first)
                     s = (SK == 1)
                             ? dense_row_wave<double>(
                                   (const double *)sinv + (size_t)row * np, wp,
@@ -530,8 +535,12 @@ template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_orth(int n, const double *__restrict__ V, size_t ld, double *__restrict__ w,
        const double *__restrict__ part_in, int in_nparts, int j, int pass,
-       double *__restrict__ out, int out_nparts, DnsCtl *ctl) {
+       double *__restrict__ out, int out_nparts, DnsCtl *ctl,
+       RowMap rm = RowMap{0, -1, 0, 0}) {
+    // rm (MODE 0 only): the entries to update and to take the norm over -- all
+    // of them on one GPU (len1 < 0), this rank's own rows when partitioned
     if (ctl->done) return;
+    if (rm.len1 < 0) rm = RowMap{0, n, 0, 0};
     const int nvec = j + 1;
     __shared__ double h[kMaxRestart + 1];
     __shared__ double red[4];
@@ -541,8 +550,9 @@ k_orth(int n, const double *__restrict__ V, size_t ld, double *__restrict__ w,
         ctl->hcol[threadIdx.x] =
             (pass == 0 ? 0.0 : ctl->hcol[threadIdx.x]) + h[threadIdx.x];
     double acc = 0.0;
-    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
-         e += gridDim.x * kBlock) {
+    for (int li = blockIdx.x * kBlock + threadIdx.x; li < rm.len1 + rm.len2;
+         li += gridDim.x * kBlock) {
+        const int e = map_row(rm, li);
         double we = w[e];
         for (int i = 0; i < nvec; ++i)
             we = fma(-h[i], V[(size_t)i * ld + e], we);

@@ -57,6 +57,17 @@ __device__ __forceinline__ const double *tab_row(const TabRef &t) {
     return t.base + (size_t)r * t.stride;
 }
 
+// Rows a kernel launch works on: local row i of the (possibly sliced) CSR
+// arrays is global row `row0 + i` for i < len1, `row2 + i - len1` beyond -- one
+// GPU: {0, n, 0, 0}; row-partitioned: this rank's velocity rows, then its
+// pressure rows (K = [[F, JT], [J, 0]] sliced by rows).
+struct RowMap {
+    int row0, len1, row2, len2;
+};
+__device__ __forceinline__ int map_row(const RowMap &m, int i) {
+    return i < m.len1 ? m.row0 + i : m.row2 + (i - m.len1);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -335,23 +335,19 @@ struct dns_saddle {
     // K, the nv velocity rows (Fh^-1) and the np pressure rows (Sh^-1)
     dns_comm *comm = nullptr;
     bool dist_active = false;         // false during set-up (done redundantly)
-    std::vector<int> st_n, st_v, st_p;
+    struct dns_dist_data *dd = nullptr;   // row blocks + halo plans (dist_solve.inc)
+    bool dist_sliced = false;         // K, Gc, JG hold this rank's rows only
+    int setup_dist(const dns::HostCsr &Gch, const dns::HostCsr *JGh);
+    int restore_full_device();
+    int update_values_dist();
+    int enqueue_cycle_dist(const double *b, double *x, int c,
+                           const dns_solve_opts *o, int first);
+    dns::RowMap dist_rowmap() const;
+    dns::HostCsr tmp_Gch, tmp_JGh;    // handed from build_explicit to setup_dist
+    std::vector<int> st_v, st_p;      // block partitions of the velocity /
+                                      // pressure rows over the ranks
     dns::DevBuf<double> dsum;         // all-reduced scalars
     bool dist() const { return comm != nullptr && dist_active; }
-    int r0n() const { return dist() ? st_n[comm->rank] : 0; }
-    int r1n() const { return dist() ? st_n[comm->rank + 1] : n; }
-    int v0() const { return dist() ? st_v[comm->rank] : 0; }
-    int v1() const { return dist() ? st_v[comm->rank + 1] : nv; }
-    // the Schur block (tau, Sh^-1 rows) of a small pressure space is computed
-    // in full by every rank: 10 us of redundant work instead of two
-    // collectives; so is the multigrid V-cycle (not partitioned this round)
-    bool repl_schur() const {
-        return dist() && (np <= 8192 || popts.schur == DNS_SCHUR_MG);
-    }
-    int p0() const { return (dist() && !repl_schur()) ? st_p[comm->rank] : 0; }
-    int p1() const {
-        return (dist() && !repl_schur()) ? st_p[comm->rank + 1] : np;
-    }
     int *step_counter = nullptr;      // device step counter of the attached
                                       // stepper (tables of per-step data);
                                       // bumped by the first head kernel of

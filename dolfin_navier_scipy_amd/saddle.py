@@ -89,6 +89,13 @@ class SaddleSystem(object):
             self._h, comm._h if comm is not None else None))
         self.precond_ready = False
 
+    def device_matrix_bytes(self):
+        """bytes of HBM this rank's matrices occupy (`dns_saddle_device_bytes`)
+        -- shrinks with the number of ranks of a row-partitioned handle"""
+        out = ct.c_int64(0)
+        C.check(self.lib.dns_saddle_device_bytes(self._h, ct.byref(out)))
+        return out.value
+
     def set_schur_mg(self, prolongations, smooth_steps=2):
         """nested pressure spaces for `schur='mg'`: `prolongations[l]` maps
         level `l+1` (coarser) to level `l`, finest first; the coarsest level

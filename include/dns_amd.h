@@ -186,14 +186,18 @@ void dns_default_precond_opts(dns_precond_opts *o);
 void dns_default_solve_opts(dns_solve_opts *o);
 
 /* ---- row-partitioned solve over several GPUs ------------------------------
- * One process per GPU.  Every rank creates the same saddle system, attaches
- * a communicator, and from then on computes only its block of rows of every
- * operator apply (K, Fh^-1, Sh^-1); vectors are kept in full on every rank:
- * an in-place all-gather-v of the row blocks follows each apply (the halo
- * gather) and the Krylov dot products are summed by an all-reduce of a few
- * fp64 scalars.  Production backend: RCCL over xGMI.  Test backend: host
- * callbacks (the tests drive them with torch.distributed/gloo so that two
- * ranks can share one GPU).  The reference has no counterpart.
+ * One process per GPU.  Every rank creates the saddle system, attaches a
+ * communicator and sets up the preconditioner; from then on it keeps in HBM
+ * only ITS row block of every operator (K, the explicit Fh^-1, J Fh^-1) and
+ * computes only those rows.  Per Arnoldi step: one halo exchange of the new
+ * basis vector's velocity part (each neighbour gets exactly the entries its
+ * rows reference: index lists from the column footprint), one all-gather of
+ * the pressure-sized Schur input, one halo exchange of the preconditioned
+ * velocity in front of the K apply, ONE all-reduce of the step's j+2 dot
+ * products.  Production backend: RCCL over xGMI (grouped ncclSend/ncclRecv +
+ * ncclAllReduce).  Test backend: host callbacks (torch.distributed/gloo, so
+ * that two ranks can share one GPU).  Needs the explicit Fh^-1.  The
+ * reference has no counterpart.
  */
 typedef struct dns_comm dns_comm;
 #define DNS_UNIQUE_ID_BYTES 128
@@ -203,6 +207,13 @@ typedef int (*dns_allreduce_cb)(void *ctx, double *dev, int32_t count);
  * holds every block; `starts` has nranks+1 entries */
 typedef int (*dns_allgatherv_cb)(void *ctx, double *dev, const int32_t *starts,
                                  int32_t nranks);
+/* halo exchange: send `sendcounts[q]` doubles at DEVICE `send + senddispls[q]`
+ * to rank q, receive `recvcounts[q]` at DEVICE `recv + recvdispls[q]` */
+typedef int (*dns_alltoallv_cb)(void *ctx, const double *send_dev,
+                                const int32_t *sendcounts,
+                                const int32_t *senddispls, double *recv_dev,
+                                const int32_t *recvcounts,
+                                const int32_t *recvdispls, int32_t nranks);
 int dns_comm_unique_id(char *out_128_bytes);          /* call on rank 0     */
 int dns_comm_create_rccl(int device, int32_t nranks, int32_t rank,
                          const char *unique_id_128_bytes, dns_comm **out);
@@ -210,8 +221,26 @@ int dns_comm_create_callbacks(int device, int32_t nranks, int32_t rank,
                               dns_allreduce_cb allreduce,
                               dns_allgatherv_cb allgatherv, void *ctx,
                               dns_comm **out);
+/* the callback backend's halo exchange (RCCL: grouped ncclSend/ncclRecv) */
+int dns_comm_set_alltoallv_cb(dns_comm *c, dns_alltoallv_cb alltoallv);
 void dns_comm_destroy(dns_comm *c);
 int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather);
+/* calls and bytes this rank sent: out[0..4] = all-reduce calls, all-gather-v
+ * calls, halo exchanges, halo bytes, all-gather bytes */
+int dns_comm_stats2(dns_comm *c, int64_t *out5);
+/* The halo plan of a row partition, host only (no GPU needed): for the CSR
+ * pattern `a` (n rows, columns < ncols_part partitioned by `col_starts`
+ * [nranks+1]; columns >= ncols_part are ignored) and the rows [row0, row1) of
+ * rank `rank`, the sorted distinct columns that rank references in every
+ * other rank's range.  `counts` [nranks] receives the list lengths, `lists`
+ * (capacity `cap`) the concatenated lists; returns the total in `*total`. */
+int dns_halo_lists(const dns_csr *a, int32_t row0, int32_t row1,
+                   int32_t nranks, int32_t rank, const int32_t *col_starts,
+                   int32_t ncols_part, int32_t *counts, int32_t *lists,
+                   int64_t cap, int64_t *total);
+/* bytes of HBM the handle's matrices occupy on this rank (K, Fh^-1, J Fh^-1,
+ * Schur block, F/J/JT copies): shrinks with the number of ranks */
+int dns_saddle_device_bytes(dns_saddle *h, int64_t *matrix_bytes);
 /* attach before dns_saddle_setup_precond; NULL detaches */
 int dns_saddle_set_comm(dns_saddle *h, dns_comm *c);
 /* the block partition used for n rows: [start, end) of `rank` */

@@ -61,6 +61,40 @@ def _worker(rank, world, port, outdir):
     M, A, J = (prob['smc'][k] for k in 'MAJ')
     F = (M + .5*5e-3*A).tocsr()
     NP, NV = J.shape
+
+    # 3a. halo plan of the row partition (`dns_halo_lists`, host only) + the
+    # staged halo exchange: after it, every rank holds exactly the entries of
+    # a vector that its row block of F references -- and its SpMV rows agree
+    # with the serial product
+    stv = dist_model.starts_for(NV, world)
+    need = dcomm.halo_lists(F, stv[rank], stv[rank+1], world, rank, stv, NV)
+    cols = np.unique(F[stv[rank]:stv[rank+1], :].indices)
+    for q in range(world):
+        want_q = cols[(cols >= stv[q]) & (cols < stv[q+1])] if q != rank \
+            else np.zeros(0, dtype=np.int32)
+        assert np.array_equal(need[q], want_q), (rank, q)
+    # what the others need from me: they computed it the same way
+    send_lists = [dcomm.halo_lists(F, stv[q], stv[q+1], world, q, stv, NV)[rank]
+                  if q != rank else np.zeros(0, dtype=np.int32)
+                  for q in range(world)]
+    xfull = np.sin(0.3*np.arange(NV))
+    mine = np.full(NV, np.nan)
+    mine[stv[rank]:stv[rank+1]] = xfull[stv[rank]:stv[rank+1]]
+    sc = [len(l) for l in send_lists]
+    sd = np.concatenate([[0], np.cumsum(sc)[:-1]]).astype(int).tolist()
+    rc = [len(l) for l in need]
+    rd = np.concatenate([[0], np.cumsum(rc)[:-1]]).astype(int).tolist()
+    sbuf = np.concatenate([mine[l] for l in send_lists]) if sum(sc) else \
+        np.zeros(0)
+    rbuf = dcomm.host_alltoallv(sbuf, sc, sd, rc, rd, rank)
+    for q in range(world):
+        mine[need[q]] = rbuf[rd[q]:rd[q] + rc[q]]
+    assert not np.isnan(mine[cols]).any()
+    halo = sum(rc)
+    assert 0 < halo < NV - (stv[rank+1] - stv[rank])     # a halo, not all
+    yloc = F[stv[rank]:stv[rank+1], :] @ np.nan_to_num(mine)
+    assert np.allclose(yloc, (F @ xfull)[stv[rank]:stv[rank+1]], rtol=0,
+                       atol=1e-14)
     rng = np.random.default_rng(3)
     b = np.concatenate([M @ rng.standard_normal(NV),
                         1e-3*rng.standard_normal(NP)])
