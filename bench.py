@@ -13,14 +13,26 @@ excluded") is timed as well and reported in `config`.
 
 Workload at N=1: Schaefer-Turek cylinder wake, mesh level N=2 (NV=9356,
 NP=1289), Re=100, dt=1/512, Taylor-Hood, CNAB -- the configuration
-BASELINE.json quotes the metric on.  For N>1 the headline is an ENSEMBLE:
-every rank advances its own simulation of that workload on its own GPU (weak
-scaling, no data-path collective) -- at n ~ 1e4 a time step is ~100 us of
-launch-bound work and a single RCCL collective costs 10-20 us, so partitioning
-ONE simulation of this size cannot pay.  The row-partitioned solve over RCCL
-(all-gather-v halo + all-reduce of the Krylov dots) is
-then timed on the same ranks as a secondary figure, `config.row_partitioned`
-(strong scaling of one simulation), so that both numbers are on record.
+BASELINE.json quotes the metric on.
+
+For N>1 the headline is ONE row-partitioned simulation:
+every rank holds its row blocks of K, Fh^-1 and J Fh^-1 only, exchanges halo
+entries by index lists (ncclSend/Recv) and takes part in ONE all-reduce per
+Arnoldi step.  Weak scaling: the mesh grows with the ranks so that the rows per
+rank stay about constant -- `WEAK_LADDER` below: level 2 (n=10 645) on 1 rank,
+level 3 (n=22 060) on 2, level 2 refined once (n=43 009) on 4, level 3 refined
+once (n=88 789) on 8, dt halved per refinement.  `value` is the time steps/s of
+that one simulation (no normalisation); `config.weak_scaling` carries n, the
+rows per rank and dof-steps/s, `config.collectives` the RCCL call counts of
+the timed window from `dns_comm_stats2`.  Secondary figures on the same ranks:
+`config.strong_scaling` (the N=1 workload itself partitioned over the N ranks,
+reported as it is -- at n ~ 1e4 a step is ~45 us of work on one GPU and every
+collective costs 10-20 us, so this is SLOWER than one GPU) and
+`config.ensemble` (N independent simulations, one per GPU, no collective).
+The partitioned runs execute in child processes (one per rank, their own
+rendezvous) under a time limit, so that a collective that never completes
+leaves an error in the JSON line instead of a hung benchmark; if the headline
+run fails the line says so and falls back to the ensemble figure.
 
 The JSON line also carries
   roofline     : CSR SpMV `y = K x` (the kernel family that dominates the
@@ -49,6 +61,19 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
 # 512 steps of BASELINE config 2 with exactly these and checks the 1e-8 parity)
 DEFAULTS = dict(cheb=6, rtol=1e-10, extrap=4, fp32=1, drop=1e-3, fact='full',
                 reorth=2)
+
+
+# (mesh level, red refinements): unknowns relative to the N=1 workload
+WEAK_LADDER = [((2, 0), 1.0), ((3, 0), 2.07), ((2, 1), 4.04), ((3, 1), 8.34),
+               ((2, 2), 16.2), ((3, 2), 33.5)]
+
+
+def weak_ladder(world):
+    """the mesh whose size relative to the N=1 workload is closest to the
+    number of ranks (rows per rank ~ constant)"""
+    import math
+    return min(WEAK_LADDER,
+               key=lambda e: abs(math.log(e[1]) - math.log(world)))[0]
 
 
 class stdout_to_stderr(object):
@@ -288,6 +313,339 @@ def roofline_spmv(saddle, Kmat, reps, label, variants=('vector', 'stream')):
     return best
 
 
+def partitioned_run(args, world, rank, device, dist, one_gpu):
+    """ONE row-partitioned simulation on `world` ranks:
+    start from rest, `--spinup` + `--warmup` untimed steps, then `--steps`
+    timed ones between barriers; the maximum over the ranks counts"""
+    from dolfin_navier_scipy_amd import saddle, _capi, convection, perfmodel
+    from dolfin_navier_scipy_amd import comm as dcomm
+    dt = 1./args.nts
+    femp, sm, rhsd = build_problem(N=args.level, Re=args.Re,
+                                   refine=args.refine)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    th, inv = femp['V'], femp['invinds']
+    schur_kind = 'dense' if NP <= args.dense_max else 'mg'
+    prols = None
+    if schur_kind == 'mg':
+        from dolfin_navier_scipy_amd.fem import (
+            cylinder_mesh_hierarchy, pressure_prolongations, TaylorHood)
+        hier = cylinder_mesh_hierarchy(N=args.level, refine=args.refine)
+        spaces = [TaylorHood(m) for m, _ in hier][::-1]
+        prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
+    F = (M + .5*dt*A).tocsr()
+    R1 = (M - .5*dt*A).tocsr()
+    system = saddle.SaddleSystem(F, J, device=device)
+    with stdout_to_stderr():
+        if one_gpu:
+            comm_obj = dcomm.Comm.gloo(device)
+        elif dist is not None:
+            comm_obj = dcomm.Comm.rccl_from_torch(device)
+        else:
+            comm_obj = dcomm.Comm.rccl(device, 1, 0, dcomm.rccl_unique_id())
+    system.set_comm(comm_obj)
+    if prols is not None:
+        system.set_schur_mg(prols)
+    t_setup = time.perf_counter()
+    system.setup_precond(cheb_degree=args.cheb, schur=schur_kind,
+                         fhat=args.fhat, fp32_store=bool(args.fp32),
+                         drop_tol=args.drop, factorization=args.fact)
+    _capi.device_synchronize(device)
+    t_setup = time.perf_counter() - t_setup
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
+    v0 = np.zeros((NV, 1))
+    nfc = cvop.apply(v0, scale=-1.0)
+    stp = saddle.ImexStepper(system, R1)
+    stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+    stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    stp.set_convection(cvop, scale=-1.0)
+    cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
+                                   pscale=-1./dt, extrapolate=args.extrap)
+    opts = saddle.solve_opts(method='gmres', rtol=args.rtol, maxiter=400,
+                             restart=60, check_every=args.check_every,
+                             use_graph=not args.eager, reorth=args.reorth)
+
+    def barrier():
+        _capi.device_synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            _capi.device_synchronize(device)
+
+    def over_ranks(vals, op):
+        if dist is None:
+            return list(vals)
+        import torch
+        t = torch.tensor(list(vals), dtype=torch.float64,
+                         device='cpu' if one_gpu else 'cuda')
+        dist.all_reduce(t, op=op)
+        return [float(x) for x in t.cpu()]
+
+    if args.spinup > 0:
+        stp.run(args.spinup, cf, opts)
+    stp.run(args.warmup, cf, opts)
+    c0 = comm_obj.stats()
+    barrier()
+    t0 = time.perf_counter()
+    _, its, lst = stp.run(args.steps, cf, opts)
+    barrier()
+    wall = time.perf_counter() - t0
+    c1 = comm_obj.stats()
+    MAX = None if dist is None else dist.ReduceOp.MAX
+    SUM = None if dist is None else dist.ReduceOp.SUM
+    wall = over_ranks([wall], MAX)[0]
+    info = system.precond_info()       # the nnz are those of THIS rank's rows
+    glob = over_ranks([info['nnz_K'], info['nnz_Gc'], info['nnz_JG']], SUM)
+    mbytes = system.device_matrix_bytes()
+    mb = over_ranks([mbytes], MAX)[0]
+    ginfo = dict(info, nnz_K=int(glob[0]), nnz_Gc=int(glob[1]),
+                 nnz_JG=int(glob[2]))
+    roof = perfmodel.step_roofline(
+        ginfo, int(R1.nnz), int(th.mesh.ncells), its/float(args.steps),
+        1e3*wall/args.steps, peak_GBs=world*HBM_PEAK_GBS)
+    roof.pop('ops', None)
+    v0r, v1r = dcomm.partition_range(NV, world, rank)
+    res = dict(
+        steps_per_s=args.steps/wall, ms_per_step=1e3*wall/args.steps,
+        steps=args.steps, warmup=args.warmup, spinup=args.spinup,
+        ranks=world, level=args.level, refine=args.refine, dt=dt,
+        NV=int(NV), NP=int(NP), unknowns=int(NV + NP),
+        rows_per_rank=(NV + NP)/float(world),
+        dof_steps_per_s=(NV + NP)*args.steps/wall, schur=schur_kind,
+        krylov_iters_per_step=its/float(args.steps),
+        true_relres_last=lst['true_relres'],
+        collectives_timed_window={k: int(c1[k] - c0[k]) for k in c1},
+        matrix_bytes_per_rank_max=int(mb), precond_setup_s=t_setup,
+        backend='gloo, host staged (one-GPU rehearsal)' if one_gpu
+        else 'RCCL', roofline_step=roof,
+        what='one simulation; every rank holds its row blocks of K, Fh^-1, '
+             'J Fh^-1 (and of the dense Schur inverse); halo entries by '
+             'index lists (Send/Recv), one all-reduce per Arnoldi step')
+    stp.close()
+    cvop.close()
+    system.set_comm(None)
+    comm_obj.close()
+    system.close()
+    return res
+
+
+def partitioned_child(args, world, rank, local_rank):
+    """`--partitioned-only`: the process of one rank of a partitioned run"""
+    dist, one_gpu = None, False
+    import faulthandler
+    # say where it hangs, shortly before the parent's time limit strikes
+    faulthandler.dump_traceback_later(max(30., args.partitioned_timeout - 15.),
+                                      exit=True)
+    if world > 1:
+        import datetime
+        import torch
+        import torch.distributed as dist
+        # rehearsal of the N > 1 code path on a ONE-GPU box: every rank on
+        # device 0 and the host-staged gloo communicator (RCCL refuses two
+        # ranks per device)
+        one_gpu = os.environ.get('DNS_BENCH_REHEARSE_ONE_GPU') == '1'
+        if one_gpu:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        with stdout_to_stderr():
+            dist.init_process_group(
+                'gloo' if one_gpu else 'nccl',
+                timeout=datetime.timedelta(seconds=args.partitioned_timeout))
+            dist.barrier()
+    from dolfin_navier_scipy_amd import _capi
+    if _capi.device_count() <= local_rank:
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+    res = partitioned_run(args, world, rank, local_rank, dist, one_gpu)
+    if rank == 0:
+        print(json.dumps(res))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.destroy_process_group()
+    return res
+
+
+def child_env(**override):
+    """environment of a child run: the launcher's rendezvous variables only.
+    The TORCHELASTIC_* variables must not travel -- with
+    TORCHELASTIC_USE_AGENT_STORE a process group expects the launcher's agent
+    to host the store on MASTER_PORT, which is not true on the child's port
+    (rank 0 has to host it itself)."""
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith('TORCHELASTIC_')}
+    env.update({k: str(v) for k, v in override.items()})
+    return env
+
+
+def run_child(cmd, env, timeout, want_result):
+    """a child process under a time limit; its last JSON line (or an error).
+    The child's stderr goes straight to this process's stderr (a run that is
+    killed has then said where it was)."""
+    import subprocess
+    try:
+        child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
+                                 stderr=None, start_new_session=True)
+        try:
+            cout, _ = child.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, 9)         # exactly the group started above
+            child.communicate()
+            return dict(error='no result within {0:g} s (killed)'
+                        .format(timeout))
+        lines = [ln for ln in cout.decode(errors='replace').splitlines()
+                 if ln.startswith('{')]
+        if lines:
+            return json.loads(lines[-1])
+        if not want_result and child.returncode == 0:
+            return None
+        return dict(error='child exited with code {0} and no result (its '
+                    'stderr is in this run\'s stderr)'.format(
+                        child.returncode))
+    except Exception as exc:
+        return dict(error=str(exc))
+
+
+def multi_gpu_main(args, world, rank, local_rank):
+    """`--gpus N`, N > 1 (launched by torch.distributed.run, one rank per GPU).
+
+    The parent ranks only coordinate (gloo group, no GPU context): every
+    measured run lives in a child process per rank with its own rendezvous and
+    a time limit."""
+    import torch
+    import torch.distributed as dist
+    with stdout_to_stderr():
+        dist.init_process_group('gloo')
+        dist.barrier()
+    base_port = int(os.environ.get('MASTER_PORT', '29500'))
+    common = ['--Re', str(args.Re), '--cheb', str(args.cheb), '--rtol',
+              str(args.rtol), '--extrap', str(args.extrap), '--fp32',
+              str(args.fp32), '--drop', str(args.drop), '--fhat', args.fhat,
+              '--fact', args.fact, '--reorth', str(args.reorth),
+              '--check-every', str(args.check_every)]
+    if args.eager:
+        common.append('--eager')
+
+    def partitioned(port_offset, level, refine, nts):
+        env = child_env(MASTER_PORT=base_port + port_offset,
+                        MASTER_ADDR='127.0.0.1')
+        cmd = [sys.executable, os.path.abspath(__file__), '--partitioned-only',
+               '--gpus', str(world), '--steps', str(args.steps), '--warmup',
+               str(args.warmup), '--spinup', str(args.spinup), '--level',
+               str(level), '--refine', str(refine), '--nts', str(nts),
+               '--dense-max', str(args.dense_max), '--partitioned-timeout',
+               str(args.partitioned_timeout)] + common
+        dist.barrier()
+        res = run_child(cmd, env, args.partitioned_timeout, rank == 0)
+        # a rank whose child failed makes the run a failure for everybody
+        bad = torch.tensor([1 if (res is not None and 'error' in res) else 0])
+        dist.all_reduce(bad)
+        if int(bad.item()) and rank == 0 and 'error' not in res:
+            res = dict(error='the child of another rank failed', partial=res)
+        return res
+
+    level, refine = weak_ladder(world)
+    nts_w = args.nts*2**refine
+    weak = partitioned(17, level, refine, nts_w)
+    strong = None
+    if not args.no_strong and (level, refine) != (args.level, 0):
+        strong = partitioned(29, args.level, 0, args.nts)
+    elif not args.no_strong:
+        strong = 'identical to the headline run (same mesh)'
+
+    # ensemble: every rank advances its own copy of the N=1 workload on its own
+    # GPU -- a single-GPU run of this script per rank (own timed window of
+    # exactly --steps steps each; the slowest rank counts)
+    ensemble = None
+    if not args.no_ensemble:
+        env = {k: v for k, v in child_env().items()
+               if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR',
+                            'MASTER_PORT', 'GROUP_RANK', 'LOCAL_WORLD_SIZE',
+                            'ROLE_RANK', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE',
+                            'ROLE_NAME')}
+        one_gpu = os.environ.get('DNS_BENCH_REHEARSE_ONE_GPU') == '1'
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1',
+               '--steps', str(args.steps), '--warmup', str(args.warmup),
+               '--spinup', str(args.spinup), '--level', str(args.level),
+               '--nts', str(args.nts), '--device',
+               '0' if one_gpu else str(local_rank), '--profile-step'] + common
+        dist.barrier()
+        one = run_child(cmd, env, args.partitioned_timeout, True)
+        ms = torch.tensor([one.get('ms_per_step', float('inf'))
+                           if 'error' not in one else float('inf')],
+                          dtype=torch.float64)
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+        slowest = float(ms.item())
+        ensemble = dict(
+            steps_per_s=(world*1e3/slowest if np.isfinite(slowest) else None),
+            ms_per_step_slowest_rank=slowest if np.isfinite(slowest) else None,
+            krylov_iters_per_step=(
+                one.get('config', {}).get('krylov_iters_per_step')
+                if 'error' not in one else None),
+            error=one.get('error'),
+            what='{0} independent simulations of the N=1 workload, one per '
+                 'GPU, no data-path collective (started from rest, unlike '
+                 'the N=1 headline)'.format(world))
+    dist.barrier()
+
+    out = None
+    if rank == 0:
+        ok = isinstance(weak, dict) and 'error' not in weak
+        if ok:
+            value, ms = weak['steps_per_s'], weak['ms_per_step']
+            mode = ('ONE simulation, row-partitioned over {0} ranks: per-rank '
+                    'row blocks, halo index lists (Send/Recv), one '
+                    'all-reduce per Arnoldi step'.format(world))
+            workload = ('cylinderwake N={0} refined {1}x Re={2:g} CNAB '
+                        'dt=1/{3} Taylor-Hood NV={4} NP={5} (weak-scaling '
+                        'ladder: {6:.0f} rows per rank); convection on the '
+                        'device every step; state: rest advanced {7} untimed '
+                        'spin-up steps'.format(
+                            level, refine, args.Re, nts_w, weak['NV'],
+                            weak['NP'], weak['rows_per_rank'], args.spinup))
+            rs = weak.get('roofline_step') or {}
+            roofline = dict(bound='hbm', achieved=rs.get('achieved'),
+                            peak=world*HBM_PEAK_GBS, unit='GB/s',
+                            frac=rs.get('frac'), traffic=None,
+                            kernel='(whole CNAB step of the partitioned run: '
+                            'published op list x measured Krylov steps / '
+                            'measured time, all ranks together)', step=rs)
+        else:
+            # the partitioned run failed: say so, report the ensemble
+            sps = (ensemble or {}).get('steps_per_s')
+            value = sps if sps else 0.0
+            ms = world*1e3/sps if sps else None
+            mode = ('FALLBACK -- the row-partitioned headline run failed '
+                    '(config.weak_scaling.error); value is the ensemble of '
+                    '{0} independent simulations'.format(world))
+            workload = ('cylinderwake N={0} Re={1:g} CNAB dt=1/{2}, one '
+                        'independent simulation per GPU'.format(
+                            args.level, args.Re, args.nts))
+            roofline = None
+        out = dict(
+            metric='timesteps/sec, 2D cylinder wake Re={0:g} (CNAB step: device '
+                   'convection + rhs SpMV + preconditioned Krylov saddle solve '
+                   '+ p rescale)'.format(args.Re),
+            value=value, unit='timesteps/s', n_gpus=world, steps=args.steps,
+            warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
+            scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+            config=dict(workload=workload, parallelism=mode,
+                        collectives=(weak.get('collectives_timed_window')
+                                     if ok else None),
+                        weak_scaling=weak, strong_scaling=strong,
+                        ensemble=ensemble, spinup_steps=args.spinup,
+                        method='gmres', cheb_degree=args.cheb,
+                        factorization=args.fact, drop_tol=args.drop,
+                        rtol=args.rtol,
+                        krylov_iters_per_step=(
+                            weak.get('krylov_iters_per_step') if ok else None),
+                        note='no scaling curve is claimed here: the driver '
+                        'computes it from the per-N lines'),
+            roofline=roofline, cpu_baseline=None, parity=None)
+        print(json.dumps(out))
+        sys.stdout.flush()
+    dist.destroy_process_group()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -336,40 +694,36 @@ def main():
                     help='skip the secondary refined-mesh figures')
     ap.add_argument('--no-picard', action='store_true',
                     help='skip the secondary Newton/Picard sweep figures')
-    ap.add_argument('--replicas', action='store_true',
-                    help='N>1: skip the secondary row-partitioned leg')
+    ap.add_argument('--no-strong', action='store_true',
+                    help='N>1: skip the secondary strong-scaling leg')
+    ap.add_argument('--no-ensemble', action='store_true',
+                    help='N>1: skip the secondary ensemble leg')
     ap.add_argument('--refine', type=int, default=0,
-                    help='(partitioned-only runs) red refinements of the mesh; '
-                    'uses the multigrid Schur block')
+                    help='red refinements of the mesh')
+    ap.add_argument('--dense-max', type=int, default=12000,
+                    help='(partitioned runs) largest pressure space with the '
+                    'dense Schur inverse (held by rows per rank); beyond it '
+                    'the multigrid Schur block')
+    ap.add_argument('--device', type=int, default=0,
+                    help='HIP device of a single-GPU run')
     ap.add_argument('--partitioned-only', action='store_true',
-                    help='(internal) run only the row-partitioned leg and '
-                    'print its figures')
-    ap.add_argument('--partitioned-timeout', type=float, default=100.,
-                    help='time limit [s] of the row-partitioned child run')
+                    help='(internal) one row-partitioned simulation on the '
+                    'ranks of this launch; prints its figures')
+    ap.add_argument('--partitioned-timeout', type=float, default=300.,
+                    help='time limit [s] of a row-partitioned child run')
     ap.add_argument('--force-dist', action='store_true',
                     help='attach an RCCL communicator even with one rank '
                     '(self-test of the multi-GPU code path)')
     args = ap.parse_args()
 
-    one_gpu = False
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
+    if args.partitioned_only:
+        return partitioned_child(args, world, rank, local_rank)
     if world > 1:
-        import torch
-        import torch.distributed as dist
-        # rehearsal of the N > 1 code path on a ONE-GPU box (gloo, every rank
-        # on device 0; RCCL itself refuses two ranks per device, so the
-        # partitioned child then reports an error -- which is the point)
-        one_gpu = os.environ.get('DNS_BENCH_REHEARSE_ONE_GPU') == '1'
-        if one_gpu:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        with stdout_to_stderr():
-            dist.init_process_group('gloo' if one_gpu else 'nccl')
-            dist.barrier()
-    device = local_rank if world > 1 else 0
+        return multi_gpu_main(args, world, rank, local_rank)
+    device = args.device
 
     from dolfin_navier_scipy_amd import saddle, _capi
     from dolfin_navier_scipy_amd import lin_alg_utils as lau
@@ -411,10 +765,7 @@ def main():
     R1 = (M - .5*dt*A).tocsr()
     t_setup = time.perf_counter()
     system = factory(F, J)
-    mode, scaling, comm_obj = ('single', 'weak', None)
-    if world > 1:
-        mode = ('ensemble: {0} independent simulations, one per GPU, no '
-                'data-path collective'.format(world))
+    mode, scaling = ('single', 'weak')
     schur_kind = 'dense'
     if prols is not None:
         system.set_schur_mg(prols)
@@ -441,10 +792,6 @@ def main():
 
     def barrier():
         _capi.device_synchronize(device)
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
 
     def timed_run(with_convection, nsteps=None, nwarm=None, spinup=None):
         nsteps = args.steps if nsteps is None else nsteps
@@ -466,60 +813,11 @@ def main():
         dev_s, its, lst = stp.run(nsteps, cf, opts)
         barrier()
         wl = time.perf_counter() - t0
-        if dist is not None:
-            import torch
-            tw = torch.tensor([wl], dtype=torch.float64,
-                              device='cpu' if one_gpu else 'cuda')
-            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-            wl = float(tw.item())
         vv, pp = stp.get_state()
         lst = dict(lst, run_record=dict(stp.last_run))
         stp.close()
         cvop.close()
         return wl, dev_s, its, lst, vv, pp
-
-    def partitioned_leg():
-        comm_obj = None
-        try:
-            from dolfin_navier_scipy_amd import comm as dcomm
-            with stdout_to_stderr():
-                if dist is not None:
-                    comm_obj = dcomm.Comm.rccl_from_torch(device)
-                else:
-                    comm_obj = dcomm.Comm.rccl(device, 1, 0,
-                                               dcomm.rccl_unique_id())
-            system.set_comm(comm_obj)
-            system.setup_precond(cheb_degree=args.cheb, schur=schur_kind,
-                                 fhat=args.fhat, fp32_store=bool(args.fp32),
-                                 drop_tol=args.drop, factorization=args.fact)
-            psteps = min(args.steps, 200)
-            pwall, _, piters, plast, _, _ = timed_run(
-                True, nsteps=psteps, nwarm=min(args.warmup, 20), spinup=0)
-            res = dict(
-                steps_per_s=psteps/pwall, steps=psteps, scaling='strong',
-                krylov_iters_per_step=piters/float(psteps),
-                true_relres_last=plast['true_relres'],
-                collectives=comm_obj.stats(), unknowns=int(NV + NP),
-                dt=dt,
-                what='one simulation, rows of every operator apply '
-                     'partitioned over {0} rank(s); RCCL all-gather-v + '
-                     'all-reduce per Arnoldi step'.format(world))
-        except Exception as exc:       # keep the headline alive
-            sys.stderr.write('row-partitioned leg failed: {0}\n'.format(exc))
-            res = dict(error=str(exc))
-        system.set_comm(None)
-        if comm_obj is not None:
-            comm_obj.close()
-        return res
-
-    if args.partitioned_only:
-        res = partitioned_leg()
-        if rank == 0:
-            print(json.dumps(res))
-        system.close()
-        if dist is not None:
-            dist.destroy_process_group()
-        return res
 
     # headline: the complete time step, convection evaluated on the device
     wall, dev_s, iters, last, v_gpu, p_gpu = timed_run(True)
@@ -532,60 +830,11 @@ def main():
         # state, no spin-up): the solves need about two Krylov steps there
         wall_et, _, iters_et, _, _, _ = timed_run(True, spinup=0)
 
-    # secondary (N > 1, or --force-dist): ONE simulation whose operator applies
-    # are row-partitioned over the ranks -- RCCL all-gather-v of the row blocks
-    # + all-reduce of the Krylov dots (strong scaling by construction).  With
-    # N > 1 it runs in CHILD processes (one per rank, their own rendezvous) under
-    # a time limit: a collective that never completes must not take the
-    # headline measurement with it.
+    # self-test of the multi-GPU code path on one rank (RCCL communicator of
+    # size 1): the same partitioned run the N > 1 headline times
     partitioned = None
-    partitioned_refined = None
-
-    def run_children(port_offset, steps, warmup, nts, refine):
-        """the row-partitioned leg in one child process per rank"""
-        import subprocess
-        env = dict(os.environ)
-        env['MASTER_PORT'] = str(int(os.environ.get('MASTER_PORT', '29500'))
-                                 + port_offset)
-        cmd = [sys.executable, os.path.abspath(__file__), '--partitioned-only',
-               '--gpus', str(world), '--steps', str(steps), '--warmup',
-               str(warmup), '--level', str(args.level), '--Re',
-               str(args.Re), '--nts', str(nts), '--cheb', str(args.cheb),
-               '--rtol', str(args.rtol), '--extrap', str(args.extrap),
-               '--fp32', str(args.fp32), '--drop', str(args.drop),
-               '--fhat', args.fhat, '--fact', args.fact, '--refine',
-               str(refine)]
-        res = None
-        barrier()
-        try:
-            child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE,
-                                     stderr=subprocess.DEVNULL,
-                                     start_new_session=True)
-            try:
-                cout, _ = child.communicate(timeout=args.partitioned_timeout)
-                lines = [ln for ln in cout.decode().splitlines()
-                         if ln.startswith('{')]
-                if rank == 0:
-                    res = (json.loads(lines[-1]) if lines else
-                           dict(error='child exited with code {0} and no '
-                                'result'.format(child.returncode)))
-            except subprocess.TimeoutExpired:
-                os.killpg(child.pid, 9)
-                child.wait()
-                res = dict(error='no result within {0} s (killed)'
-                           .format(args.partitioned_timeout))
-        except Exception as exc:
-            res = dict(error=str(exc))
-        barrier()
-        return res
-
-    if args.force_dist and world == 1:
-        partitioned = partitioned_leg()
-    elif world > 1 and not args.replicas:
-        partitioned = run_children(17, args.steps, args.warmup, args.nts, 0)
-        # the same on the mesh refined twice (n = 173k, multigrid Schur
-        # block, dt/4): the size at which partitioning starts to have a chance
-        partitioned_refined = run_children(29, 100, 10, 4*args.nts, 2)
+    if args.force_dist:
+        partitioned = partitioned_run(args, 1, 0, device, None, False)
 
     out = None
     if rank == 0:
@@ -690,7 +939,6 @@ def main():
                                 args.warmup, args.warmup + args.steps)),
                         parallelism=mode, collectives=None,
                         row_partitioned=partitioned,
-                        row_partitioned_refined=partitioned_refined,
                         method=args.method, cheb_degree=args.cheb,
                         factorization=args.fact, drop_tol=args.drop,
                         schur='dense', rtol=args.rtol,
@@ -712,8 +960,6 @@ def main():
         print(json.dumps(out))
     system.close()
     lau.clear_cache()
-    if dist is not None:
-        dist.destroy_process_group()
     return out
 
 

@@ -198,6 +198,9 @@ k_bicg_x(int n, double *__restrict__ x, double *__restrict__ r,
 //   b_v = R1 (a_c v_c + a_p v_p) + cn_c nfc_c + cn_o nfc_o + g
 //   b_p = gp
 // ---------------------------------------------------------------------------
+// row0 / [prow0, prow1): the CSR arrays hold the `nv` velocity rows starting at
+// global row `row0` (row-partitioned: this rank's block; else 0 and all rows)
+// and the pressure rows [prow0, prow1) are written
 template <int LPR>
 __global__ void __launch_bounds__(kBlock)
 k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
@@ -205,31 +208,34 @@ k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
            const double *__restrict__ v_c, const double *__restrict__ v_p,
            double a_c, double a_p, const double *__restrict__ nfc_c,
            const double *__restrict__ nfc_o, double cn_c, double cn_o,
-           TabRef gtab, TabRef gptab, double *__restrict__ b) {
+           TabRef gtab, TabRef gptab, double *__restrict__ b, int row0,
+           int nv_all, int prow0, int prow1) {
     const double *__restrict__ g = tab_row(gtab);
     const double *__restrict__ gp = tab_row(gptab);
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < nv; row += nsub) {
-        const int k1 = rowptr[row + 1];
+    for (int li = sub; li < nv; li += nsub) {
+        const int row = row0 + li;
+        const int k1 = rowptr[li + 1];
         double s = 0.0;
         if (a_p != 0.0) {
-            for (int k = rowptr[row] + sublane; k < k1; k += LPR) {
+            for (int k = rowptr[li] + sublane; k < k1; k += LPR) {
                 const int c = colidx[k];
                 s = fma(vals[k], fma(a_c, v_c[c], a_p * v_p[c]), s);
             }
         } else {
-            for (int k = rowptr[row] + sublane; k < k1; k += LPR)
+            for (int k = rowptr[li] + sublane; k < k1; k += LPR)
                 s = fma(vals[k], a_c * v_c[colidx[k]], s);
         }
         s = subwave_sum<LPR>(s);
         if (sublane == 0)
             b[row] = s + cn_c * nfc_c[row] + cn_o * nfc_o[row] + g[row];
     }
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
+    (void)np;
+    for (int i = prow0 + blockIdx.x * kBlock + threadIdx.x; i < prow1;
          i += gridDim.x * kBlock)
-        b[nv + i] = gp[i];
+        b[nv_all + i] = gp[i];
 }
 
 // the vector part of the IMEX right-hand side (bandwidth regime: R1 v then goes

@@ -35,12 +35,17 @@ conv_cells_block(int bid, int ncells, const int *__restrict__ cellmap,   // [12]
              const double *__restrict__ glam,               // [6][ncells]
              const double *__restrict__ area,
              const double *__restrict__ v_inner, TabRef dbctab,
-             double *__restrict__ cellvals) {               // [12][ncells]
+             double *__restrict__ cellvals,                 // [12][ncells]
+             const int *__restrict__ sel = nullptr, int nsel = 0) {
+    // sel: only the cells sel[0..nsel) (row-partitioned time steppers: the
+    // cells that touch this rank's rows)
     const double *__restrict__ dbcvals = tab_row(dbctab);
     const int t = bid * kBlock + threadIdx.x;
-    const int c = t >> 3;
+    const int slot = t >> 3;
     const int q = t & 7;
-    const bool live = c < ncells;        // whole 8-lane groups are live or not
+    // whole 8-lane groups are live or not
+    const bool live = sel ? slot < nsel : slot < ncells;
+    const int c = (sel && live) ? sel[slot] : slot;
     const int cc = live ? c : 0;
     const int qq = (q < 7) ? q : 0;
     double ul[6][2];
@@ -100,17 +105,18 @@ __global__ void __launch_bounds__(kBlock)
 k_conv_cells(int ncells, const int *__restrict__ cellmap,
              const double *__restrict__ glam, const double *__restrict__ area,
              const double *__restrict__ v_inner, TabRef dbctab,
-             double *__restrict__ cellvals) {
+             double *__restrict__ cellvals, const int *__restrict__ sel,
+             int nsel) {
     conv_cells_block(blockIdx.x, ncells, cellmap, glam, area, v_inner, dbctab,
-                     cellvals);
+                     cellvals, sel, nsel);
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_conv_gather(int nrows, const int *__restrict__ gptr,
+k_conv_gather(int row0, int row1, const int *__restrict__ gptr,
               const int *__restrict__ gidx,
               const double *__restrict__ cellvals, double scale,
               double *__restrict__ out) {
-    for (int r = blockIdx.x * kBlock + threadIdx.x; r < nrows;
+    for (int r = row0 + blockIdx.x * kBlock + threadIdx.x; r < row1;
          r += gridDim.x * kBlock) {
         double s = 0.0;
         for (int k = gptr[r]; k < gptr[r + 1]; ++k) s += cellvals[gidx[k]];
@@ -139,6 +145,7 @@ struct dns_conv {
         return {dbc_tab.p + (size_t)r * std::max(1, ndbc), nullptr, 0, 1};
     }
     std::vector<int> cmap_host;            // [12][ncells], as on the device
+    std::vector<int> gptr_host, gidx_host; // the inverted index, as on the device
     struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
     ~dns_conv();
     // local matrices of N1(u) (+ N2(u)) -> mat->L
@@ -149,11 +156,28 @@ struct dns_conv {
                            hipStream_t s);
     int enqueue_bc_gather(double *rhsbc, hipStream_t s);
     // element kernel alone (the gather is fused into the step prologue)
-    int enqueue_cells(const double *v_dev, hipStream_t s) {
-        const int g1 = (8 * ncells + dns::kBlock - 1) / dns::kBlock;
+    int enqueue_cells(const double *v_dev, hipStream_t s,
+                      const int *sel = nullptr, int nsel = 0) {
+        const int live = sel ? nsel : ncells;
+        if (live <= 0) return DNS_OK;
+        const int g1 = (8 * live + dns::kBlock - 1) / dns::kBlock;
         hipLaunchKernelGGL(dns::k_conv_cells, g1, dns::kBlock, 0, s, ncells,
                            cellmap.p, glam.p, area.p, v_dev, dbc_ref(),
-                           cellvals.p);
+                           cellvals.p, sel, nsel);
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
+    }
+    // the rows [row0, row1) of scale * N(u)u from the cells sel[0..nsel) (the
+    // cells that touch those rows: dns_imex::ensure_partition)
+    int enqueue_rows(const double *v_dev, double scale, double *out_dev,
+                     int row0, int row1, const int *sel, int nsel,
+                     hipStream_t s) {
+        DNS_TRY(enqueue_cells(v_dev, s, sel, nsel));
+        if (row1 <= row0) return DNS_OK;
+        const int g2 = std::max(1, std::min((row1 - row0 + dns::kBlock - 1) /
+                                                dns::kBlock, 2048));
+        hipLaunchKernelGGL(dns::k_conv_gather, g2, dns::kBlock, 0, s, row0,
+                           row1, gptr.p, gidx.p, cellvals.p, scale, out_dev);
         DNS_HIP(hipGetLastError());
         return DNS_OK;
     }
@@ -163,8 +187,9 @@ struct dns_conv {
         DNS_TRY(enqueue_cells(v_dev, s));
         const int g2 = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
                                                 dns::kBlock, 2048));
-        hipLaunchKernelGGL(dns::k_conv_gather, g2, dns::kBlock, 0, s, nv_inner,
-                           gptr.p, gidx.p, cellvals.p, scale, out_dev);
+        hipLaunchKernelGGL(dns::k_conv_gather, g2, dns::kBlock, 0, s, 0,
+                           nv_inner, gptr.p, gidx.p, cellvals.p, scale,
+                           out_dev);
         DNS_HIP(hipGetLastError());
         return DNS_OK;
     }

@@ -7,7 +7,24 @@
 
 struct dns_imex {
     dns_saddle *sys = nullptr;
-    dns::CsrDev R1;
+    dns::CsrDev R1;                // all rows, or this rank's (partitioned)
+    dns::HostCsr R1h;              // host copy (row blocks are cut from it)
+    // row-partitioned system (dist_solve.inc): the right-hand side is formed
+    // for this rank's rows only -- R1 by rows, the convection from the cells
+    // that touch them -- and the solution's halo entries are exchanged by
+    // index lists (footprints of K, R1 and those cells) instead of gathering
+    // the whole vector
+    struct Partition {
+        bool on = false;
+        uint64_t gen = 0;          // sys->dist_generation it was built for
+        const dns_conv *conv_for = nullptr;
+        dns_halo_plan planX;
+        dns::DevBuf<int> conv_sel;
+        int nsel = 0;
+        bool state_full = true;    // xs[cur] holds every rank's rows
+    } part;
+    int ensure_partition();
+    int gather_state();
     // two solution-space vectors [v; p~] (current, previous) + work
     // current and the four solutions before it, work
     dns::DevBuf<double> xs[6];

@@ -11,6 +11,7 @@
 #include "bicgstab_kernels.hpp"
 #include "comm.hpp"
 #include "gmres_kernels.hpp"
+#include "halo.hpp"
 #include "hostcsr.hpp"
 #include "kernels.hpp"
 
@@ -337,6 +338,9 @@ struct dns_saddle {
     bool dist_active = false;         // false during set-up (done redundantly)
     struct dns_dist_data *dd = nullptr;   // row blocks + halo plans (dist_solve.inc)
     bool dist_sliced = false;         // K, Gc, JG hold this rank's rows only
+    uint64_t dist_generation = 0;     // bumped whenever the slicing changes
+                                      // (attached steppers re-slice their own
+                                      // operators then)
     int setup_dist(const dns::HostCsr &Gch, const dns::HostCsr *JGh);
     int restore_full_device();
     int update_values_dist();

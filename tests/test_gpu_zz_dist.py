@@ -80,7 +80,8 @@ def _cyl3_problem():
     return dict(M=M, A=A, J=J, F=(M + .5*dt*A).tocsr(),
                 R1=(M - .5*dt*A).tocsr(), rhsv=M @ rng.standard_normal(NV),
                 rhsp=1e-3*(J @ rng.standard_normal(NV)), dt=dt,
-                v0=rng.standard_normal(NV), nfc=M @ rng.standard_normal(NV))
+                v0=1e-2*rng.standard_normal(NV),
+                nfc=M @ rng.standard_normal(NV), femp=femp)
 
 
 def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
@@ -108,7 +109,19 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
     # a few device-resident CNAB steps through the same communicator
     stepper = sad.ImexStepper(system, pr['R1'])
     dt = pr['dt']
-    stepper.set_state(pr['v0'], nfc_c=pr['nfc'], nfc_o=pr['nfc'])
+    cvop = None
+    if 'femp' in pr:
+        # the convection on the device too: in the partitioned run every rank
+        # evaluates only the cells that touch its rows
+        from dolfin_navier_scipy_amd import convection
+        femp = pr['femp']
+        cvop = convection.ConvectionP2.from_taylor_hood(
+            femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+        nfc = cvop.apply(pr['v0'].reshape((-1, 1)), scale=-1.0)
+        stepper.set_state(pr['v0'], nfc_c=nfc, nfc_o=nfc)
+        stepper.set_convection(cvop, scale=-1.0)
+    else:
+        stepper.set_state(pr['v0'], nfc_c=pr['nfc'], nfc_o=pr['nfc'])
     stepper.set_rhs(dt*pr['rhsv'], pr['rhsp'])
     cf = sad.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
                                 pscale=-1./dt)
@@ -116,6 +129,8 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
     stepper.run(5, cf, opts)
     v, p = stepper.get_state()
     stepper.close()
+    if cvop is not None:
+        cvop.close()
     system.close()
     return x, stats, v, p
 
