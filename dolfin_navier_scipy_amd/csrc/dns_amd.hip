@@ -1213,14 +1213,14 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         // one GPU, fused Gram-Schmidt: tail and correction in ONE launch
         hipLaunchKernelGGL(k_arn_tail_acc, gridD, kBlock, 0, stream, c, n,
                            partA.p, kparts(c - 1), ctl.p, histdev.p,
-                           (int)hist_cap, o->maxiter, Z.p, ld, x);
+                           (int)hist_cap, o->maxiter, Z.p, ld, x, tail_extrap);
         DNS_HIP(hipGetLastError());
         return DNS_OK;
     }
     hipLaunchKernelGGL(k_arn_tail, 1, kBlock, 0, stream, c, partN.p, gridD,
                        ctl.p, histdev.p, (int)hist_cap, o->maxiter, 0);
     hipLaunchKernelGGL(k_basis_combine_acc, gridD, kBlock, 0, stream, n, Z.p,
-                       ld, ctl.p, x);
+                       ld, ctl.p, x, tail_extrap);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

@@ -659,7 +659,7 @@ __global__ void __launch_bounds__(kBlock)
 k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
                DnsCtl *ctl, double *__restrict__ histbuf, int hist_cap,
                int maxiter, const double *__restrict__ Z, size_t ld,
-               double *__restrict__ x) {
+               double *__restrict__ x, TailExtrap te) {
     __shared__ double sc[kMaxRestart + 2];
     __shared__ double yl[kMaxRestart];
     __shared__ int jl;
@@ -747,13 +747,14 @@ k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
     }
     __syncthreads();
     const int jcols = jl;
-    if (jcols == 0) return;
+    if (jcols == 0 && !te.out) return;
     for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
          e += gridDim.x * kBlock) {
         double s = x[e];
         for (int i = 0; i < jcols; ++i)
             s = fma(yl[i], Z[(size_t)i * ld + e], s);
-        x[e] = s;
+        if (jcols > 0) x[e] = s;
+        if (te.out) tail_extrapolate(te, e, s);
     }
 }
 
@@ -779,10 +780,10 @@ k_basis_combine(int n, const double *__restrict__ V, size_t ld,
 // cycle)
 __global__ void __launch_bounds__(kBlock)
 k_basis_combine_acc(int n, const double *__restrict__ Z, size_t ld,
-                    const DnsCtl *ctl, double *__restrict__ x) {
+                    const DnsCtl *ctl, double *__restrict__ x, TailExtrap te) {
     __shared__ double y[kMaxRestart];
     const int jcols = ctl->jdone;
-    if (jcols == 0) return;
+    if (jcols == 0 && !te.out) return;
     if (threadIdx.x < jcols) y[threadIdx.x] = ctl->y[threadIdx.x];
     __syncthreads();
     for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
@@ -790,7 +791,8 @@ k_basis_combine_acc(int n, const double *__restrict__ Z, size_t ld,
         double s = x[e];
         for (int i = 0; i < jcols; ++i)
             s = fma(y[i], Z[(size_t)i * ld + e], s);
-        x[e] = s;
+        if (jcols > 0) x[e] = s;
+        if (te.out) tail_extrapolate(te, e, s);
     }
 }
 

@@ -28,10 +28,39 @@ struct dns_imex {
     // two solution-space vectors [v; p~] (current, previous) + work
     // current and the four solutions before it, work
     dns::DevBuf<double> xs[6];
-    dns::DevBuf<double> ck[5];     // checkpoint of the history for a batch
+    dns::DevBuf<double> ck[6];     // checkpoint of the history (and of the
+                                   // work buffer: it holds the warm start)
+                                   // for a batch
     dns::DevBuf<double> ckn[2];    // ... and of the convection history
     int cur = 0, prev = 1, pprev = 2, p3 = 3, p4 = 4, work = 5;
     int nsol = 0;                  // how many valid solution vectors (0..5)
+    // the work buffer already holds this step's warm start (written by the
+    // previous step's tail kernel, dns::TailExtrap) for the coefficient set
+    // `pre_sig` = extrap_sig(nsol, order)
+    bool pre_ok = false;
+    int pre_sig = -1;
+    // coefficients of the polynomial warm start from `nsol_` solutions
+    static int extrap_coeffs(int nsol_, int order, double e[5]) {
+        e[0] = 1.0;
+        e[1] = e[2] = e[3] = e[4] = 0.0;
+        if (nsol_ >= 5 && order >= 4) {
+            e[0] = 5.0; e[1] = -10.0; e[2] = 10.0; e[3] = -5.0; e[4] = 1.0;
+            return 4;
+        }
+        if (nsol_ >= 4 && order >= 3) {
+            e[0] = 4.0; e[1] = -6.0; e[2] = 4.0; e[3] = -1.0;
+            return 3;
+        }
+        if (nsol_ >= 3 && order >= 2) {
+            e[0] = 3.0; e[1] = -3.0; e[2] = 1.0;
+            return 2;
+        }
+        if (nsol_ >= 2 && order >= 1) {
+            e[0] = 2.0; e[1] = -1.0;
+            return 1;
+        }
+        return 0;
+    }
     long steps_enqueued = 0;       // counts step_device calls (graph replay
                                    // must advance the host state itself)
     void rotate_host() {           // p4 <- p3 <- pprev <- prev <- cur <- new
@@ -101,16 +130,20 @@ struct dns_imex {
     struct HostState {
         int cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos;
         long steps_enqueued;
+        bool pre_ok;
+        int pre_sig;
     };
     HostState host_state() const {
         return {cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos,
-                steps_enqueued};
+                steps_enqueued, pre_ok, pre_sig};
     }
     void set_host_state(const HostState &s) {
         cur = s.cur; prev = s.prev; pprev = s.pprev; p3 = s.p3; p4 = s.p4;
         work = s.work; nsol = s.nsol; nc = s.nc; no = s.no;
         tab_pos = s.tab_pos;
         steps_enqueued = s.steps_enqueued;
+        pre_ok = s.pre_ok;
+        pre_sig = s.pre_sig;
     }
     std::vector<uint64_t> group_key(const dns_imex_coeffs *cf,
                                     const dns_solve_opts *o, int group) const;

@@ -57,6 +57,27 @@ __device__ __forceinline__ const double *tab_row(const TabRef &t) {
     return t.base + (size_t)r * t.stride;
 }
 
+// Warm start of the NEXT time step, written by the kernel that finishes the
+// solution of this one (resident time steppers): out = e0 x_new + e1 h1 + e2 h2
+// + e3 h3 + e4 h4 -- the polynomial extrapolation of the last solutions.  The
+// next step's front kernel then gathers ONE vector along the rows of K instead
+// of five (10.6 -> 7.4 us at n = 1e4).  out == nullptr: off.
+struct TailExtrap {
+    const double *h1, *h2, *h3, *h4;
+    double e0, e1, e2, e3, e4;
+    double *out;
+};
+
+__device__ __forceinline__ void tail_extrapolate(const TailExtrap &t, int e,
+                                                 double xn) {
+    double v = t.e0 * xn;
+    if (t.e1 != 0.0) v = fma(t.e1, t.h1[e], v);
+    if (t.e2 != 0.0) v = fma(t.e2, t.h2[e], v);
+    if (t.e3 != 0.0) v = fma(t.e3, t.h3[e], v);
+    if (t.e4 != 0.0) v = fma(t.e4, t.h4[e], v);
+    t.out[e] = v;
+}
+
 // Rows a kernel launch works on: local row i of the (possibly sliced) CSR
 // arrays is global row `row0 + i` for i < len1, `row2 + i - len1` beyond -- one
 // GPU: {0, n, 0, 0}; row-partitioned: this rank's velocity rows, then its

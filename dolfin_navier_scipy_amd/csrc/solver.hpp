@@ -356,6 +356,8 @@ struct dns_saddle {
                                       // stepper (tables of per-step data);
                                       // bumped by the first head kernel of
                                       // a solve
+    dns::TailExtrap tail_extrap = {}; // warm start of the next step, written
+                                      // by the tail kernels (set by dns_imex)
     int prologue_nparts = 0;          // > 0: partials of ||r||^2, ||b||^2 the
                                       // caller's prologue kernel has written
     int last_iters = -1;              // iteration count of the previous solve

@@ -17,7 +17,10 @@
 
 namespace dns {
 
-template <int LPR>
+// PRE: the warm start x0 has been written into `x0` by the previous step's
+// tail kernel (TailExtrap): the K chain gathers that ONE vector (x0 is not
+// stored again)
+template <int LPR, bool PRE>
 __global__ void __launch_bounds__(kBlock)
 k_step_front(int nconv_blocks,
              // --- convection half
@@ -35,8 +38,7 @@ k_step_front(int nconv_blocks,
              const double *__restrict__ x_pp, const double *__restrict__ x_p3,
              const double *__restrict__ x_p4, double e_c, double e_p,
              double e_pp, double e_p3, double e_p4, double a_c, double a_p,
-             double *__restrict__ x0, double *__restrict__ kx,
-             double *__restrict__ rs) {
+             double *x0, double *__restrict__ kx, double *__restrict__ rs) {
     if ((int)blockIdx.x < nconv_blocks) {
         if (ncells > 0)
             conv_cells_block(blockIdx.x, ncells, cellmap, glam, area, x_c,
@@ -70,7 +72,9 @@ k_step_front(int nconv_blocks,
             rval = r_vals[rk];
         }
         double ks = 0.0, rsum = 0.0;
-        if (k_on) {
+        if (k_on && PRE) {
+            ks = kval * x0[kc];
+        } else if (k_on) {
             double xv = e_c * x_c[kc];
             if (e_p != 0.0) xv = fma(e_p, x_p[kc], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[kc], xv);
@@ -85,6 +89,10 @@ k_step_front(int nconv_blocks,
         }
         for (kk += LPR; kk < kend; kk += LPR) {
             const int c = k_colidx[kk];
+            if (PRE) {
+                ks = fma(k_vals[kk], x0[c], ks);
+                continue;
+            }
             double xv = e_c * x_c[c];
             if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
@@ -101,12 +109,14 @@ k_step_front(int nconv_blocks,
         ks = subwave_sum<LPR>(ks);
         rsum = subwave_sum<LPR>(rsum);
         if (sublane == 0) {
-            double xv = e_c * x_c[row];
-            if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
-            if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
-            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[row], xv);
-            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[row], xv);
-            x0[row] = xv;
+            if (!PRE) {
+                double xv = e_c * x_c[row];
+                if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
+                if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
+                if (e_p3 != 0.0) xv = fma(e_p3, x_p3[row], xv);
+                if (e_p4 != 0.0) xv = fma(e_p4, x_p4[row], xv);
+                x0[row] = xv;
+            }
             kx[row] = ks;
             if (isv) rs[row] = rsum;
         }
