@@ -422,17 +422,27 @@ int dns_saddle::apply_precond(const double *rvec, double *zout,
         if (fp32_store)
             hipLaunchKernelGGL(k_schur_dense<float>, g, kBlock, 0, stream, np,
                                sinv32.p, rvec_schur, (size_t)0, zero_ptr(), nv, zp,
-                               guard, xpf, r0, r1);
+                               guard, xpf, r0, r1, sld);
         else
             hipLaunchKernelGGL(k_schur_dense<double>, g, kBlock, 0, stream, np,
                                sinv.p, rvec_schur, (size_t)0, zero_ptr(), nv, zp,
-                               guard, xpf, r0, r1);
+                               guard, xpf, r0, r1, np);
     } else {
         hipLaunchKernelGGL(k_schur_jacobi, grid_for_elems(r1 - r0), kBlock, 0,
                            stream, np, sinv.p, rvec_schur, (size_t)0, zero_ptr(), nv,
                            zp, guard, xpf, r0, r1);
     }
     return apply_fhat_part(rvec, zp, zout, guard, xacc);
+}
+
+// the dense Schur inverse as fp32 with padded, 16-byte aligned rows
+int dns_saddle::schur_to_f32() {
+    sld = (np + 3) & ~3;
+    DNS_TRY(sinv32.alloc((size_t)np * sld));
+    hipLaunchKernelGGL(k_to_f32_rows, grid_for_elems((int64_t)np * sld), kBlock,
+                       0, stream, np, np, sld, sinv.p, sinv32.p);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
 }
 
 int dns_saddle::to_f32(const double *in, DevBuf<float> &out, size_t count) {
@@ -872,14 +882,14 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         if (fp32_store && popts.schur == DNS_SCHUR_DENSE) {
             // (only the fp32 copy is applied from here on: the fp64 inverse,
             // 8 NP^2 bytes, goes back to the allocator)
-            DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
+            DNS_TRY(schur_to_f32());
             DNS_HIP(hipStreamSynchronize(stream));
             sinv.release();
         }
     } else if (popts.schur == DNS_SCHUR_DENSE) {
         DNS_TRY(build_dense_schur());
         if (fp32_store) {
-            DNS_TRY(to_f32(sinv.p, sinv32, (size_t)np * np));
+            DNS_TRY(schur_to_f32());
             DNS_HIP(hipStreamSynchronize(stream));
             sinv.release();
         }
@@ -1099,7 +1109,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                    nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
                                    ld,
                                    Z.p, (const void *)sinv32.p, ctl.p,
-                                   o->maxiter, tin);
+                                   o->maxiter, tin, 0, np, sld);
             else if (dense)
                 hipLaunchKernelGGL(k_arn_head_f<1>, gridA, kBlock, 0, stream, n,
                                    nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
@@ -1118,7 +1128,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                                (const void *)sinv32.p, zp, ctl.p, o->rtol,
                                o->atol, bb_part, rr_np, o->maxiter, q0, q1,
                                (j == 0) ? first : 0, tin,
-                               (j == 0 && first == 1) ? step_counter : nullptr);
+                               (j == 0 && first == 1) ? step_counter : nullptr,
+                               sld);
         else if (dense)
             hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, stream, n, nv,
                                np, j, src, spart, snp, V.p, ld,
@@ -1785,7 +1796,9 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv32.p, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
-                                           h->gridS, 1 << 30, 0, np, 0, (const double *)nullptr);
+                                           h->gridS, 1 << 30, 0, np, 0,
+                                           (const double *)nullptr,
+                                           (int *)nullptr, h->sld);
                     else
                         hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, s, n,
                                            nv, np, j, h->w.p, h->partN.p,

@@ -120,7 +120,10 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
            double *__restrict__ zp, DnsCtl *ctl, double rtol, double atol,
            const double *__restrict__ bb_part, int bb_nparts, int maxiter,
            int prow0, int prow1, int first,
-           const double *__restrict__ sp_in, int *stepctr = nullptr) {
+           const double *__restrict__ sp_in, int *stepctr = nullptr,
+           int sld = 0) {
+    // sld (SK == 2): row stride of the fp32 inverse, a multiple of four (rows
+    // padded with zeros, 16-byte aligned) -- 0: rows of np entries
     // stepctr (first cycle of a time step's solve only): the device step
     // counter behind the rhs / boundary-value tables; every kernel of the step
     // that reads a table row has run before this one
@@ -146,10 +149,16 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
         if (SK == 1)
             s_first = dense_row_wave<double>(
                 (const double *)sinv + (size_t)row_first * np, sp, np, lane);
+        else if (sld)
+            s_first = dense_row_wave_f4(
+                (const float *)sinv + (size_t)row_first * sld, sp, np, lane);
         else
             s_first = dense_row_wave<float>(
                 (const float *)sinv + (size_t)row_first * np, sp, np, lane);
     }
+    // (likewise this thread's first entry of the vector to be normalised)
+    const int ef = blockIdx.x * kBlock + threadIdx.x;
+    const double src_first = (ef < n) ? src[ef] : 0.0;
     reduce_partials(src_part, src_nparts, src_nparts, 1, sc);
     if (j == 0) reduce_partials(bb_part, bb_nparts, bb_nparts, 1, sc + 1);
     const double hn = sqrt(sc[0]);
@@ -165,8 +174,8 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     if (!stop && hn > 0.0) {
         const double scale = 1.0 / hn;
         double *vj = V + (size_t)j * ld;
-        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
-             e += gridDim.x * kBlock)
+        if (ef < n) vj[ef] = src_first * scale;
+        for (int e = ef + gridDim.x * kBlock; e < n; e += gridDim.x * kBlock)
             vj[e] = src[e] * scale;
         if (SK == 1 || SK == 2) {
             if (row_first < prow1 && lane == 0)
@@ -177,9 +186,12 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
                         ? dense_row_wave<double>(
                               (const double *)sinv + (size_t)row * np, sp, np,
                               lane)
-                        : dense_row_wave<float>(
-                              (const float *)sinv + (size_t)row * np, sp, np,
-                              lane);
+                        : (sld ? dense_row_wave_f4((const float *)sinv +
+                                                       (size_t)row * sld,
+                                                   sp, np, lane)
+                               : dense_row_wave<float>(
+                                     (const float *)sinv + (size_t)row * np,
+                                     sp, np, lane));
                 if (lane == 0) zp[row] = -scale * s;
             }
         } else if (SK == 0) {
@@ -298,7 +310,9 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
              const double *__restrict__ hpart, int hnparts,
              double *__restrict__ V, size_t ld, double *__restrict__ Z,
              const void *__restrict__ sinv, DnsCtl *ctl, int maxiter,
-             const double *__restrict__ sp_in, int prow0 = 0, int prow1 = -1) {
+             const double *__restrict__ sp_in, int prow0 = 0, int prow1 = -1,
+             int sld = 0) {
+    // sld: as in k_arn_head
     // sp_in: tau(w) = w_p - J Fh^-1 w_v (full block factorisation); the
     // linearity argument below holds for tau as it does for the pressure part
     // [prow0, prow1): the Schur rows this rank computes (all on one GPU)
@@ -320,6 +334,9 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
         if (SK == 1)
             s_first = dense_row_wave<double>(
                 (const double *)sinv + (size_t)row_first * np, wp, np, lane);
+        else if (sld)
+            s_first = dense_row_wave_f4(
+                (const float *)sinv + (size_t)row_first * sld, wp, np, lane);
         else
             s_first = dense_row_wave<float>(
                 (const float *)sinv + (size_t)row_first * np, wp, np, lane);
@@ -370,9 +387,13 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
                             ? dense_row_wave<double>(
                                   (const double *)sinv + (size_t)row * np, wp,
                                   np, lane)
-                            : dense_row_wave<float>(
-                                  (const float *)sinv + (size_t)row * np, wp,
-                                  np, lane);
+                            : (sld ? dense_row_wave_f4((const float *)sinv +
+                                                           (size_t)row * sld,
+                                                       wp, np, lane)
+                                   : dense_row_wave<float>(
+                                         (const float *)sinv +
+                                             (size_t)row * np,
+                                         wp, np, lane));
                 if (lane == 0) {
                     double corr = 0.0;
                     for (int i = 0; i < j; ++i)
@@ -664,6 +685,23 @@ k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
     __shared__ double yl[kMaxRestart];
     __shared__ int jl;
     const bool open_col = !ctl->done && c > 0;
+    // this thread's first element: everything it needs from memory is asked
+    // for BEFORE the reduction and the serial close of the column (none of it
+    // depends on them) -- with n <= gridDim.x * kBlock that is all there is
+    const int ef = blockIdx.x * kBlock + threadIdx.x;
+    double pfx = 0.0, pz0 = 0.0, pz1 = 0.0, ph1 = 0.0, ph2 = 0.0, ph3 = 0.0,
+           ph4 = 0.0;
+    if (ef < n) {
+        pfx = x[ef];
+        if (c > 0) pz0 = Z[ef];
+        if (c > 1) pz1 = Z[ld + ef];
+        if (te.out) {
+            if (te.e1 != 0.0) ph1 = te.h1[ef];
+            if (te.e2 != 0.0) ph2 = te.h2[ef];
+            if (te.e3 != 0.0) ph3 = te.h3[ef];
+            if (te.e4 != 0.0) ph4 = te.h4[ef];
+        }
+    }
     if (open_col) reduce_partials(norm_part, nparts, nparts, c + 1, sc);
     if (threadIdx.x == 0) {
         // local copies of what closing column c-1 changes
@@ -748,8 +786,23 @@ k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
     __syncthreads();
     const int jcols = jl;
     if (jcols == 0 && !te.out) return;
-    for (int e = blockIdx.x * kBlock + threadIdx.x; e < n;
-         e += gridDim.x * kBlock) {
+    if (ef < n) {
+        double s = pfx;
+        if (jcols > 0) s = fma(yl[0], pz0, s);
+        if (jcols > 1) s = fma(yl[1], pz1, s);
+        for (int i = 2; i < jcols; ++i)
+            s = fma(yl[i], Z[(size_t)i * ld + ef], s);
+        if (jcols > 0) x[ef] = s;
+        if (te.out) {
+            double v = te.e0 * s;
+            v = fma(te.e1, ph1, v);
+            v = fma(te.e2, ph2, v);
+            v = fma(te.e3, ph3, v);
+            v = fma(te.e4, ph4, v);
+            te.out[ef] = v;
+        }
+    }
+    for (int e = ef + gridDim.x * kBlock; e < n; e += gridDim.x * kBlock) {
         double s = x[e];
         for (int i = 0; i < jcols; ++i)
             s = fma(yl[i], Z[(size_t)i * ld + e], s);

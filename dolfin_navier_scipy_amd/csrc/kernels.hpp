@@ -901,10 +901,11 @@ __device__ __forceinline__ void dense_rows_block(const VT *__restrict__ a,
                                                  double *__restrict__ out,
                                                  double *__restrict__ xacc,
                                                  double *red, int row0 = 0,
-                                                 int row1 = -1) {
+                                                 int row1 = -1, int lda = 0) {
     if (row1 < 0) row1 = n;
+    if (lda <= 0) lda = n;
     for (int row = row0 + blockIdx.x; row < row1; row += gridDim.x) {
-        const VT *ar = a + (size_t)row * n;
+        const VT *ar = a + (size_t)row * lda;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         int c = threadIdx.x;
         for (; c + 3 * kBlock < n; c += 4 * kBlock) {
@@ -936,6 +937,77 @@ __device__ __forceinline__ void dense_rows_block(const VT *__restrict__ a,
 // that a workgroup's reduction of the dot-product partials is shared by four
 // rows and the kernel has np/4 workgroups instead of np): the whole row is in
 // flight before the first use; returns the wave-reduced dot product
+typedef float dns_float4 __attribute__((ext_vector_type(4)));
+
+// fp32 row whose start is 16-byte aligned and whose length is padded to a
+// multiple of four (zeros): 16-byte loads, a quarter of the load instructions.
+// `x` has n entries (nothing beyond them is read)
+__device__ __forceinline__ double dense_row_wave_f4(const float *__restrict__ ar,
+                                                    const double *__restrict__ x,
+                                                    int n, int lane) {
+    const dns_float4 *a4 = reinterpret_cast<const dns_float4 *>(ar);
+    const int n4 = n >> 2, rem = n & 3;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (rem && lane == 63) {
+        // the last, partial group of four
+        const dns_float4 v = a4[n4];
+        const double *xq = x + 4 * n4;
+        s0 = (double)v.x * xq[0];
+        if (rem > 1) s1 = (double)v.y * xq[1];
+        if (rem > 2) s2 = (double)v.z * xq[2];
+    }
+    int q = lane;
+    for (; q + 192 < n4; q += 256) {
+        const dns_float4 v0 = a4[q], v1 = a4[q + 64], v2 = a4[q + 128],
+                         v3 = a4[q + 192];
+        const double *x0 = x + 4 * q, *x1 = x0 + 256, *x2 = x0 + 512,
+                     *x3 = x0 + 768;
+        s0 = fma((double)v0.x, x0[0], s0);
+        s1 = fma((double)v0.y, x0[1], s1);
+        s2 = fma((double)v0.z, x0[2], s2);
+        s3 = fma((double)v0.w, x0[3], s3);
+        s0 = fma((double)v1.x, x1[0], s0);
+        s1 = fma((double)v1.y, x1[1], s1);
+        s2 = fma((double)v1.z, x1[2], s2);
+        s3 = fma((double)v1.w, x1[3], s3);
+        s0 = fma((double)v2.x, x2[0], s0);
+        s1 = fma((double)v2.y, x2[1], s1);
+        s2 = fma((double)v2.z, x2[2], s2);
+        s3 = fma((double)v2.w, x2[3], s3);
+        s0 = fma((double)v3.x, x3[0], s0);
+        s1 = fma((double)v3.y, x3[1], s1);
+        s2 = fma((double)v3.z, x3[2], s2);
+        s3 = fma((double)v3.w, x3[3], s3);
+    }
+    // up to three more 16-byte loads per lane, all issued before their use
+    const bool t0 = q < n4, t1 = q + 64 < n4, t2 = q + 128 < n4;
+    const dns_float4 z4 = {0.f, 0.f, 0.f, 0.f};
+    const dns_float4 v0 = t0 ? a4[q] : z4, v1 = t1 ? a4[q + 64] : z4,
+                     v2 = t2 ? a4[q + 128] : z4;
+    if (t0) {
+        const double *xq = x + 4 * q;
+        s0 = fma((double)v0.x, xq[0], s0);
+        s1 = fma((double)v0.y, xq[1], s1);
+        s2 = fma((double)v0.z, xq[2], s2);
+        s3 = fma((double)v0.w, xq[3], s3);
+    }
+    if (t1) {
+        const double *xq = x + 4 * (q + 64);
+        s0 = fma((double)v1.x, xq[0], s0);
+        s1 = fma((double)v1.y, xq[1], s1);
+        s2 = fma((double)v1.z, xq[2], s2);
+        s3 = fma((double)v1.w, xq[3], s3);
+    }
+    if (t2) {
+        const double *xq = x + 4 * (q + 128);
+        s0 = fma((double)v2.x, xq[0], s0);
+        s1 = fma((double)v2.y, xq[1], s1);
+        s2 = fma((double)v2.z, xq[2], s2);
+        s3 = fma((double)v2.w, xq[3], s3);
+    }
+    return wave_sum((s0 + s1) + (s2 + s3));
+}
+
 template <typename VT>
 __device__ __forceinline__ double dense_row_wave(const VT *__restrict__ ar,
                                                  const double *__restrict__ x,
@@ -967,11 +1039,11 @@ k_schur_dense(int np, const VT *__restrict__ sinv,
               const double *__restrict__ rbase, size_t ld,
               const int *__restrict__ jsel, int nv, double *__restrict__ zp,
               const int *__restrict__ guard, double *__restrict__ xacc,
-              int row0, int row1) {
+              int row0, int row1, int lda) {
     if (*guard) return;
     __shared__ double red[4];
     const double *rp = rbase + (size_t)(*jsel) * ld + nv;
-    dense_rows_block<VT>(sinv, rp, np, -1.0, zp, xacc, red, row0, row1);
+    dense_rows_block<VT>(sinv, rp, np, -1.0, zp, xacc, red, row0, row1, lda);
 }
 
 // plain streaming kernels: what the HBM delivers to a kernel of this library
@@ -1130,6 +1202,19 @@ k_mg_sweep(int n, const int *__restrict__ rowptr,
         if (xin) s = csr_row_dot<LPR>(rowptr, colidx, vals, xin, row, sublane);
         if (sublane == 0)
             xout[row] = (xin ? xin[row] : 0.0) + omega * dinv[row] * (b[row] - s);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_to_f32_rows(int nrows, int ncols, int ldo, const double *__restrict__ in,
+              float *__restrict__ out) {
+    // rows padded with zeros to `ldo` entries
+    const int64_t tot = (int64_t)nrows * ldo;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < tot;
+         i += (int64_t)gridDim.x * kBlock) {
+        const int64_t r = i / ldo;
+        const int c = (int)(i - r * ldo);
+        out[i] = (c < ncols) ? (float)in[r * ncols + c] : 0.0f;
     }
 }
 

@@ -299,7 +299,10 @@ struct dns_saddle {
     bool fhat_explicit = false;
     bool fp32_store = false;         // fp32 copies of Gc values / dense Sinv
     dns::DevBuf<float> sinv32, gc32;
+    int sld = 0;                      // row stride of sinv32 (np padded to a
+                                      // multiple of four: 16-byte row loads)
     int to_f32(const double *in, dns::DevBuf<float> &out, size_t count);
+    int schur_to_f32();
     dns::CsrDev Gc;                  // [G, -G JT], explicit polynomial F^-1
     dns::HostCsr Fh, Jh, JTh;        // host copies for preconditioner set-up
     // convection-dominated F (steady Oseen / Newton systems, snu:458,497): the

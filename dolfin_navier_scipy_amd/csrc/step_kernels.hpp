@@ -143,6 +143,20 @@ k_step_back(int n, int nv, double *__restrict__ nfc_c,
     for (int row = sub; row < n; row += nsub) {
         double cvs = 0.0;
         const bool isv = row < nv;
+        // the row's own entries go out before the (three loads deep) gather
+        // chain of the convection: none of them depends on it
+        double b_in = 0.0, r_in = 0.0, no_in = 0.0, g_in = 0.0, nc_in = 0.0;
+        if (sublane == 0) {
+            r_in = r[row];
+            if (isv) {
+                b_in = b[row];
+                no_in = nfc_o[row];
+                g_in = g[row];
+                if (!gptr) nc_in = nfc_c[row];
+            } else {
+                g_in = gp[row - nv];
+            }
+        }
         if (isv && gptr) {
             const int gend = gptr[row + 1];
             for (int k = gptr[row] + sublane; k < gend; k += LPR)
@@ -152,13 +166,13 @@ k_step_back(int n, int nv, double *__restrict__ nfc_c,
         if (sublane == 0) {
             double bv;
             if (isv) {
-                const double nc = gptr ? conv_scale * cvs : nfc_c[row];
+                const double nc = gptr ? conv_scale * cvs : nc_in;
                 if (gptr) nfc_c[row] = nc;
-                bv = b[row] + cn_c * nc + cn_o * nfc_o[row] + g[row];
+                bv = b_in + cn_c * nc + cn_o * no_in + g_in;
             } else {
-                bv = gp[row - nv];
+                bv = g_in;
             }
-            const double rv = bv - r[row];
+            const double rv = bv - r_in;
             b[row] = bv;
             r[row] = rv;
             arr = fma(rv, rv, arr);
