@@ -241,18 +241,32 @@ k_imex_rhs(int nv, int np, const int *__restrict__ rowptr,
 // the vector part of the IMEX right-hand side (bandwidth regime: R1 v then goes
 // through the streaming kernel with beta = 1):
 //   b_v = cn_c nfc_c + cn_o nfc_o + g ;  b_p = gp ;  xin = a_c v_c + a_p v_p
+// gptr != nullptr: the convection gather rides along (nfc_c = scale * sum of
+// the cell values of the row's inverted index)
 __global__ void __launch_bounds__(kBlock)
 k_imex_bvec(int nv, int np, const double *__restrict__ v_c,
             const double *__restrict__ v_p, double a_c, double a_p,
-            const double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
+            double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
             double cn_c, double cn_o, TabRef gtab, TabRef gptab,
-            double *__restrict__ b, double *__restrict__ xin) {
+            double *__restrict__ b, double *__restrict__ xin,
+            const int *__restrict__ gptr, const int *__restrict__ gidx,
+            const double *__restrict__ cellvals, double conv_scale) {
     const double *__restrict__ g = tab_row(gtab);
     const double *__restrict__ gp = tab_row(gptab);
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < nv + np;
          i += gridDim.x * kBlock) {
         if (i < nv) {
-            b[i] = cn_c * nfc_c[i] + cn_o * nfc_o[i] + g[i];
+            double nc;
+            if (gptr) {
+                double s = 0.0;
+                const int k1 = gptr[i + 1];
+                for (int k = gptr[i]; k < k1; ++k) s += cellvals[gidx[k]];
+                nc = conv_scale * s;
+                nfc_c[i] = nc;
+            } else {
+                nc = nfc_c[i];
+            }
+            b[i] = cn_c * nc + cn_o * nfc_o[i] + g[i];
             xin[i] = (a_p != 0.0) ? fma(a_c, v_c[i], a_p * v_p[i])
                                   : a_c * v_c[i];
         } else {

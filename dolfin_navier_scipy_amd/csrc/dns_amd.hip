@@ -104,6 +104,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     }
     if (const char *sn = getenv("DNS_STREAM_NNZ")) stream_nnz = atoll(sn);
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
+    if (const char *sn = getenv("DNS_MG_FUSED")) mg_fused_knob = sn[0] != '0';
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
@@ -614,6 +615,9 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
     }
     mg.clear();
     for (int l = 0; l < L; ++l) mg.emplace_back();
+    // two sweeps each way: the cycle runs on fused operators (9 launches for
+    // three levels instead of 16); DNS_MG_FUSED=0 keeps the plain cycle
+    mg_fused = mg_nu == 2 && mg_fused_knob;
     HostCsr Sl = S0;
     for (int l = 0; l < L; ++l) {
         MgLevel &lv = mg[l];
@@ -660,7 +664,31 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
         DNS_TRY(lv.dinv.alloc((size_t)lv.n));
         DNS_TRY(lv.dinv.upload(dv.data(), dv.size(), stream));
         DNS_HIP(hipStreamSynchronize(stream));
-        Sl = host_spgemm(PT, host_spgemm(Sl, P));
+        const HostCsr SP = host_spgemm(Sl, P);
+        if (mg_fused) {
+            // the operators of the fused cycle (solver.hpp, MgLevel)
+            std::vector<double> wd((size_t)lv.n);
+            for (int i = 0; i < lv.n; ++i) wd[i] = lv.omega * dv[i];
+            const HostCsr I = host_diag(std::vector<double>((size_t)lv.n, 1.0));
+            HostCsr WS = Sl;
+            host_scale_rows(wd, WS);                       // w D^-1 S
+            const HostCsr T = host_add(1.0, I, -1.0, WS);
+            HostCsr Ap = host_add(2.0, I, -1.0, WS);       // (I + T) ...
+            for (size_t k = 0; k < Ap.vals.size(); ++k)    // ... w D^-1
+                Ap.vals[k] *= wd[Ap.colidx[k]];
+            HostCsr mPTS = host_spgemm(PT, Sl);
+            for (double &v : mPTS.vals) v = -v;
+            const HostCsr Rr = host_hstack(PT, mPTS);
+            HostCsr WSP = SP;
+            host_scale_rows(wd, WSP);
+            const HostCsr Qq = host_hstack(T, host_add(1.0, P, -1.0, WSP));
+            dns_csr av = Ap.view(), rv = Rr.view(), qv = Qq.view();
+            DNS_TRY(lv.Apre.upload(&av, stream));
+            DNS_TRY(lv.Rr.upload(&rv, stream));
+            DNS_TRY(lv.Qq.upload(&qv, stream));
+            DNS_HIP(hipStreamSynchronize(stream));
+        }
+        Sl = host_spgemm(PT, SP);
     }
     mg_ready = true;
     return DNS_OK;
@@ -671,6 +699,7 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
 int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
                                const int *guard) {
     const int L = (int)mg.size();
+    if (mg_fused && L > 1) return schur_mg_apply_fused(in, zp, xacc, guard);
     // sweeps ping-pong between lv.x and lv.x2; returns where the result is
     auto smooth = [&](MgLevel &lv, const double *b, bool from_zero,
                       double *cur) -> double * {
@@ -751,6 +780,93 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
         // guarded form: zp = -x through the (guarded) Jacobi kernel
         hipLaunchKernelGGL(k_mg_jacobi_guard, grid_for_elems(np), kBlock, 0,
                            stream, np, xat[0], zp, xacc, guard);
+    }
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+// out = A [xa ; xb] (+ omega dinv .* b): sub-wave kernel, or the streaming
+// kernel in the bandwidth regime
+int dns_saddle::mg_op(const CsrDev &A, const double *xa, int nsplit,
+                      const double *xb, const MgLevel *add, const double *b,
+                      double *out, const int *guard) {
+    if (!dist() && streams(A)) {
+        StreamEpi ep = stream_epi_plain(1.0, 0.0, nullptr);
+        ep.x2 = xb;
+        ep.nsplit = nsplit;
+        if (add) {
+            ep.dinv = add->dinv.p;
+            ep.b = b;
+            ep.omega = add->omega;
+            ep.add_cb = 1;
+        }
+        return launch_stream16x<double>(A, A.vals.p, xa, out, ep, stream, guard);
+    }
+    DNS_LPR_SWITCH(
+        A.lpr,
+        hipLaunchKernelGGL(k_mg_split<L>, grid_for_rows(A.nrows, A.lpr), kBlock,
+                           0, stream, A.nrows, A.rowptr.p, A.colidx.p, A.vals.p,
+                           xa, nsplit, xb,
+                           add ? add->dinv.p : (const double *)nullptr, b,
+                           add ? add->omega : 0.0, out, guard));
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+// the V(2,2) cycle on the fused operators: per level two launches down
+// (x_pre = Apre b; b_c = Rr [b; x_pre]) and two up (x' = Qq [x_pre; e] + c(b);
+// one more sweep -- the finest level's writes zp = -x'' itself)
+int dns_saddle::schur_mg_apply_fused(const double *in, double *zp, double *xacc,
+                                     const int *guard) {
+    const int L = (int)mg.size();
+    for (int l = 0; l + 1 < L; ++l) {
+        MgLevel &lv = mg[l];
+        const double *b = (l == 0) ? in : lv.b.p;
+        DNS_TRY(mg_op(lv.Apre, b, lv.n, nullptr, nullptr, nullptr, lv.x.p,
+                      guard));
+        DNS_TRY(mg_op(lv.Rr, b, lv.n, lv.x.p, nullptr, nullptr, mg[l + 1].b.p,
+                      guard));
+    }
+    {
+        MgLevel &lc = mg[L - 1];
+        const DnsCtl *gctl = (guard && guard == done_ptr())
+                                 ? (const DnsCtl *)ctl.p
+                                 : (const DnsCtl *)nullptr;
+        const int gg = std::max(1, std::min((lc.n + 3) / 4, 2048));
+        if (fp32_store && mg_cinv32.p)
+            hipLaunchKernelGGL(k_gemv_rows<float>, gg, kBlock, 0, stream, lc.n,
+                               mg_cinv32.p, lc.b.p, lc.x.p, 1.0, gctl);
+        else
+            hipLaunchKernelGGL(k_gemv_rows<double>, gg, kBlock, 0, stream, lc.n,
+                               mg_cinv.p, lc.b.p, lc.x.p, 1.0, gctl);
+    }
+    for (int l = L - 2; l >= 0; --l) {
+        MgLevel &lv = mg[l];
+        const double *b = (l == 0) ? in : lv.b.p;
+        DNS_TRY(mg_op(lv.Qq, lv.x.p, lv.n, mg[l + 1].x.p, &lv, b, lv.x2.p,
+                      guard));
+        // the second post-sweep; on the finest level it delivers zp = -x''
+        double *out = (l == 0) ? zp : lv.x.p;
+        const double osc = (l == 0) ? -1.0 : 1.0;
+        if (!dist() && streams(lv.S)) {
+            StreamEpi ep = stream_epi_plain(osc, 0.0, b);
+            ep.dinv = lv.dinv.p;
+            ep.xin = lv.x2.p;
+            ep.omega = lv.omega;
+            DNS_TRY(launch_stream16x<double>(lv.S, lv.S.vals.p, lv.x2.p, out,
+                                             ep, stream, guard));
+            if (l == 0 && xacc)
+                hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0,
+                                   stream, (int64_t)np, 1.0, zp, 1.0, xacc);
+        } else {
+            DNS_LPR_SWITCH(
+                lv.S.lpr,
+                hipLaunchKernelGGL(k_mg_sweep<L>, grid_for_rows(lv.n, lv.S.lpr),
+                                   kBlock, 0, stream, lv.n, lv.S.rowptr.p,
+                                   lv.S.colidx.p, lv.S.vals.p, lv.dinv.p,
+                                   lv.omega, b, lv.x2.p, out, guard, osc,
+                                   (l == 0) ? xacc : (double *)nullptr));
+        }
     }
     DNS_HIP(hipGetLastError());
     return DNS_OK;
@@ -1032,13 +1148,19 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     // (one GPU; the row-partitioned solve has its own: enqueue_cycle_dist)
     // r = b - K x, ||r||^2, ||b||^2 (unless the caller's prologue kernel has
     // produced r and the partials already)
+    int resid_np = gridS;
     if (!have_resid && streams(K)) {
-        // bandwidth regime: r = b - K x at the streaming rate, then the norms
-        DNS_TRY(launch_stream16x<double>(K, K.vals.p, x, r.p,
-                                         stream_epi_plain(-1.0, 1.0, b), stream,
-                                         nullptr));
-        hipLaunchKernelGGL(k_norm2_pair, gridS, kBlock, 0, stream, n, r.p, b,
-                           partR.p, partB.p);
+        // bandwidth regime: r = b - K x at the streaming rate with the
+        // partials of both norms from the same launch
+        StreamEpi ep = stream_epi_plain(-1.0, 1.0, b);
+        ep.part = partR.p;
+        ep.nvec = 0;
+        ep.with_ww = 1;
+        resid_np = stream_grid(K, kStreamGrid);
+        ep.nparts = resid_np;
+        ep.part_bb = partB.p;
+        DNS_TRY(launch_stream16x<double>(K, K.vals.p, x, r.p, ep, stream,
+                                         nullptr, kStreamGrid));
     } else if (!have_resid) {
         DNS_LPR_SWITCH(
             K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
@@ -1049,7 +1171,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     // the consumers of a reduction read the per-workgroup partials
     const double *rr_part = partR.p, *bb_part = partB.p;
     const int rr_np =
-        (have_resid && prologue_nparts > 0) ? prologue_nparts : gridS;
+        (have_resid && prologue_nparts > 0) ? prologue_nparts : resid_np;
     const bool dense = popts.schur == DNS_SCHUR_DENSE;
     const int q0 = 0, q1 = np;
     // (dense Schur rows: one wave each, four per workgroup)

@@ -435,11 +435,17 @@ struct StreamEpi {
     int nsplit;
     const double *dinv, *xin;    // Jacobi sweep (dinv != nullptr)
     double omega;
+    int add_cb;                  // y = alpha A x + omega dinv .* b (the fused
+                                 // multigrid operators; dinv, b, omega as in
+                                 // the sweep)
     const double *V;             // fused dots (part != nullptr)
     size_t ld;
     int nvec, with_ww;
     double *part;
     int nparts;
+    double *part_bb;             // != nullptr: partials of <b, b> as well (the
+                                 // residual r = b - A x of a solve with both
+                                 // of its norms in ONE launch)
 };
 
 inline StreamEpi stream_epi_plain(double alpha, double beta, const double *b) {
@@ -475,6 +481,7 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
     const bool split = ep.x2 != nullptr;
     const bool dots = ep.part != nullptr;
     double acc[kStreamDots + 1];
+    double accb = 0.0;
 #pragma unroll
     for (int i = 0; i <= kStreamDots; ++i) acc[i] = 0.0;
     for (int blk = vb; blk < nblocks; blk += gridDim.x) {
@@ -545,9 +552,13 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
             if (g == 0) {
                 const int row = r0 + r;
                 double out;
-                if (ep.dinv) {
+                if (ep.dinv && ep.add_cb) {
+                    out = fma(ep.alpha, s,
+                              ep.omega * ep.dinv[row] * ep.b[row]);
+                } else if (ep.dinv) {
                     const double xi = ep.xin ? ep.xin[row] : 0.0;
-                    out = xi + ep.omega * ep.dinv[row] * (ep.b[row] - s);
+                    out = ep.alpha *
+                          (xi + ep.omega * ep.dinv[row] * (ep.b[row] - s));
                 } else {
                     out = ep.b ? fma(ep.alpha, s, ep.beta * ep.b[row])
                                : ep.alpha * s;
@@ -569,6 +580,10 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
                         acc[i] = fma(ep.V[(size_t)i * ep.ld + row], out,
                                      acc[i]);
                 acc[kStreamDots] = fma(out, out, acc[kStreamDots]);
+                if (ep.part_bb) {
+                    const double bv = ep.b[row];
+                    accb = fma(bv, bv, accb);
+                }
             }
         }
     }
@@ -586,6 +601,10 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
             const double a = block_sum(acc[kStreamDots], red);
             if (threadIdx.x == 0)
                 ep.part[(size_t)ep.nvec * ep.nparts + blockIdx.x] = a;
+        }
+        if (ep.part_bb) {
+            const double a = block_sum(accb, red);
+            if (threadIdx.x == 0) ep.part_bb[blockIdx.x] = a;
         }
     }
 }
@@ -1192,7 +1211,10 @@ k_mg_sweep(int n, const int *__restrict__ rowptr,
            const int *__restrict__ colidx, const double *__restrict__ vals,
            const double *__restrict__ dinv, double omega,
            const double *__restrict__ b, const double *__restrict__ xin,
-           double *__restrict__ xout, const int *__restrict__ guard) {
+           double *__restrict__ xout, const int *__restrict__ guard,
+           double oscale = 1.0, double *__restrict__ xacc = nullptr) {
+    // oscale, xacc: the last sweep of a V-cycle writes zp = -x itself (and
+    // x_p += zp)
     if (guard && *guard) return;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
@@ -1200,8 +1222,49 @@ k_mg_sweep(int n, const int *__restrict__ rowptr,
     for (int row = sub; row < n; row += nsub) {
         double s = 0.0;
         if (xin) s = csr_row_dot<LPR>(rowptr, colidx, vals, xin, row, sublane);
-        if (sublane == 0)
-            xout[row] = (xin ? xin[row] : 0.0) + omega * dinv[row] * (b[row] - s);
+        if (sublane == 0) {
+            const double v = oscale * ((xin ? xin[row] : 0.0) +
+                                       omega * dinv[row] * (b[row] - s));
+            xout[row] = v;
+            if (xacc) xacc[row] += v;
+        }
+    }
+}
+
+// One operator of the fused V(2,2) cycle (dns_saddle::build_mg_schur):
+//   out = A [xa ; xb] (+ omega dinv .* b)
+// columns < nsplit read xa, the others xb (xb == nullptr: a plain product)
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_mg_split(int nrows, const int *__restrict__ rowptr,
+           const int *__restrict__ colidx, const double *__restrict__ vals,
+           const double *__restrict__ xa, int nsplit,
+           const double *__restrict__ xb, const double *__restrict__ dinv,
+           const double *__restrict__ b, double omega,
+           double *__restrict__ out, const int *__restrict__ guard) {
+    if (guard && *guard) return;
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    for (int row = sub; row < nrows; row += nsub) {
+        const int k1 = rowptr[row + 1];
+        int k = rowptr[row] + sublane;
+        // (the row's own addend does not depend on the gather chain)
+        const double add =
+            (dinv && sublane == 0) ? omega * dinv[row] * b[row] : 0.0;
+        double s0 = 0.0, s1 = 0.0;
+        for (; k + LPR < k1; k += 2 * LPR) {
+            const int c0 = colidx[k], c1 = colidx[k + LPR];
+            const double v0 = vals[k], v1 = vals[k + LPR];
+            s0 = fma(v0, (xb && c0 >= nsplit) ? xb[c0 - nsplit] : xa[c0], s0);
+            s1 = fma(v1, (xb && c1 >= nsplit) ? xb[c1 - nsplit] : xa[c1], s1);
+        }
+        if (k < k1) {
+            const int c = colidx[k];
+            s0 = fma(vals[k], (xb && c >= nsplit) ? xb[c - nsplit] : xa[c], s0);
+        }
+        const double s = subwave_sum<LPR>(s0 + s1);
+        if (sublane == 0) out[row] = s + add;
     }
 }
 

@@ -363,6 +363,8 @@ struct dns_saddle {
                                       // by the tail kernels (set by dns_imex)
     int prologue_nparts = 0;          // > 0: partials of ||r||^2, ||b||^2 the
                                       // caller's prologue kernel has written
+    bool mg_fused = false;            // the V-cycle runs on the fused operators
+    bool mg_fused_knob = true;        // DNS_MG_FUSED (read once, at create)
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open
@@ -371,6 +373,12 @@ struct dns_saddle {
         int n = 0;
         double omega = 0.6;               // Jacobi damping, 4 / (3 lambda_max)
         dns::CsrDev S, P, PT;             // operator, prolongation from l+1, P^T
+        // fused V(2,2) cycle (mg_fused): with T = I - w D^-1 S, c(b) = w D^-1 b
+        //   Apre = (I + T) w D^-1     x_pre = Apre b       (two sweeps from 0)
+        //   Rr   = [P^T, -P^T S]      b_c = Rr [b; x_pre]  (residual+restriction)
+        //   Qq   = [T, T P]           x' = Qq [x_pre; e] + c(b)
+        //                                            (prolongation + first sweep)
+        dns::CsrDev Apre, Rr, Qq;
         dns::DevBuf<double> dinv, x, b, r, x2;
     };
     std::deque<MgLevel> mg;               // (device buffers do not move)
@@ -381,6 +389,11 @@ struct dns_saddle {
     int mg_nu = 2;
     bool mg_ready = false, mg_set = false;
     int build_mg_schur(const dns::HostCsr &S0);
+    int mg_op(const dns::CsrDev &A, const double *xa, int nsplit,
+              const double *xb, const MgLevel *add, const double *b,
+              double *out, const int *guard);
+    int schur_mg_apply_fused(const double *in, double *zp, double *xacc,
+                             const int *guard);
     int schur_mg_apply(const double *in, double *zp, double *xacc,
                        const int *guard);
     // full block factorisation: J Fh^-1 as one CSR matrix, tau = r_p - JG r_v
