@@ -334,7 +334,13 @@ k_spmv_stream(int nblocks, const int *__restrict__ rowblocks,
 // DIAG != 0 are diagnostic variants (scripts/spmv_c16.py; wrong results by
 // design): 1 = x read at the stream position instead of the column (no
 // gather), 2 = additionally no LDS reduction phase
-template <int G, int DIAG = 0, typename VT = double>
+// PAIR: every lane loads TWO consecutive non-zeros per instruction (16 bytes of
+// values, 4 bytes of offsets) from the even-aligned stream -- half the load
+// instructions for the same bytes
+typedef unsigned short dns_ushort2 __attribute__((ext_vector_type(2)));
+typedef double dns_double2 __attribute__((ext_vector_type(2)));
+
+template <int G, int DIAG = 0, typename VT = double, int PAIR = 0>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
                 const int *__restrict__ rowptr, const int *__restrict__ colidx,
@@ -370,7 +376,49 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
         const int nr = r1 - r0;
         if (threadIdx.x < nr) rps[threadIdx.x] = rowptr[r0 + threadIdx.x] - k0;
         if (threadIdx.x == 0) rps[nr] = nn;
-        if (blo >= 0 && nn > 0) {
+        if (PAIR && blo >= 0 && nn > 0 && sizeof(VT) == 8 &&
+            (nn + (k0 & 1)) <= TILE) {
+            // pairs from the even-aligned stream: position q of the window
+            // [ke, ke + TILE), ke = k0 rounded down to even; entries outside
+            // [k0, k1) belong to the neighbours (or to the two spare entries
+            // behind the arrays) and are not stored
+            constexpr int NP2 = TILE / kBlock / 2;
+            const int ke = k0 & ~1;
+            const int last = (k1 - 1 - ke) >> 1;        // last pair with data
+            dns_double2 v[NP2];
+            dns_ushort2 e[NP2];
+            const dns_double2 *v2 =
+                reinterpret_cast<const dns_double2 *>(vals + ke);
+            const dns_ushort2 *e2 =
+                reinterpret_cast<const dns_ushort2 *>(c16 + ke);
+#pragma unroll
+            for (int i = 0; i < NP2; ++i) {
+                const int q = min((int)threadIdx.x + i * kBlock, last);
+                v[i] = v2[q];
+                e[i] = e2[q];
+            }
+            double xa[NP2], xb[NP2];
+#pragma unroll
+            for (int i = 0; i < NP2; ++i) {
+                const int ca = ((e[i].x & 0x8000) ? bhi : blo) + (e[i].x & 0x7fff);
+                const int cb = ((e[i].y & 0x8000) ? bhi : blo) + (e[i].y & 0x7fff);
+                // (a neighbour's entry decodes against this block's bases: keep
+                // the address inside x)
+                const int q = min((int)threadIdx.x + i * kBlock, last);
+                const bool oka = ke + 2 * q >= k0, okb = ke + 2 * q + 1 < k1;
+                xa[i] = oka ? x[ca] : 0.0;
+                xb[i] = okb ? x[cb] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < NP2; ++i) {
+                const int q = (int)threadIdx.x + i * kBlock;
+                const int pa = 2 * q - (k0 & 1);
+                if (q <= last) {
+                    if (pa >= 0) prod[pa] = v[i].x * xa[i];
+                    if (pa + 1 < nn) prod[pa + 1] = v[i].y * xb[i];
+                }
+            }
+        } else if (blo >= 0 && nn > 0) {
             // branch-free: every lane issues its TILE/kBlock value and index
             // loads back to back (positions past the end are clamped to the
             // last entry; their products land in LDS slots nobody reads), then
@@ -1067,7 +1115,6 @@ k_schur_dense(int np, const VT *__restrict__ sinv,
 
 // plain streaming kernels: what the HBM delivers to a kernel of this library
 // (dns_hbm_probe); 16-byte accesses, grid-stride, fully coalesced
-typedef double dns_double2 __attribute__((ext_vector_type(2)));
 
 __global__ void __launch_bounds__(kBlock)
 k_stream_read(int64_t n2, const dns_double2 *__restrict__ a,

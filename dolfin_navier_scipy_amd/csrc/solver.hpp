@@ -171,29 +171,41 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                                A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p,
                                A.c16.p, A.c16base.p, A.vals.p, x, y, alpha,
                                beta, b);
+    } else if (variant == 5 && A.c16.p) {
+        // single loads (the kernel before the pair loads; A/B record,
+        // scripts/spmv_c16.py)
+        const int nb = A.nrowblocks_t[1];
+        hipLaunchKernelGGL((k_spmv_stream16<4, 0, double, 0>),
+                           std::min(nb, 65535), kBlock, 0, s, nb,
+                           A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p, A.c16.p,
+                           A.c16base.p, A.vals.p, x, y, alpha, beta, b, guard);
     } else if (variant == DNS_SPMV_STREAM16 && A.c16.p) {
         // the same with 16-bit column offsets: 10 instead of 12 bytes per
-        // non-zero cross the HBM
+        // non-zero cross the HBM; pair loads (16 bytes per lane)
         const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
         const int nb = A.nrowblocks_t[1];
         const int grid = std::min(nb, 65535);
         const int *rbp = A.rowblocks_t[1].p;
         if (avg <= 6)
-            hipLaunchKernelGGL((k_spmv_stream16<1>), grid, kBlock, 0, s, nb, rbp,
-                               A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                               A.vals.p, x, y, alpha, beta, b, guard);
+            hipLaunchKernelGGL((k_spmv_stream16<1, 0, double, 1>), grid, kBlock,
+                               0, s, nb, rbp, A.rowptr.p, A.colidx.p, A.c16.p,
+                               A.c16base.p, A.vals.p, x, y, alpha, beta, b,
+                               guard);
         else if (avg <= 12)
-            hipLaunchKernelGGL((k_spmv_stream16<2>), grid, kBlock, 0, s, nb, rbp,
-                               A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                               A.vals.p, x, y, alpha, beta, b, guard);
+            hipLaunchKernelGGL((k_spmv_stream16<2, 0, double, 1>), grid, kBlock,
+                               0, s, nb, rbp, A.rowptr.p, A.colidx.p, A.c16.p,
+                               A.c16base.p, A.vals.p, x, y, alpha, beta, b,
+                               guard);
         else if (avg <= 48)
-            hipLaunchKernelGGL((k_spmv_stream16<4>), grid, kBlock, 0, s, nb, rbp,
-                               A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                               A.vals.p, x, y, alpha, beta, b, guard);
+            hipLaunchKernelGGL((k_spmv_stream16<4, 0, double, 1>), grid, kBlock,
+                               0, s, nb, rbp, A.rowptr.p, A.colidx.p, A.c16.p,
+                               A.c16base.p, A.vals.p, x, y, alpha, beta, b,
+                               guard);
         else
-            hipLaunchKernelGGL((k_spmv_stream16<16>), grid, kBlock, 0, s, nb,
-                               rbp, A.rowptr.p, A.colidx.p, A.c16.p,
-                               A.c16base.p, A.vals.p, x, y, alpha, beta, b, guard);
+            hipLaunchKernelGGL((k_spmv_stream16<16, 0, double, 1>), grid,
+                               kBlock, 0, s, nb, rbp, A.rowptr.p, A.colidx.p,
+                               A.c16.p, A.c16base.p, A.vals.p, x, y, alpha,
+                               beta, b, guard);
     } else if (variant == DNS_SPMV_STREAM || variant == DNS_SPMV_STREAM16) {
         // tile 2048, branch-free full-tile loads (UNR = 0), row pointers
         // staged in LDS

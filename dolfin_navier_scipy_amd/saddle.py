@@ -324,7 +324,8 @@ def spmv(A, x, y=None, alpha=1., beta=0., variant='vector', device=0):
     x = C.as_f64(x, size=view.shape[1])
     out = np.zeros(view.shape[0]) if y is None else C.as_f64(y).copy()
     C.check(lib.dns_spmv(device, view.byref(), C.dptr(x), C.dptr(out),
-                         float(alpha), float(beta), _VARIANTS[variant]))
+                         float(alpha), float(beta),
+                         _VARIANTS.get(variant, variant)))
     return out
 
 

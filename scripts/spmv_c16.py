@@ -11,7 +11,8 @@ _, sm, _ = bench.build_problem(N=2, Re=100., refine=refine)
 K = bench.saddle_csr((sm['M'] + .5/512*sm['A']).tocsr(), sm['J'])
 nb = bench.spmv_bytes(K)
 names = {17: 'stream, 2 loads per lane in flight (earlier kernel)',
-         1: 'stream (int32 cols)', 2: 'stream16 (u16 offsets)',
+         1: 'stream (int32 cols)', 2: 'stream16 (u16 offsets, pair loads)',
+         5: 'stream16, single loads (before)',
          3: 'diag: stream16 without the x gather',
          4: 'diag: ... and without the LDS row reduction'}
 res = {k: [] for k in names}
@@ -27,3 +28,5 @@ x = np.random.default_rng(0).standard_normal(K.shape[1])
 y1 = saddle.spmv(K, x, variant='stream')
 y2 = saddle.spmv(K, x, variant='stream16')
 print('max |y16 - y32| =', np.abs(y1 - y2).max())
+y3 = saddle.spmv(K, x, variant=5)
+print('max |ysingle - y32| =', np.abs(y1 - y3).max())
