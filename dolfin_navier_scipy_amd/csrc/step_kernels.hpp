@@ -187,4 +187,33 @@ k_step_back(int n, int nv, double *__restrict__ nfc_c,
     }
 }
 
+// Start of a pipelined batch in ONE launch: checkpoint of the ring (and of
+// the convection history) and reset of the batch accumulators of the control
+// block -- eight hipMemcpyAsync + two hipMemsetAsync cost the host ~50 us per
+// batch, which a 20-step window sees.
+struct CopyList {
+    const double *src[8];
+    double *dst[8];
+    int n[8];
+    int count;
+};
+
+__global__ void __launch_bounds__(kBlock)
+k_batch_begin(CopyList cl, DnsCtl *ctl) {
+    for (int q = 0; q < cl.count; ++q) {
+        const double *__restrict__ s = cl.src[q];
+        double *__restrict__ d = cl.dst[q];
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < cl.n[q];
+             i += gridDim.x * kBlock)
+            d[i] = s[i];
+    }
+    if (ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->acc_solves = 0;
+        ctl->acc_fail = 0;
+        ctl->acc_iters = 0;
+        ctl->acc_maxit = 0;
+        ctl->acc_maxrel = 0.0;
+    }
+}
+
 }  // namespace dns
