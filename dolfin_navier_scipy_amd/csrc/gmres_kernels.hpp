@@ -121,9 +121,13 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
            const double *__restrict__ bb_part, int bb_nparts, int maxiter,
            int prow0, int prow1, int first,
            const double *__restrict__ sp_in, int *stepctr = nullptr,
-           int sld = 0) {
-    // sld (SK == 2): row stride of the fp32 inverse, a multiple of four (rows
-    // padded with zeros, 16-byte aligned) -- 0: rows of np entries
+           int sld = 0, int scol0 = 0, int sncols = -1) {
+    // sld: row stride of the dense inverse (SK == 2: a multiple of four, rows
+    // padded with zeros and 16-byte aligned) -- 0: rows of np entries
+    // [scol0, scol0 + sncols): the COLUMNS of the inverse this rank holds
+    // (row-partitioned solve: every rank forms its share of all rows of
+    // zp = -Sinv tau from its own entries of tau; the shares are all-reduced);
+    // sncols < 0: all columns
     // stepctr (first cycle of a time step's solve only): the device step
     // counter behind the rhs / boundary-value tables; every kernel of the step
     // that reads a table row has run before this one
@@ -140,7 +144,9 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gwave = blockIdx.x * (kBlock / 64) + wave;
     const int nwaves = gridDim.x * (kBlock / 64);
-    const double *sp = sp_in ? sp_in : src + nv;
+    const double *sp = (sp_in ? sp_in : src + nv) + scol0;
+    const int ncl = sncols >= 0 ? sncols : np;
+    const size_t rst = sld ? (size_t)sld : (size_t)np;
     // dense Schur rows: one wave per row; the first row's loads are issued
     // BEFORE the reduction of the norm partials (they do not depend on it)
     double s_first = 0.0;
@@ -148,13 +154,13 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     if ((SK == 1 || SK == 2) && row_first < prow1) {
         if (SK == 1)
             s_first = dense_row_wave<double>(
-                (const double *)sinv + (size_t)row_first * np, sp, np, lane);
+                (const double *)sinv + row_first * rst, sp, ncl, lane);
         else if (sld)
             s_first = dense_row_wave_f4(
-                (const float *)sinv + (size_t)row_first * sld, sp, np, lane);
+                (const float *)sinv + row_first * rst, sp, ncl, lane);
         else
             s_first = dense_row_wave<float>(
-                (const float *)sinv + (size_t)row_first * np, sp, np, lane);
+                (const float *)sinv + row_first * rst, sp, ncl, lane);
     }
     // (likewise this thread's first entry of the vector to be normalised)
     const int ef = blockIdx.x * kBlock + threadIdx.x;
@@ -184,21 +190,20 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
                 const double s =
                     (SK == 1)
                         ? dense_row_wave<double>(
-                              (const double *)sinv + (size_t)row * np, sp, np,
-                              lane)
-                        : (sld ? dense_row_wave_f4((const float *)sinv +
-                                                       (size_t)row * sld,
-                                                   sp, np, lane)
+                              (const double *)sinv + row * rst, sp, ncl, lane)
+                        : (sld ? dense_row_wave_f4(
+                                     (const float *)sinv + row * rst, sp, ncl,
+                                     lane)
                                : dense_row_wave<float>(
-                                     (const float *)sinv + (size_t)row * np,
-                                     sp, np, lane));
+                                     (const float *)sinv + row * rst, sp, ncl,
+                                     lane));
                 if (lane == 0) zp[row] = -scale * s;
             }
         } else if (SK == 0) {
             const double *sd = (const double *)sinv;
             for (int i = prow0 + blockIdx.x * kBlock + threadIdx.x; i < prow1;
                  i += gridDim.x * kBlock)
-                zp[i] = -sd[i] * sp[i] * scale;
+                zp[i] = -sd[i] * sp[i] * scale;     // (scol0 == 0 here)
         }   // SK == 3: the Schur block is a multi-kernel V-cycle behind this
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -311,8 +316,10 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
              double *__restrict__ V, size_t ld, double *__restrict__ Z,
              const void *__restrict__ sinv, DnsCtl *ctl, int maxiter,
              const double *__restrict__ sp_in, int prow0 = 0, int prow1 = -1,
-             int sld = 0) {
-    // sld: as in k_arn_head
+             int sld = 0, int scol0 = 0, int sncols = -1, int add_corr = 1) {
+    // sld, scol0, sncols: as in k_arn_head; add_corr: this rank adds the
+    // Gram-Schmidt correction - sum h_i zp_i to its share (exactly one rank
+    // does when the shares are all-reduced)
     // sp_in: tau(w) = w_p - J Fh^-1 w_v (full block factorisation); the
     // linearity argument below holds for tau as it does for the pressure part
     // [prow0, prow1): the Schur rows this rank computes (all on one GPU)
@@ -325,7 +332,9 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gwave = blockIdx.x * (kBlock / 64) + wave;
     const int nwaves = gridDim.x * (kBlock / 64);
-    const double *wp = sp_in ? sp_in : w + nv;
+    const double *wp = (sp_in ? sp_in : w + nv) + scol0;
+    const int ncl = sncols >= 0 ? sncols : np;
+    const size_t rst = sld ? (size_t)sld : (size_t)np;
     // dense Schur rows by waves; the first row's loads go out before the
     // reduction of the Gram-Schmidt partials
     double s_first = 0.0;
@@ -333,13 +342,13 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
     if ((SK == 1 || SK == 2) && row_first < prow1 && !pre) {
         if (SK == 1)
             s_first = dense_row_wave<double>(
-                (const double *)sinv + (size_t)row_first * np, wp, np, lane);
+                (const double *)sinv + row_first * rst, wp, ncl, lane);
         else if (sld)
             s_first = dense_row_wave_f4(
-                (const float *)sinv + (size_t)row_first * sld, wp, np, lane);
+                (const float *)sinv + row_first * rst, wp, ncl, lane);
         else
             s_first = dense_row_wave<float>(
-                (const float *)sinv + (size_t)row_first * np, wp, np, lane);
+                (const float *)sinv + row_first * rst, wp, ncl, lane);
     }
     reduce_partials(hpart, hnparts, hnparts, j + 1, h);
     const double hn = pythagoras_norm(h, j);
@@ -385,19 +394,20 @@ k_arn_head_f(int n, int nv, int np, int j, const double *__restrict__ w,
                 if (row != row_first)
                     s = (SK == 1)
                             ? dense_row_wave<double>(
-                                  (const double *)sinv + (size_t)row * np, wp,
-                                  np, lane)
-                            : (sld ? dense_row_wave_f4((const float *)sinv +
-                                                           (size_t)row * sld,
-                                                       wp, np, lane)
+                                  (const double *)sinv + row * rst, wp, ncl,
+                                  lane)
+                            : (sld ? dense_row_wave_f4(
+                                         (const float *)sinv + row * rst, wp,
+                                         ncl, lane)
                                    : dense_row_wave<float>(
-                                         (const float *)sinv +
-                                             (size_t)row * np,
-                                         wp, np, lane));
+                                         (const float *)sinv + row * rst, wp,
+                                         ncl, lane));
                 if (lane == 0) {
                     double corr = 0.0;
-                    for (int i = 0; i < j; ++i)
-                        corr = fma(h[i], Z[(size_t)i * ld + nv + row], corr);
+                    if (add_corr)
+                        for (int i = 0; i < j; ++i)
+                            corr = fma(h[i], Z[(size_t)i * ld + nv + row],
+                                       corr);
                     zp[row] = (-s - corr) * scale;
                 }
             }
