@@ -105,6 +105,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     if (const char *sn = getenv("DNS_STREAM_NNZ")) stream_nnz = atoll(sn);
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
     if (const char *sn = getenv("DNS_MG_FUSED")) mg_fused_knob = sn[0] != '0';
+    if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
@@ -687,6 +688,17 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
             DNS_TRY(lv.Rr.upload(&rv, stream));
             DNS_TRY(lv.Qq.upload(&qv, stream));
             DNS_HIP(hipStreamSynchronize(stream));
+            // the prolongation itself is not applied by the fused cycle
+            lv.nnz_P = lv.P.nnz;
+            lv.nnz_S = lv.S.nnz;
+            lv.P.release_all();
+            lv.PT.release_all();
+            if (comm) {
+                lv.Sh = Sl;
+                lv.Apreh = std::move(Ap);
+                lv.Rrh = Rr;
+                lv.Qqh = Qq;
+            }
         }
         Sl = host_spgemm(PT, SP);
     }
@@ -2033,8 +2045,12 @@ int dns_saddle_precond_info(dns_saddle *h, int32_t cap, int64_t *out,
     v.push_back(h->mg_nu);
     for (int l = 0; l < L; ++l) {
         v.push_back(h->mg[l].n);
-        v.push_back(l + 1 < L ? h->mg[l].S.nnz : 0);
-        v.push_back(l + 1 < L ? h->mg[l].P.nnz : 0);
+        // (the whole level's operator and prolongation, also when the level
+        // is stored by row blocks / the prolongation has been folded away)
+        v.push_back(l + 1 < L ? std::max<int64_t>(h->mg[l].S.nnz,
+                                                  h->mg[l].nnz_S) : 0);
+        v.push_back(l + 1 < L ? std::max<int64_t>(h->mg[l].P.nnz,
+                                                  h->mg[l].nnz_P) : 0);
     }
     *count = (int32_t)v.size();
     if (out)

@@ -1259,16 +1259,20 @@ k_mg_sweep(int n, const int *__restrict__ rowptr,
            const double *__restrict__ dinv, double omega,
            const double *__restrict__ b, const double *__restrict__ xin,
            double *__restrict__ xout, const int *__restrict__ guard,
-           double oscale = 1.0, double *__restrict__ xacc = nullptr) {
+           double oscale = 1.0, double *__restrict__ xacc = nullptr,
+           int row0 = 0) {
     // oscale, xacc: the last sweep of a V-cycle writes zp = -x itself (and
     // x_p += zp)
+    // row0: the CSR arrays hold the n rows that start at global row `row0`
+    // (row-partitioned cycle; vectors are indexed by global row)
     if (guard && *guard) return;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < n; row += nsub) {
+    for (int li = sub; li < n; li += nsub) {
+        const int row = row0 + li;
         double s = 0.0;
-        if (xin) s = csr_row_dot<LPR>(rowptr, colidx, vals, xin, row, sublane);
+        if (xin) s = csr_row_dot<LPR>(rowptr, colidx, vals, xin, li, sublane);
         if (sublane == 0) {
             const double v = oscale * ((xin ? xin[row] : 0.0) +
                                        omega * dinv[row] * (b[row] - s));
@@ -1288,14 +1292,17 @@ k_mg_split(int nrows, const int *__restrict__ rowptr,
            const double *__restrict__ xa, int nsplit,
            const double *__restrict__ xb, const double *__restrict__ dinv,
            const double *__restrict__ b, double omega,
-           double *__restrict__ out, const int *__restrict__ guard) {
+           double *__restrict__ out, const int *__restrict__ guard,
+           int row0 = 0) {
+    // row0: as in k_mg_sweep
     if (guard && *guard) return;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = sub; row < nrows; row += nsub) {
-        const int k1 = rowptr[row + 1];
-        int k = rowptr[row] + sublane;
+    for (int li = sub; li < nrows; li += nsub) {
+        const int row = row0 + li;
+        const int k1 = rowptr[li + 1];
+        int k = rowptr[li] + sublane;
         // (the row's own addend does not depend on the gather chain)
         const double add =
             (dinv && sublane == 0) ? omega * dinv[row] * b[row] : 0.0;

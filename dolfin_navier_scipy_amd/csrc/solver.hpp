@@ -377,6 +377,13 @@ struct dns_saddle {
                                       // caller's prologue kernel has written
     bool mg_fused = false;            // the V-cycle runs on the fused operators
     bool mg_fused_knob = true;        // DNS_MG_FUSED (read once, at create)
+    int mg_part_min = 100000;         // levels with at least this many rows are
+                                      // row-partitioned over the ranks
+                                      // (DNS_MG_PART_MIN), smaller ones run
+                                      // replicated
+    int mg_nparts = 0;                // how many levels are partitioned
+    int setup_dist_mg();
+    int schur_mg_apply_dist(const double *in, double *zp, const int *guard);
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
     bool capturing = false;           // a run_cached capture is open
@@ -391,6 +398,17 @@ struct dns_saddle {
         //   Qq   = [T, T P]           x' = Qq [x_pre; e] + c(b)
         //                                            (prolongation + first sweep)
         dns::CsrDev Apre, Rr, Qq;
+        // host copies (kept while a communicator is attached: the row blocks
+        // of a partitioned cycle are cut from them, dist_solve.inc)
+        dns::HostCsr Sh, Apreh, Rrh, Qqh;
+        // row-partitioned level: rows [r0, r1) of this level's operators
+        // (Rr: rows [c0, c1) of the next level), halo plans of the level's
+        // vectors (planF) and of the next level's correction (planC)
+        bool part = false;
+        int64_t nnz_S = 0, nnz_P = 0;     // sizes of the whole S and P
+        std::vector<int> st;              // block partition of the rows
+        dns_halo_plan planF, planC;
+        bool coarse_replicated = true;    // level l+1 is not partitioned
         dns::DevBuf<double> dinv, x, b, r, x2;
     };
     std::deque<MgLevel> mg;               // (device buffers do not move)

@@ -68,6 +68,30 @@ def _mg_problem():
                 prols=prols)
 
 
+def _mg3_problem():
+    """the toy mesh refined twice: three multigrid levels once the dense
+    coarsest level is capped at 300 dofs (DNS_MG_DENSE_MAX)"""
+    from dolfin_navier_scipy_amd.fem import (
+        get_sysmats, channel_cylinder_mesh, refine_uniform, TaylorHood,
+        pressure_prolongations)
+    coarse = channel_cylinder_mesh()
+    mid, par1 = refine_uniform(coarse)
+    fine, par2 = refine_uniform(mid)
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N='toy', Re=40.,
+                                 mesh=fine)
+    prols = pressure_prolongations(
+        [femp['V'], TaylorHood(mid), TaylorHood(coarse)], [par2, par1, None])
+    M, A, J = sm['M'], sm['A'], sm['J']
+    dt = 2.5e-3
+    rng = np.random.default_rng(11)
+    NP, NV = J.shape
+    return dict(M=M, A=A, J=J, F=(M + .5*dt*A).tocsr(),
+                R1=(M - .5*dt*A).tocsr(), rhsv=M @ rng.standard_normal(NV),
+                rhsp=1e-3*(J @ rng.standard_normal(NV)), dt=dt,
+                v0=rng.standard_normal(NV), nfc=M @ rng.standard_normal(NV),
+                prols=prols)
+
+
 def _cyl3_problem():
     """config 4: cylinder wake on `cylinder_3`, Re=40, dt = 0.5/256
     (`tests/time_dep_nse_krylov.py:52`)"""
@@ -85,10 +109,31 @@ def _cyl3_problem():
 
 
 def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
-    mgs = fhat == 'mg'
+    # 'mgpart' / 'mg3part': the multigrid levels row-partitioned too (every
+    # level but the dense coarsest one; the knobs are read when the handle is
+    # created)
+    knobs = {}
+    if fhat in ('mgpart', 'mg3part'):
+        knobs['DNS_MG_PART_MIN'] = '0'
+    if fhat in ('mg3', 'mg3part'):
+        knobs['DNS_MG_DENSE_MAX'] = '300'
+    if fhat in ('mg', 'mgpart'):
+        knobs['DNS_MG_DENSE_MAX'] = '100'      # (two levels at least)
+    three = fhat in ('mg3', 'mg3part')
+    mgs = fhat in ('mg', 'mgpart', 'mg3', 'mg3part')
     cyl3 = fhat == 'cyl3'
-    pr = _mg_problem() if mgs else (_cyl3_problem() if cyl3 else _problem())
-    system = sad.SaddleSystem(pr['F'], pr['J'])
+    pr = (_mg3_problem() if three else _mg_problem()) if mgs else (
+        _cyl3_problem() if cyl3 else _problem())
+    saved = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        system = sad.SaddleSystem(pr['F'], pr['J'])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     if comm is not None:
         system.set_comm(comm)
     if cyl3:
@@ -104,6 +149,7 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
                          factorization=fact, drop_tol=1e-3 if cyl3 else None)
     if info is not None:
         info['matrix_bytes'] = system.device_matrix_bytes()
+        info['precond'] = system.precond_info()
     x = system.solve(pr['rhsv'], pr['rhsp'], rtol=1e-12, reorth=reorth)
     stats = dict(system.last_stats)
     # a few device-resident CNAB steps through the same communicator
@@ -133,6 +179,10 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
         cvop.close()
     system.close()
     return x, stats, v, p
+
+
+def system_levels(info):
+    return info['precond'].get('mg_levels', [])
 
 
 def test_rccl_world_size_one_equals_plain_solve():
@@ -171,6 +221,7 @@ def _worker(rank, world, port, outdir):
     cm = dcomm.Comm.gloo(0)
     out = {}
     for fhat, reorth in (('explicit', False), ('full', False), ('mg', False),
+                         ('mgpart', False), ('mg3', False), ('mg3part', False),
                          ('cyl3', False)):
         info = {}
         before = cm.stats()
@@ -222,6 +273,31 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
     assert np.linalg.norm(r0['mg_0'] - xm) <= 1e-9*np.linalg.norm(xm)
     assert np.linalg.norm(r0['mg_1'] - vm) <= 1e-9*np.linalg.norm(vm)
     assert abs(int(r0['mg_3']) - stm['iters']) <= 1
+    # the multigrid levels row-partitioned as well: the same iterates, and the
+    # level operators are stored by row blocks
+    info3 = {}
+    x3, st3, v3, p3 = _solve_and_step(saddle, None, 'mg3', False, info=info3)
+    for key, (xr, vr, strf) in (('mgpart', (xm, vm, stm)),
+                                ('mg3part', (x3, v3, st3))):
+        assert np.array_equal(r0[key + '_0'], r1[key + '_0'])
+        assert float(r0[key + '_4']) <= 5e-12
+        assert np.linalg.norm(r0[key + '_0'] - xr) <= 1e-9*np.linalg.norm(xr)
+        assert np.linalg.norm(r0[key + '_1'] - vr) <= 1e-9*np.linalg.norm(vr)
+        assert abs(int(r0[key + '_3']) - strf['iters']) <= 1
+    assert len(system_levels(info3)) >= 3
+    # (the partitioned cycle exchanges halos per level: more exchanges than the
+    # replicated one, fewer bytes of matrices)
+    for a, b in (('mg', 'mgpart'), ('mg3', 'mg3part')):
+        assert int(r0[b + '_7']) > int(r0[a + '_7']), (a, b)
+        assert int(r0[b + '_5']) < int(r0[a + '_5']), (a, b)
+    print('multigrid over 2 ranks: matrix bytes per rank, replicated cycle',
+          int(r0['mg3_5']), 'partitioned', int(r0['mg3part_5']), 'serial',
+          info3['matrix_bytes'], '; halo exchanges', int(r0['mg3_7']), '->',
+          int(r0['mg3part_7']), '; levels',
+          [lv['n'] for lv in system_levels(info3)])
+    for rr in (r0, r1):
+        assert int(rr['mg3part_5']) < 0.62*info3['matrix_bytes'], \
+            (int(rr['mg3part_5']), info3['matrix_bytes'])
     # the full block factorisation is partitioned too (one more all-gather
     # per apply) and needs the same few steps as on one GPU
     assert abs(int(r0['full_3']) - stf['iters']) <= 3
