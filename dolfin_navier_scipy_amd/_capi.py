@@ -184,6 +184,10 @@ SIGNATURES = {
     'dns_trap_set_rhs': (ct.c_int, [ct.c_void_p, c_double_p, c_double_p]),
     'dns_trap_traj_write': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32,
                                        c_double_p]),
+    'dns_trap_traj_export_async': (ct.c_int, [ct.c_void_p, ct.c_int32,
+                                              ct.c_int32, ct.c_int32,
+                                              c_double_p]),
+    'dns_trap_traj_export_wait': (ct.c_int, [ct.c_void_p]),
     'dns_trap_traj_read': (ct.c_int, [ct.c_void_p, ct.c_int32, ct.c_int32,
                                       c_double_p]),
     'dns_trap_start': (ct.c_int, [ct.c_void_p, c_double_p, ct.c_int32]),

@@ -11,6 +11,7 @@
 // two trajectory buffers (nslots x NV each) in HBM -- they replace the
 // per-time-step .npy files of the reference (snu:1012-1014, 1424-1431).
 #pragma once
+#include <mutex>
 #include "convection.hpp"
 #include "solver.hpp"
 
@@ -85,6 +86,17 @@ struct dns_trap {
     int nsol = 0;
     dns::DevBuf<double> fv, fp, fvn_c, fvn_n, rhsbc, rhscon, b, dtmp, mtmp;
     dns::DevBuf<double> traj[2];
+    // asynchronous export of trajectory slots to the host (the "async writer"
+    // of SURVEY 8f4): a copy stream of its own; the solver's stream only
+    // waits for a pending export before it overwrites the exported buffer
+    struct Export {
+        hipStream_t cstream = nullptr;
+        hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
+        bool pending[2] = {false, false};
+        std::vector<void *> pinned;
+        std::mutex mu;
+    } exp_;
+    int export_fence(int which);   // solver stream waits for a pending export
     double updnorm = 0.0;                      // sum dt ||v_n - v_lin||_M^2
     dns::DevBuf<double> updnorm_dev;           // ... its part still on the device
     int pipeline_c = 0;                        // > 0: steps do not synchronise

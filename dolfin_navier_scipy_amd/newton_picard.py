@@ -144,6 +144,39 @@ class TrapezoidalStepper(object):
         C.check(self.lib.dns_trap_traj_read(self._h, which, slot, C.dptr(out)))
         return out.reshape((-1, 1))
 
+    def export_async(self, which, slot0=0, count=None):
+        """queue the copy of trajectory slots to the host on a copy stream of
+        its own and return the (not yet filled) `count x NV` array; the next
+        sweep may be started at once.  `export_wait()` before reading it."""
+        count = self.nslots - slot0 if count is None else count
+        out = np.empty((count, self.NV))
+        C.check(self.lib.dns_trap_traj_export_async(self._h, which, slot0,
+                                                    count, C.dptr(out)))
+        self._exports = getattr(self, '_exports', []) + [out]   # keep alive
+        return out
+
+    def export_wait(self):
+        C.check(self.lib.dns_trap_traj_export_wait(self._h))
+        self._exports = []
+
+    def save_trajectory_async(self, which, times, namer, slot0=0):
+        """the asynchronous writer of the trajectory store: what the
+        reference does with a blocking `dou.save_npa` per time step
+        (snu:1012-1014, 1424-1431).  Queues the export of the slots of `times`
+        and hands the waiting + `np.save(namer(t), v_t)` to a background
+        thread; returns the thread (`join()` it before the files are used)."""
+        import threading
+        times = list(times)
+        arr = self.export_async(which, slot0, len(times))
+
+        def work():
+            C.check(self.lib.dns_trap_traj_export_wait(self._h))
+            for k, t in enumerate(times):
+                np.save(namer(t), arr[k].reshape((-1, 1)))
+        th = threading.Thread(target=work, name='dns-traj-writer')
+        th.start()
+        return th
+
     def start(self, iniv, newton):
         v = C.as_f64(iniv, self.NV)
         C.check(self.lib.dns_trap_start(self._h, C.dptr(v), int(bool(newton))))

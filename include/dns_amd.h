@@ -441,6 +441,18 @@ int dns_trap_set_rhs(dns_trap *t, const double *fv, const double *fp);
 int dns_trap_traj_write(dns_trap *t, int32_t which, int32_t slot,
                         const double *v);
 int dns_trap_traj_read(dns_trap *t, int32_t which, int32_t slot, double *v);
+/* Asynchronous writer of the trajectory store (replaces the
+ * blocking per-step `dou.save_npa`, reference snu:1012-1014, 1424-1431): the
+ * copy of the slots [slot0, slot0+count) of traj[which] into `host` (count*NV
+ * doubles, page-locked by the call) is queued on a copy stream of its own
+ * behind the work the solver's stream has been given so far; the call returns
+ * at once and the next sweep runs while the data travels.  The solver's stream
+ * waits for a pending export only before it overwrites traj[which].
+ * dns_trap_traj_export_wait blocks until all exports have arrived and releases
+ * the page locks; any host thread may call it. */
+int dns_trap_traj_export_async(dns_trap *t, int32_t which, int32_t slot0,
+                               int32_t count, double *host);
+int dns_trap_traj_export_wait(dns_trap *t);
 int dns_trap_start(dns_trap *t, const double *iniv, int32_t newton);
 int dns_trap_step(dns_trap *t, double dt, int32_t lin_which, int32_t lin_slot,
                   int32_t out_slot, int32_t newton, int32_t extrapolate_x0,

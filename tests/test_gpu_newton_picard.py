@@ -137,6 +137,74 @@ def test_device_sweep_matches_oracle(setup, cvop, picard):
     stp.close()
 
 
+def test_async_trajectory_writer(setup, cvop, tmp_path):
+    """the trajectory of a sweep travels to the host (and to
+    `.npy` files, what `dou.save_npa` writes per step in the reference,
+    snu:1012-1014) on a copy stream of its own while the NEXT sweep runs; the
+    solver's stream only waits before it overwrites the exported buffer"""
+    from dolfin_navier_scipy_amd import newton_picard as dnp, saddle
+    s = setup
+    tr = s['trange']
+    stp = dnp.TrapezoidalStepper(s['M'], s['A'], s['J'], cvop, nslots=tr.size,
+                                 dt=tr[1] - tr[0], precond=dict(cheb_degree=4))
+    stp.set_rhs(s['fv'], s['fp'])
+    for k, t in enumerate(tr):
+        stp.write_linpoint(0, k, s['lin0'][t])
+    opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True)
+    v1, _, _, _ = stp.sweep(tr, s['iniv'], 0, True, opts=opts)   # -> traj[1]
+    names = {t: str(tmp_path / 'v_{0:.6f}.npy'.format(t)) for t in tr}
+    writer = stp.save_trajectory_async(1, tr[1:], lambda t: names[t], slot0=1)
+    host = stp.export_async(1)                     # a second export, in memory
+    # the next sweep linearises about traj[1] and writes traj[0]: it runs while
+    # the exports are in flight; the one after it writes traj[1] and has to
+    # wait for them
+    v2, _, _, _ = stp.sweep(tr, s['iniv'], 1, False, opts=opts)
+    v3, _, _, _ = stp.sweep(tr, s['iniv'], 0, False, opts=opts)
+    writer.join()
+    stp.export_wait()
+    for k, t in enumerate(tr):
+        if k == 0:
+            continue
+        assert np.array_equal(np.load(names[t]), v1[t])
+        assert np.array_equal(host[k].reshape((-1, 1)), v1[t])
+    # ... and the sweeps were not disturbed
+    assert np.allclose(stp.read_traj(1, tr.size - 1), v3[tr[-1]])
+    assert not np.array_equal(v3[tr[-1]], v1[tr[-1]])
+    stp.close()
+
+
+def test_conv_kat_at_full_size():
+    """`N(u)u == N1(u) u == N2(u) u` (tests/test_units_fenicsci.py:84-85) and
+    the device convection vector against the host assembly on the cylinder
+    mesh of BASELINE config 2 (N=2, NV=9356), not only on the toy mesh"""
+    from dolfin_navier_scipy_amd import convection, newton_picard as dnp
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=100.)
+    th, inv = femp['V'], femp['invinds']
+    NV = inv.size
+    cv = convection.ConvectionP2.from_taylor_hood(
+        th, inv, femp['dbcinds'], femp['dbcvals'])
+    rng = np.random.default_rng(21)
+    u = rng.standard_normal((NV, 1))
+    # vector against the host assembly (with the inflow data)
+    full = np.zeros((th.vdim, 1))
+    full[inv] = u
+    full[femp['dbcinds'], 0] = femp['dbcvals']
+    ref = th.convection_vec(full)[inv, :]
+    got = cv.apply(u, scale=1.0)
+    assert np.abs(got - ref).max() <= 1e-12*np.abs(ref).max()
+    # the reference's KAT (homogeneous data: the identity holds on the full
+    # space only)
+    cv.set_dbcvals(0*np.asarray(femp['dbcvals'], dtype=float))
+    cv.bind_pattern(dnp.union_pattern(cv.connectivity()))
+    N1, _, nuu = cv.assemble(u, newton=False)
+    N12, _, _ = cv.assemble(u, newton=True)
+    scale = np.abs(nuu).max()
+    assert np.abs(N1 @ u - nuu).max() <= 1e-12*scale
+    assert np.abs((N12 - N1) @ u - nuu).max() <= 1e-12*scale
+    cv.close()
+
+
 def test_device_newton_picard_driver_matches_oracle(setup, cvop):
     from dolfin_navier_scipy_amd import newton_picard as dnp, saddle
     s = setup
