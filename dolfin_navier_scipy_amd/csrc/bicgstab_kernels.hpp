@@ -75,7 +75,8 @@ k_bicg_start(int n, const double *__restrict__ r, double *__restrict__ rhat,
         ctl->total_it = 0;
         ctl->status = DNS_OK;
         ctl->done = !(beta > tol) ? 1 : 0;
-        ctl->conv = !(beta > tol) ? 1 : 0;
+        ctl->conv = (beta <= tol) ? 1 : 0;
+        if (isnan(beta) || isnan(tol)) ctl->status = DNS_BREAKDOWN;
         ctl->hist_len = 0;
         bc->sc[0].rho = bc->sc[0].alpha = bc->sc[0].omega = 1.0;
         bc->sc[1] = bc->sc[0];
@@ -99,7 +100,7 @@ k_bicg_p(int n, const double *__restrict__ r, double *__restrict__ p,
     const double resn = sqrt(sc[1]);
     const BicgScal o = bc->sc[par];
     const int it = ctl->total_it;
-    const bool conv = !(resn > ctl->tol);
+    const bool conv = resn <= ctl->tol;
     const bool brk = (rho_new == 0.0) || isnan(rho_new) || isnan(resn);
     const bool stop = conv || brk || it >= maxiter;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -124,7 +125,7 @@ k_bicg_p(int n, const double *__restrict__ r, double *__restrict__ p,
 // in its own launch)
 __global__ void k_bicg_flag(DnsCtl *ctl, int maxiter) {
     if (threadIdx.x != 0 || blockIdx.x != 0 || ctl->done) return;
-    const bool conv = !(ctl->resnorm > ctl->tol);
+    const bool conv = ctl->resnorm <= ctl->tol;
     if (conv || ctl->status != DNS_OK || ctl->total_it >= maxiter ||
         isnan(ctl->resnorm))
         ctl->done = 1;

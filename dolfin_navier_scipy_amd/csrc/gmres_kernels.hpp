@@ -99,7 +99,9 @@ __device__ inline void givens_close(DnsCtl *ctl, int j, double hn,
     ctl->hist[j + 1] = res;
     ctl->jdone = j + 1;
     ctl->total_it += 1;
-    const bool conv = !(res > ctl->tol);
+    // (a NaN is never "converged": it ends the solve as a breakdown)
+    const bool conv = res <= ctl->tol;
+    if (isnan(res) && status == DNS_OK) status = DNS_BREAKDOWN;
     if (status != DNS_OK) ctl->status = status;
     if (conv) ctl->conv = 1;
     if (conv || status != DNS_OK || !(hn > 0.0) || isnan(res) ||
@@ -224,7 +226,8 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
             ctl->tol = tol;
             ctl->g[0] = hn;
             ctl->hist[0] = hn;
-            if (!(hn > tol)) ctl->conv = 1;
+            if (hn <= tol) ctl->conv = 1;
+            if (isnan(hn) || isnan(tol)) ctl->status = DNS_BREAKDOWN;
             ctl->done = stop ? 1 : 0;
         } else {
             givens_close(ctl, j - 1, hn, maxiter);
@@ -455,7 +458,7 @@ k_tau_guard(int np, int nv, const int *__restrict__ rowptr,
                     lo = -ctl->sn[i] * lo + ctl->cs[i] * h[i + 1];
                 const double den = hypot(lo, hn);
                 const double sn = den > 0.0 ? hn / den : 0.0;
-                v = !(fabs(sn * ctl->g[j - 1]) > ctl->tol);
+                v = fabs(sn * ctl->g[j - 1]) <= ctl->tol;
             }
             verdict = v;
             if (blockIdx.x == 0) ctl->predone = v;
@@ -747,7 +750,8 @@ k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
                 res = fabs(gl[1]);
                 jcols = j + 1;
                 tot += 1;
-                conv = !(res > ctl->tol);
+                conv = res <= ctl->tol;
+                if (isnan(res)) status = DNS_BREAKDOWN;
                 closed = true;
             }
         }

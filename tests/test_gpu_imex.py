@@ -207,3 +207,34 @@ def test_run_reports_unconverged_steps(gtiu, toy_prob):
     assert last['status'] == _capi.DNS_NOT_CONVERGED
     stp.close()
     system.close()
+
+
+def test_nan_state_is_a_breakdown_not_a_converged_step(gtiu, toy_prob):
+    """a blown-up state (NaN residual norm) must end the run with an error:
+    `!(norm > tol)` is true for a NaN, so a careless convergence test would
+    report such steps as converged in zero Krylov steps"""
+    from dolfin_navier_scipy_amd import saddle, _capi
+    M, A, J = (toy_prob['smc'][k] for k in 'MAJ')
+    NP, NV = J.shape
+    dt = 5e-3
+    rng = np.random.default_rng(5)
+    system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    system.setup_precond(cheb_degree=4, schur='dense', factorization='full')
+    stp = saddle.ImexStepper(system, (M - .5*dt*A).tocsr())
+    v0 = rng.standard_normal(NV)
+    v0[NV//2] = np.nan
+    stp.set_state(v0)
+    stp.set_rhs(M @ rng.standard_normal(NV), 1e-2*rng.standard_normal(NP))
+    cf = saddle.ImexStepper.coeffs(a_c=1., pscale=-1./dt, extrapolate=4)
+    for graph in (False, True):
+        opts = saddle.solve_opts(rtol=1e-10, maxiter=50, use_graph=graph,
+                                 reorth=2)
+        with pytest.raises(_capi.DnsError):
+            stp.run(12, cf, opts)
+    # a plain solve with a NaN right-hand side likewise
+    b = M @ rng.standard_normal(NV)
+    b[3] = np.nan
+    with pytest.raises(_capi.DnsError):
+        system.solve(b, rtol=1e-10)
+    stp.close()
+    system.close()
