@@ -1933,11 +1933,26 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
                                            h->gridS, 1 << 30, 0, np, 0,
                                            (const double *)nullptr,
                                            (int *)nullptr, h->sld);
-                    else
+                    else if (dense)
                         hipLaunchKernelGGL(k_arn_head<1>, gridA, kBlock, 0, s, n,
                                            nv, np, j, h->w.p, h->partN.p,
                                            h->gridD, h->V.p, h->ld,
                                            (const void *)h->sinv.p, zp,
+                                           h->ctl.p, 1e-10, 0.0, h->partB.p,
+                                           h->gridS, 1 << 30, 0, np, 0, (const double *)nullptr);
+                    else if (h->popts.schur == DNS_SCHUR_JACOBI)
+                        // (sinv is the DIAGONAL here: np entries)
+                        hipLaunchKernelGGL(k_arn_head<0>, gridA, kBlock, 0, s, n,
+                                           nv, np, j, h->w.p, h->partN.p,
+                                           h->gridD, h->V.p, h->ld,
+                                           (const void *)h->sinv.p, zp,
+                                           h->ctl.p, 1e-10, 0.0, h->partB.p,
+                                           h->gridS, 1 << 30, 0, np, 0, (const double *)nullptr);
+                    else
+                        hipLaunchKernelGGL(k_arn_head<3>, gridA, kBlock, 0, s, n,
+                                           nv, np, j, h->w.p, h->partN.p,
+                                           h->gridD, h->V.p, h->ld,
+                                           (const void *)nullptr, zp,
                                            h->ctl.p, 1e-10, 0.0, h->partB.p,
                                            h->gridS, 1 << 30, 0, np, 0, (const double *)nullptr);
                     break;
