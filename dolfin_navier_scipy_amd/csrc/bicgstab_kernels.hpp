@@ -276,137 +276,6 @@ k_imex_bvec(int nv, int np, const double *__restrict__ v_c,
     }
 }
 
-// ---------------------------------------------------------------------------
-// Whole prologue of a resident IMEX step in ONE launch (row-parallel over the
-// n rows of K; replaces gather + k_imex_rhs + k_lincomb* + k_resid_norm):
-//   nfc_c = scale * (convection gather)            [if a device operator is on]
-//   b_v   = R1 (a_c v_c + a_p v_p) + cn_c nfc_c + cn_o nfc_o + g ;  b_p = gp
-//   x0    = e_c x_c + e_p x_p + e_pp x_pp + e_p3 x_p3 + e_p4 x_p4   (warm start)
-//   r     = b - K x0 ,  partials of ||r||^2 and ||b||^2
-// K x0 is formed from the history vectors directly (x0 of other rows is not
-// available inside the launch): up to three gathers per non-zero.
-// ---------------------------------------------------------------------------
-template <int LPR>
-__global__ void __launch_bounds__(kBlock)
-k_step_prologue(int n, int nv, const int *__restrict__ k_rowptr,
-                const int *__restrict__ k_colidx,
-                const double *__restrict__ k_vals,
-                const int *__restrict__ r_rowptr,
-                const int *__restrict__ r_colidx,
-                const double *__restrict__ r_vals,
-                const double *__restrict__ x_c, const double *__restrict__ x_p,
-                const double *__restrict__ x_pp,
-                const double *__restrict__ x_p3,
-                const double *__restrict__ x_p4, double e_c, double e_p,
-                double e_pp, double e_p3, double e_p4, double a_c, double a_p,
-                double *__restrict__ nfc_c, const double *__restrict__ nfc_o,
-                double cn_c, double cn_o, TabRef gtab, TabRef gptab,
-                const int *__restrict__ gptr, const int *__restrict__ gidx,
-                const double *__restrict__ cellvals, double conv_scale,
-                double *__restrict__ b, double *__restrict__ x0,
-                double *__restrict__ r, double *__restrict__ part_rr,
-                double *__restrict__ part_bb) {
-    __shared__ double red[4];
-    const double *__restrict__ g = tab_row(gtab);
-    const double *__restrict__ gp = tab_row(gptab);
-    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
-    const int sublane = threadIdx.x % LPR;
-    const int nsub = gridDim.x * (kBlock / LPR);
-    double arr = 0.0, abb = 0.0;
-    for (int row = sub; row < n; row += nsub) {
-        // three independent gather chains (K x0, R1 v, convection list): the
-        // first pass of each is issued level by level -- row pointers, then
-        // indices, then values -- so that the dependent-load latency is paid
-        // three times per row, not nine; longer rows finish in the loops below
-        const bool isv = row < nv;
-        const bool hasg = isv && gptr != nullptr;
-        int kk = k_rowptr[row] + sublane;
-        const int kend = k_rowptr[row + 1];
-        int rk = 0, rend = 0, gk = 0, gend = 0;
-        if (isv) {
-            rk = r_rowptr[row] + sublane;
-            rend = r_rowptr[row + 1];
-        }
-        if (hasg) {
-            gk = gptr[row] + sublane;
-            gend = gptr[row + 1];
-        }
-        const bool k_on = kk < kend, r_on = rk < rend, g_on = gk < gend;
-        int kc = 0, rc = 0, gi = 0;
-        double kval = 0.0, rval = 0.0;
-        if (k_on) {
-            kc = k_colidx[kk];
-            kval = k_vals[kk];
-        }
-        if (r_on) {
-            rc = r_colidx[rk];
-            rval = r_vals[rk];
-        }
-        if (g_on) gi = gidx[gk];
-        double kx = 0.0, rs = 0.0, cvs = 0.0;
-        if (k_on) {
-            double xv = e_c * x_c[kc];
-            if (e_p != 0.0) xv = fma(e_p, x_p[kc], xv);
-            if (e_pp != 0.0) xv = fma(e_pp, x_pp[kc], xv);
-            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[kc], xv);
-            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[kc], xv);
-            kx = kval * xv;
-        }
-        if (r_on) {
-            double vv = a_c * x_c[rc];
-            if (a_p != 0.0) vv = fma(a_p, x_p[rc], vv);
-            rs = rval * vv;
-        }
-        if (g_on) cvs = cellvals[gi];
-        for (kk += LPR; kk < kend; kk += LPR) {
-            const int c = k_colidx[kk];
-            double xv = e_c * x_c[c];
-            if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
-            if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
-            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[c], xv);
-            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[c], xv);
-            kx = fma(k_vals[kk], xv, kx);
-        }
-        for (rk += LPR; rk < rend; rk += LPR) {
-            const int c = r_colidx[rk];
-            double vv = a_c * x_c[c];
-            if (a_p != 0.0) vv = fma(a_p, x_p[c], vv);
-            rs = fma(r_vals[rk], vv, rs);
-        }
-        for (gk += LPR; gk < gend; gk += LPR) cvs += cellvals[gidx[gk]];
-        kx = subwave_sum<LPR>(kx);
-        rs = subwave_sum<LPR>(rs);
-        if (gptr) cvs = subwave_sum<LPR>(cvs);
-        if (sublane == 0) {
-            double bv;
-            if (row < nv) {
-                double nc = gptr ? conv_scale * cvs : nfc_c[row];
-                if (gptr) nfc_c[row] = nc;
-                bv = rs + cn_c * nc + cn_o * nfc_o[row] + g[row];
-            } else {
-                bv = gp[row - nv];
-            }
-            double xv = e_c * x_c[row];
-            if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
-            if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
-            if (e_p3 != 0.0) xv = fma(e_p3, x_p3[row], xv);
-            if (e_p4 != 0.0) xv = fma(e_p4, x_p4[row], xv);
-            const double rv = bv - kx;
-            b[row] = bv;
-            x0[row] = xv;
-            r[row] = rv;
-            arr = fma(rv, rv, arr);
-            abb = fma(bv, bv, abb);
-        }
-    }
-    arr = block_sum(arr, red);
-    abb = block_sum(abb, red);
-    if (threadIdx.x == 0) {
-        part_rr[blockIdx.x] = arr;
-        part_bb[blockIdx.x] = abb;
-    }
-}
-
 // x0 = e_c * x_c + e_p * x_p   (warm start, `krylovini='upd'` snu:1496-1501)
 __global__ void __launch_bounds__(kBlock)
 k_lincomb2(int n, double e_c, const double *__restrict__ x_c, double e_p,

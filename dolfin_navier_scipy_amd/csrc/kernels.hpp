@@ -657,26 +657,6 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
     }
 }
 
-// partials of ||r||^2 and ||b||^2 (one per workgroup each)
-__global__ void __launch_bounds__(kBlock)
-k_norm2_pair(int n, const double *__restrict__ r, const double *__restrict__ b,
-             double *__restrict__ part_rr, double *__restrict__ part_bb) {
-    __shared__ double red[4];
-    double a = 0.0, c = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n;
-         i += gridDim.x * kBlock) {
-        const double rv = r[i], bv = b[i];
-        a = fma(rv, rv, a);
-        c = fma(bv, bv, c);
-    }
-    a = block_sum(a, red);
-    c = block_sum(c, red);
-    if (threadIdx.x == 0) {
-        part_rr[blockIdx.x] = a;
-        if (part_bb) part_bb[blockIdx.x] = c;
-    }
-}
-
 // ---------------------------------------------------------------------------
 // vector kernels
 // ---------------------------------------------------------------------------
@@ -1223,18 +1203,6 @@ k_stream_triad(int64_t n2, const dns_double2 *__restrict__ a,
         r.y = fma(sc, v.y, u.y);
         c[i] = r;
     }
-}
-
-// xcat = [a[0..n1) ; b[0..n2)]  (input vector of the explicit Fh^-1 matrix
-// Gc = [G, -G JT] when it runs through the streaming kernel)
-__global__ void __launch_bounds__(kBlock)
-k_pack2(int n1, const double *__restrict__ a, int n2,
-        const double *__restrict__ b, double *__restrict__ out,
-        const int *__restrict__ guard) {
-    if (guard && *guard) return;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n1 + n2;
-         i += gridDim.x * kBlock)
-        out[i] = (i < n1) ? a[i] : b[i - n1];
 }
 
 // zp = -x (and xacc += zp) unless the guard is raised

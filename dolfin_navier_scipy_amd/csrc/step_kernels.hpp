@@ -8,7 +8,7 @@
 //   k_step_back  : nfc_c = scale * gather(cell values);  b = rs + cn_c nfc_c +
 //                  cn_o nfc_o + g;  r = b - kx;  partials of ||r||^2, ||b||^2
 //
-// Before (k_conv_cells -> k_step_prologue) the three gather chains of the
+// Before (k_conv_cells -> one prologue kernel) the three gather chains of the
 // prologue -- 12.2 us of the ~53 us step -- waited for the 5.8 us element
 // kernel although only the (short) convection gather depends on it.
 #pragma once
