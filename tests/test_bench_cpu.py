@@ -1,0 +1,99 @@
+"""Host logic of `bench.py` and of the published op list (`perfmodel.py`):
+what can be checked without a GPU."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench                                             # noqa: E402
+from dolfin_navier_scipy_amd import perfmodel            # noqa: E402
+
+
+def test_weak_ladder_keeps_rows_per_rank_about_constant():
+    """N > 1 headline: the mesh grows with the ranks"""
+    assert bench.weak_ladder(1) == (2, 0)
+    assert bench.weak_ladder(2) == (3, 0)
+    assert bench.weak_ladder(4) == (2, 1)
+    assert bench.weak_ladder(8) == (3, 1)
+    rel = dict(bench.WEAK_LADDER)
+    for world in (1, 2, 3, 4, 6, 8):
+        per_rank = rel[bench.weak_ladder(world)]/world
+        assert 0.6 <= per_rank <= 1.5, (world, per_rank)
+
+
+def test_child_env_drops_the_launcher_agent_store(monkeypatch):
+    """a child run hosts its own rendezvous store: with
+    TORCHELASTIC_USE_AGENT_STORE in its environment rank 0 would wait for the
+    launcher's agent on a port nobody serves (the round-1 rehearsal hung on
+    exactly this)"""
+    monkeypatch.setenv('TORCHELASTIC_USE_AGENT_STORE', 'True')
+    monkeypatch.setenv('TORCHELASTIC_RUN_ID', 'x')
+    monkeypatch.setenv('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    monkeypatch.setenv('RANK', '3')
+    env = bench.child_env(MASTER_PORT=29517, MASTER_ADDR='127.0.0.1')
+    assert not [k for k in env if k.startswith('TORCHELASTIC_')]
+    assert env['MASTER_PORT'] == '29517' and env['MASTER_ADDR'] == '127.0.0.1'
+    assert env['RANK'] == '3' and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
+def test_run_child_reports_results_failures_and_time_limits():
+    py = sys.executable
+    ok = bench.run_child([py, '-c', 'print("noise"); print(\'{"a": 1}\')'],
+                         dict(os.environ), 30., True)
+    assert ok == {'a': 1}
+    bad = bench.run_child([py, '-c', 'import sys; sys.exit(3)'],
+                          dict(os.environ), 30., True)
+    assert 'error' in bad and 'code 3' in bad['error']
+    quiet = bench.run_child([py, '-c', 'pass'], dict(os.environ), 30., False)
+    assert quiet is None
+    slow = bench.run_child([py, '-c', 'import time; time.sleep(60)'],
+                           dict(os.environ), 1., True)
+    assert 'error' in slow and 'killed' in slow['error']
+
+
+def _info(schur='dense'):
+    info = dict(NV=9356, NP=1289, nnz_K=300000, nnz_Gc=1100000, nnz_JG=350000,
+                nnz_F=215000, nnz_J=43000, fp32_store=True, cheb_degree=6,
+                schur=schur, mg_nu=2, mg_levels=[])
+    if schur == 'mg':
+        info['mg_levels'] = [dict(n=1289, nnz_S=90000, nnz_P=5000),
+                             dict(n=340, nnz_S=0, nnz_P=0)]
+    return info
+
+
+@pytest.mark.parametrize('schur', ['dense', 'mg'])
+def test_step_roofline_is_the_sum_of_its_published_ops(schur):
+    info = _info(schur)
+    roof = perfmodel.step_roofline(info, nnz_R1=215000, ncells=4600,
+                                   iters=1.5, ms_per_step=0.05)
+    total = sum(op['count']*op['bytes'] for op in roof['ops'])
+    assert abs(total - roof['bytes_per_step']) <= 1e-6*total
+    assert abs(roof['achieved'] - total/0.05e-3/1e9) <= 1e-6*roof['achieved']
+    assert abs(roof['frac'] - roof['achieved']/8000.) <= 1e-12
+    # CSR SpMV = 12 nnz + 4 (r+1) + 8 c + 8 r
+    assert perfmodel.spmv_bytes(10, 4, 5) == 120 + 20 + 40 + 32
+    # what the kernels move (fp32 Gc) is less than the fp64 / int32 op list
+    assert roof['bytes_moved_estimate'] < roof['bytes_per_step']
+    # one more Krylov step costs exactly the ops of that step
+    more = perfmodel.step_roofline(info, 215000, 4600, 2.5, 0.05)
+    extra = sum(c*b for _, c, b in perfmodel.krylov_iteration_ops(info, 2))
+    n = info['NV'] + info['NP']
+    assert abs(more['bytes_per_step'] - roof['bytes_per_step']
+               - 0.5*sum(c*b for _, c, b in
+                         perfmodel.krylov_iteration_ops(info, 1))
+               - 0.5*extra
+               - 8*n*1.0            # (x = x0 + Z y reads one more Z_j)
+               ) <= 1e-6*total
+
+
+def test_spmv_bytes_of_the_bench_match_the_model():
+    import scipy.sparse as sps
+    A = sps.random(50, 40, density=0.1, format='csr', random_state=1)
+    assert bench.spmv_bytes(A) == perfmodel.spmv_bytes(A.nnz, 50, 40)
