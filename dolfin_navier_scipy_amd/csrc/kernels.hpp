@@ -437,7 +437,8 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 int col = ((e[i] & 0x8000) ? bhi : blo) + (e[i] & 0x7fff);
-                if (DIAG) col = r0 + (i & 7);
+                if (DIAG == 3) col &= 1023;       // gather from an 8 KB range
+                else if (DIAG) col = r0 + (i & 7);
                 xv[i] = x[col];
             }
 #pragma unroll

@@ -157,7 +157,15 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
                        hipStream_t s, const int *guard = nullptr) {
     // guard (vector and stream16 kernels): device flag, non-zero = skip the work
     if (A.nrows == 0) return DNS_OK;
-    if ((variant == 3 || variant == 4) && A.c16.p) {
+    if (variant == 7 && A.c16.p) {
+        // diagnostic: the gather reads an 8 KB range of x (cache-resident):
+        // separates the address-processing cost of the gather from its
+        // memory-side cost
+        const int nb = A.nrowblocks_t[1];
+        hipLaunchKernelGGL((k_spmv_stream16<4, 3>), std::min(nb, 65535), kBlock,
+                           0, s, nb, A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p,
+                           A.c16.p, A.c16base.p, A.vals.p, x, y, alpha, beta, b);
+    } else if ((variant == 3 || variant == 4) && A.c16.p) {
         // diagnostic variants of the 16-bit kernel (see k_spmv_stream16)
         const int nb = A.nrowblocks_t[1];
         const int grid = std::min(nb, 65535);

@@ -13,6 +13,7 @@ nb = bench.spmv_bytes(K)
 names = {17: 'stream, 2 loads per lane in flight (earlier kernel)',
          1: 'stream (int32 cols)', 2: 'stream16 (u16 offsets, pair loads)',
          5: 'stream16, single loads (before)',
+         7: 'diag: single loads, gather from an 8 KB range of x',
          3: 'diag: stream16 without the x gather',
          4: 'diag: ... and without the LDS row reduction'}
 res = {k: [] for k in names}
