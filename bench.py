@@ -287,7 +287,7 @@ def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64):
     return out
 
 
-def pmc_traffic(Kmat):
+def pmc_traffic(Kmat, kernel='k_spmv_stream16'):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes
     (profiles/spmv_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950) -- only if they were taken on this very matrix"""
@@ -297,7 +297,26 @@ def pmc_traffic(Kmat):
     rec = json.load(open(path))
     if rec.get('nnz') != int(Kmat.nnz) or rec.get('rows') != Kmat.shape[0]:
         return None
+    if kernel.startswith('k_spmv_pair'):
+        return (rec.get('pair_format') or {}).get('hbm_bytes_per_launch')
     return rec['hbm_bytes_per_launch']
+
+
+def roofline_pair(saddle, Kmat, nv, reps, label):
+    """`y = K x` through the pair format (2x2 node blocks, csrc/pair.hpp) --
+    the kernel that applies K inside the solver at this size; same HIP-event
+    timing and the same ALGORITHMIC bytes (those of the CSR product, SURVEY
+    8d) as the CSR figures"""
+    x = np.sin(0.37*np.arange(Kmat.shape[1]))
+    try:
+        _, secs, fbytes = saddle.spmv_pair(Kmat, nv, x, reps=reps, warmup=5)
+    except Exception as exc:            # odd NV, ...: the CSR kernel applies K
+        sys.stderr.write('pair format not available: {0}\n'.format(exc))
+        return None
+    return dict(kernel='k_spmv_pair16x', achieved=spmv_bytes(Kmat)/secs/1e9,
+                avg_us=secs*1e6, bytes=spmv_bytes(Kmat), nnz=int(Kmat.nnz),
+                rows=int(Kmat.shape[0]), matrix=label,
+                format_bytes=int(fbytes))
 
 
 def roofline_spmv(saddle, Kmat, reps, label, variants=('vector', 'stream')):
@@ -859,10 +878,18 @@ def main():
             # only the LDS-streaming kernel (16-bit column offsets) runs on the
             # refined matrix, so its rocprofv3 average is this measurement and
             # nothing else
-            roof_hbm = roofline_spmv(
-                saddle, Kr, 30, 'K on the mesh refined {0}x (n={1})'.format(
-                    args.roofline_refine, Kr.shape[0]), variants=('stream16',))
-            traffic = pmc_traffic(Kr)
+            label = 'K on the mesh refined {0}x (n={1})'.format(
+                args.roofline_refine, Kr.shape[0])
+            roof_csr = roofline_spmv(saddle, Kr, 30, label,
+                                     variants=('stream16',))
+            # the solver applies K through the pair format at this size (if K
+            # has an even number of velocity dofs): that is the kernel on
+            # record; the CSR streaming kernel stays next to it
+            roof_pair = roofline_pair(saddle, Kr, smr['M'].shape[0], 30, label)
+            roof_hbm = roof_pair if roof_pair is not None else roof_csr
+            roof_hbm['csr_kernel'] = None if roof_pair is None else dict(
+                roof_csr, traffic=pmc_traffic(Kr, roof_csr['kernel']))
+            traffic = pmc_traffic(Kr, roof_hbm['kernel'])
         else:
             traffic = None
         main_roof = roof_hbm if roof_hbm is not None else roof

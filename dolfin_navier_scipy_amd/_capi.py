@@ -169,6 +169,10 @@ SIGNATURES = {
     'dns_gemv': (ct.c_int, [ct.c_int, ct.c_int32, c_double_p, c_double_p,
                             c_double_p, ct.c_double]),
     'dns_dense_inverse': (ct.c_int, [ct.c_int, ct.c_int32, c_double_p]),
+    'dns_spmv_pair': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr), ct.c_int32,
+                                 c_double_p, c_double_p, ct.c_int32,
+                                 ct.c_int32, c_double_p,
+                                 ct.POINTER(ct.c_int64)]),
     'dns_spmv_bench': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr), ct.c_int32,
                                   ct.c_int32, ct.c_int32, c_double_p,
                                   c_double_p]),

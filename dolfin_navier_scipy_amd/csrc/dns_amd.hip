@@ -106,6 +106,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
     if (const char *sn = getenv("DNS_MG_FUSED")) mg_fused_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
+    if (const char *sn = getenv("DNS_PAIR")) pair_knob = sn[0] != '0';
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
@@ -213,6 +214,19 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     return DNS_OK;
 }
 
+// the pair format of K for the K applies of the bandwidth regime (one GPU);
+// silently absent for odd sizes
+int dns_saddle::build_pair() {
+    Kp.release_all();
+    if (!pair_knob || comm || !streams(K)) return DNS_OK;
+    if (fh_stale) return DNS_OK;     // (host values not current)
+    const HostCsr kf = host_k_slice(Fh, JTh, Jh, nv, 0, nv, 0, np);
+    HostPair P;
+    if (!host_pair_from_k(kf, nv, P)) return DNS_OK;
+    DNS_TRY(Kp.upload(P, stream));
+    return DNS_OK;
+}
+
 int dns_saddle::update_values(const double *fvals) {
     DNS_HIP(hipSetDevice(device));
     if (dist_sliced) {
@@ -225,6 +239,8 @@ int dns_saddle::update_values(const double *fvals) {
     }
     Fh.vals.assign(fvals, fvals + F.nnz);
     fh_stale = false;
+    if (Kp.ready) drop_graphs();     // (they launch the pair kernel)
+    Kp.release_all();                // copies of the values: next set-up
     DNS_TRY(F.vals.upload(fvals, (size_t)F.nnz, stream));
     hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
                        stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p, K.vals.p);
@@ -238,6 +254,8 @@ int dns_saddle::update_values(const double *fvals) {
 // F.vals was re-valued by a device kernel (trapezoidal stepper): bring K and
 // D^-1 along; the host copy is fetched lazily before the next set-up
 int dns_saddle::device_values_changed() {
+    if (Kp.ready) drop_graphs();
+    Kp.release_all();
     hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
                        stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p, K.vals.p);
     hipLaunchKernelGGL(k_diag_inv, grid_for_elems(nv), kBlock, 0, stream, nv,
@@ -1046,6 +1064,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
         tmp_Gch = HostCsr();
         tmp_JGh = HostCsr();
     }
+    DNS_TRY(build_pair());
     precond_ready = true;
     dist_active = (comm != nullptr);
     return DNS_OK;
@@ -1168,11 +1187,16 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         ep.part = partR.p;
         ep.nvec = 0;
         ep.with_ww = 1;
-        resid_np = stream_grid(K, kStreamGrid);
+        resid_np = Kp.ready ? pair_grid(Kp, kStreamGrid)
+                            : stream_grid(K, kStreamGrid);
         ep.nparts = resid_np;
         ep.part_bb = partB.p;
-        DNS_TRY(launch_stream16x<double>(K, K.vals.p, x, r.p, ep, stream,
-                                         nullptr, kStreamGrid));
+        if (Kp.ready)
+            DNS_TRY(launch_pair16x(Kp, x, r.p, ep, stream, nullptr,
+                                   kStreamGrid));
+        else
+            DNS_TRY(launch_stream16x<double>(K, K.vals.p, x, r.p, ep, stream,
+                                             nullptr, kStreamGrid));
     } else if (!have_resid) {
         DNS_LPR_SWITCH(
             K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
@@ -1194,7 +1218,9 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     // (while they fit its accumulators)
     const bool stream_k = streams(K);
     const bool fusedgs = o->reorth == 2 && (fuse_dots || stream_k);
-    const int gridK = stream_k ? stream_grid(K, kStreamGrid) : gridC;
+    const int gridK = stream_k ? (Kp.ready ? pair_grid(Kp, kStreamGrid)
+                                           : stream_grid(K, kStreamGrid))
+                               : gridC;
     // partials the consumers of step j's dots read: written by the kernel
     // that applied K in step j
     auto kparts = [&](int jj) {
@@ -1312,8 +1338,13 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             ep.with_ww = 1;
             ep.part = partA.p;
             ep.nparts = gridK;
-            DNS_TRY(launch_stream16x<double>(K, K.vals.p, zj, w.p, ep, stream,
-                                             done_ptr(), kStreamGrid));
+            if (Kp.ready)
+                DNS_TRY(launch_pair16x(Kp, zj, w.p, ep, stream, done_ptr(),
+                                       kStreamGrid));
+            else
+                DNS_TRY(launch_stream16x<double>(K, K.vals.p, zj, w.p, ep,
+                                                 stream, done_ptr(),
+                                                 kStreamGrid));
             continue;                    // no Gram-Schmidt kernel
         } else if (fuse_dots || fusedgs) {
             DNS_LPR_SWITCH(
@@ -2067,6 +2098,8 @@ int dns_saddle_precond_info(dns_saddle *h, int32_t cap, int64_t *out,
         v.push_back(l + 1 < L ? std::max<int64_t>(h->mg[l].P.nnz,
                                                   h->mg[l].nnz_P) : 0);
     }
+    // (last: device bytes of the pair format of K, 0 = the CSR kernels apply K)
+    v.push_back(h->Kp.ready ? h->Kp.bytes() : 0);
     *count = (int32_t)v.size();
     if (out)
         for (int32_t i = 0; i < std::min<int32_t>(cap, *count); ++i)
@@ -2226,6 +2259,60 @@ int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
         DNS_TRY(res.download(checksum, 1, ss.s));
         DNS_HIP(hipStreamSynchronize(ss.s));
     }
+    return DNS_OK;
+}
+
+// y = K x through the pair format (pair.hpp); DNS_ERR_BAD_ARGUMENT for odd
+// sizes.  reps > 0: timed like dns_spmv_bench
+// (HIP events on the launch stream), *avg_seconds = seconds per launch
+int dns_spmv_pair(int device, const dns_csr *k, int32_t nv, const double *x,
+                  double *y, int32_t reps, int32_t warmup, double *avg_seconds,
+                  int64_t *format_bytes) {
+    DNS_TRY(check_csr(k, "K"));
+    if (!x || !y) return fail(DNS_ERR_BAD_ARGUMENT, "null vector");
+    if (k->nrows != k->ncols)
+        return fail(DNS_ERR_BAD_ARGUMENT, "K must be square");
+    DNS_HIP(hipSetDevice(device));
+    ScopedStream ss;
+    DNS_HIP(hipStreamCreate(&ss.s));
+    HostPair P;
+    {
+        const HostCsr kh = host_copy(k);
+        const char *why = "";
+        if (!host_pair_from_k(kh, nv, P, &why))
+            return fail(DNS_ERR_BAD_ARGUMENT, "no pair format: %s", why);
+    }
+    PairDev A;
+    DNS_TRY(A.upload(P, ss.s));
+    if (format_bytes) *format_bytes = A.bytes();
+    DevBuf<double> dx, dy;
+    DNS_TRY(dx.alloc((size_t)k->ncols));
+    DNS_TRY(dy.alloc((size_t)k->nrows));
+    DNS_TRY(dx.upload(x, (size_t)k->ncols, ss.s));
+    const StreamEpi ep = stream_epi_plain(1.0, 0.0, nullptr);
+    // (warmup < 0: the diagnostic variant without the gather of x -- timing
+    // only, the result is wrong by design; scripts/spmv_c16.py)
+    const int diag = warmup < 0 ? 1 : 0;
+    for (int i = 0; i < std::max(1, std::abs((int)warmup)); ++i)
+        DNS_TRY(launch_pair16x(A, dx.p, dy.p, ep, ss.s, nullptr, 65535, diag));
+    if (reps > 0 && avg_seconds) {
+        hipEvent_t e0, e1;
+        DNS_HIP(hipEventCreate(&e0));
+        DNS_HIP(hipEventCreate(&e1));
+        DNS_HIP(hipEventRecord(e0, ss.s));
+        for (int i = 0; i < reps; ++i)
+            DNS_TRY(launch_pair16x(A, dx.p, dy.p, ep, ss.s, nullptr, 65535,
+                                   diag));
+        DNS_HIP(hipEventRecord(e1, ss.s));
+        DNS_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        DNS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_seconds = 1e-3 * ms / reps;
+    }
+    DNS_TRY(dy.download(y, (size_t)k->nrows, ss.s));
+    DNS_HIP(hipStreamSynchronize(ss.s));
     return DNS_OK;
 }
 

@@ -441,4 +441,33 @@ inline HostCsr host_hstack(const HostCsr &A, const HostCsr &B) {
     return C;
 }
 
+// this rank's rows of K = [[F, JT], [J, 0]]: velocity rows, then pressure rows
+inline HostCsr host_k_slice(const HostCsr &F, const HostCsr &JT,
+                            const HostCsr &J, int nv, int v0, int v1,
+                                 int p0, int p1) {
+    HostCsr S;
+    S.nrows = (v1 - v0) + (p1 - p0);
+    S.ncols = nv + J.nrows;
+    S.rowptr.assign(1, 0);
+    for (int r = v0; r < v1; ++r) {
+        for (int k = F.rowptr[r]; k < F.rowptr[r + 1]; ++k) {
+            S.colidx.push_back(F.colidx[k]);
+            S.vals.push_back(F.vals[k]);
+        }
+        for (int k = JT.rowptr[r]; k < JT.rowptr[r + 1]; ++k) {
+            S.colidx.push_back(nv + JT.colidx[k]);
+            S.vals.push_back(JT.vals[k]);
+        }
+        S.rowptr.push_back((int)S.colidx.size());
+    }
+    for (int r = p0; r < p1; ++r) {
+        for (int k = J.rowptr[r]; k < J.rowptr[r + 1]; ++k) {
+            S.colidx.push_back(J.colidx[k]);
+            S.vals.push_back(J.vals[k]);
+        }
+        S.rowptr.push_back((int)S.colidx.size());
+    }
+    return S;
+}
+
 }  // namespace dns

@@ -14,6 +14,7 @@
 #include "halo.hpp"
 #include "hostcsr.hpp"
 #include "kernels.hpp"
+#include "pair.hpp"
 
 namespace dns {
 
@@ -379,6 +380,11 @@ struct dns_saddle {
                                       // stepper (tables of per-step data);
                                       // bumped by the first head kernel of
                                       // a solve
+    // pair format of K (pair.hpp): the K applies of the bandwidth regime run
+    // on it when the velocity block has the two-component structure
+    dns::PairDev Kp;
+    bool pair_knob = true;            // DNS_PAIR (read once, at create)
+    int build_pair();
     dns::TailExtrap tail_extrap = {}; // warm start of the next step, written
                                       // by the tail kernels (set by dns_imex)
     int prologue_nparts = 0;          // > 0: partials of ||r||^2, ||b||^2 the

@@ -7,7 +7,7 @@ import scipy.sparse as sps
 from . import _capi as C
 
 __all__ = ['SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
-           'dense_inverse', 'spmv_bench', 'solve_opts', 'precond_opts']
+           'dense_inverse', 'spmv_bench', 'spmv_pair', 'solve_opts', 'precond_opts']
 
 _METHODS = {'gmres': C.DNS_METHOD_GMRES, 'bicgstab': C.DNS_METHOD_BICGSTAB}
 _SCHUR = {'dense': C.DNS_SCHUR_DENSE, 'jacobi': C.DNS_SCHUR_JACOBI, 'mg': 2}
@@ -136,6 +136,8 @@ class SaddleSystem(object):
         for l in range(v[7]):
             n, nnzs, nnzp = v[9 + 3*l:12 + 3*l]
             out['mg_levels'].append(dict(n=n, nnz_S=nnzs, nnz_P=nnzp))
+        tail = 9 + 3*v[7]
+        out['pair_format_bytes'] = v[tail] if len(v) > tail else 0
         return out
 
     def solve(self, rhsv, rhsp=None, x0=None, raise_on_fail=True, **kw):
@@ -326,6 +328,22 @@ def spmv(A, x, y=None, alpha=1., beta=0., variant='vector', device=0):
     C.check(lib.dns_spmv(device, view.byref(), C.dptr(x), C.dptr(out),
                          float(alpha), float(beta),
                          _VARIANTS.get(variant, variant)))
+    return out
+
+
+def spmv_pair(K, nv, x, reps=0, warmup=1, device=0):
+    """`y = K x` through the pair format (`dns_spmv_pair`); with `reps > 0`
+    returns `(y, seconds_per_launch, format_bytes)`"""
+    lib = C.load_library()
+    view = C.CsrView(K)
+    x = C.as_f64(x, size=view.shape[1])
+    out = np.zeros(view.shape[0])
+    secs, fb = ct.c_double(0.), ct.c_int64(0)
+    C.check(lib.dns_spmv_pair(device, view.byref(), int(nv), C.dptr(x),
+                              C.dptr(out), int(reps), int(warmup),
+                              ct.byref(secs), ct.byref(fb)))
+    if reps > 0:
+        return out, secs.value, fb.value
     return out
 
 

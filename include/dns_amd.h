@@ -380,6 +380,19 @@ int dns_dense_inverse(int device, int32_t n, double *a_rowmajor);
  * time (HIP events on the launch stream) -- the roofline measurement */
 int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
                    int32_t warmup, double *avg_seconds, double *checksum);
+/* y = K x for K = [[F, JT],[J, 0]] (CSR, velocity rows/columns first, `nv` of
+ * them) through the 2x2-blocked PAIR format: rows and columns are taken in
+ * pairs (the two velocity dofs of a node; consecutive pressure dofs), an entry
+ * is a 2x2 block = four values + one 16-bit column offset, served by one
+ * 16-byte gather of x.  Holds any K with even nv and even size (explicit zeros
+ * where a block is not full); DNS_ERR_BAD_ARGUMENT otherwise.  reps > 0 and
+ * avg_seconds != NULL: seconds per launch by HIP events, as dns_spmv_bench;
+ * format_bytes: device bytes of the format (may be NULL).  Inside a solver
+ * the format carries the K applies of the bandwidth regime automatically
+ * (DNS_PAIR=0 turns it off). */
+int dns_spmv_pair(int device, const dns_csr *k, int32_t nv, const double *x,
+                  double *y, int32_t reps, int32_t warmup, double *avg_seconds,
+                  int64_t *format_bytes);
 
 /* Multigrid Schur block for pressure spaces too large for the dense inverse
  * (refined meshes).  `prol[l]` (CSR, n_l x n_{l+1}, l = 0 .. nprol-1) are the

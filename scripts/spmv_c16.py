@@ -31,3 +31,22 @@ y2 = saddle.spmv(K, x, variant='stream16')
 print('max |y16 - y32| =', np.abs(y1 - y2).max())
 y3 = saddle.spmv(K, x, variant=5)
 print('max |ysingle - y32| =', np.abs(y1 - y3).max())
+
+# the 2x2-blocked pair format (needs even sizes)
+NV = sm['M'].shape[0]
+if NV % 2 == 0:
+    rates = []
+    for rnd in range(4):
+        yp, secs, fb = saddle.spmv_pair(K, NV, x, reps=15, warmup=2)
+        rates.append(nb/secs/1e9)
+    print('%-24s median %7.0f GB/s (algorithmic)  min %7.0f max %7.0f; '
+          'format %.1f MB (CSR16 %.1f MB)' % (
+              'pair format (2x2 blocks)', np.median(rates), min(rates),
+              max(rates), fb/1e6, (10*K.nnz + 4*K.shape[0])/1e6))
+    print('max |ypair - y32| =', np.abs(y1 - yp).max(), 'of', np.abs(y1).max())
+    rates = []
+    for rnd in range(3):
+        _, secs, _ = saddle.spmv_pair(K, NV, x, reps=15, warmup=-2)
+        rates.append(nb/secs/1e9)
+    print('%-24s median %7.0f GB/s (algorithmic)' % (
+        'diag: pair format without the x gather', np.median(rates)))

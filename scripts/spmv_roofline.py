@@ -18,5 +18,12 @@ out = {}
 for variant in ('stream16', 'stream', 'vector'):
     secs, chk = saddle.spmv_bench(K, variant=variant, reps=reps, warmup=3)
     out[variant] = dict(avg_us=secs*1e6, GBs=bench.spmv_bytes(K)/secs/1e9)
+NV = sm['M'].shape[0]
+if NV % 2 == 0:
+    import numpy as np
+    x = np.sin(0.37*np.arange(K.shape[1]))
+    _, secs, fb = saddle.spmv_pair(K, NV, x, reps=reps, warmup=3)
+    out['pair'] = dict(avg_us=secs*1e6, GBs=bench.spmv_bytes(K)/secs/1e9,
+                       format_bytes=int(fb))
 out.update(bytes=bench.spmv_bytes(K), nnz=int(K.nnz), rows=int(K.shape[0]))
 print(json.dumps(out))

@@ -124,3 +124,76 @@ def test_spmv_stream16_windows_and_raw_blocks(sad):
         got = sad.spmv(mat, x, y=np.ones(mat.shape[0]), alpha=0.5, beta=-2.0,
                        variant='stream16')
         assert np.abs(got - (0.5*ref - 2.0)).max() <= 1e-12*np.abs(ref).max()
+
+
+def _pair_k(rng, nodes, npres, dens=0.05, coupled=True):
+    """synthetic K = [[F, JT], [J, 0]] with 2 x nodes velocity dofs: ragged
+    rows, empty rows, node blocks that are full (`coupled`) or diagonal, and
+    one-sided J / JT entries"""
+    Fs = (_rand_csr(rng, nodes, nodes, dens) + sps.identity(nodes)).tocoo()
+    rows = np.concatenate([2*Fs.row, 2*Fs.row + 1])
+    cols = np.concatenate([2*Fs.col, 2*Fs.col + 1])
+    vals = np.concatenate([Fs.data, 1.5*Fs.data])
+    if coupled:
+        rows = np.concatenate([rows, 2*Fs.row, 2*Fs.row + 1])
+        cols = np.concatenate([cols, 2*Fs.col + 1, 2*Fs.col])
+        vals = np.concatenate([vals, -.3*Fs.data, .7*Fs.data])
+    F = sps.coo_matrix((vals, (rows, cols)), shape=(2*nodes, 2*nodes)).tocsr()
+    J = _rand_csr(rng, npres, 2*nodes, dens)       # x / y entries independent
+    if npres > 3:
+        J = J.tolil()
+        J[1, :] = 0
+        J = J.tocsr()
+        J.eliminate_zeros()
+    K = sps.bmat([[F, J.T], [J, None]], format='csr')
+    K.sort_indices()
+    return K, 2*nodes
+
+
+@pytest.mark.parametrize('nodes,npres,coupled', [(1, 1, True), (5, 3, False),
+                                                 (200, 40, True),
+                                                 (3000, 400, True),
+                                                 (3000, 400, False),
+                                                 (700, 0, True)])
+def test_spmv_pair_format_matches_scipy(sad, nodes, npres, coupled):
+    rng = np.random.default_rng(nodes + npres)
+    K, nv = _pair_k(rng, nodes, npres, dens=min(0.5, 12./nodes),
+                    coupled=coupled)
+    x = rng.standard_normal(K.shape[1])
+    y = sad.spmv_pair(K, nv, x)
+    ref = K @ x
+    assert np.abs(y - ref).max() <= 1e-13*max(1., np.abs(ref).max())
+
+
+def test_spmv_pair_format_refuses_what_it_cannot_hold(sad):
+    from dolfin_navier_scipy_amd import _capi
+    rng = np.random.default_rng(8)
+    K, nv = _pair_k(rng, 50, 11)         # (an odd number of pressure dofs is
+    x = rng.standard_normal(K.shape[1])  # fine: pressure is not paired)
+    y = sad.spmv_pair(K, nv, x)
+    assert np.abs(y - K @ x).max() <= 1e-13*np.abs(y).max()
+    with pytest.raises(_capi.DnsError):
+        sad.spmv_pair(K, nv - 1, x)      # odd number of velocity dofs
+    pp = K.tolil()
+    pp[nv, nv + 3] = 1.0                 # pressure-pressure entry
+    with pytest.raises(_capi.DnsError):
+        sad.spmv_pair(pp.tocsr(), nv, x)
+
+
+def test_spmv_pair_format_on_the_cylinder_system(sad):
+    """the K of the cylinder wake on the mesh refined once: the
+    result equals the CSR product to rounding, the format is smaller than the
+    16-bit CSR (dense 2x2 node blocks: 8.5 bytes per non-zero)"""
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=100,
+                                 refine=1)
+    F = (sm['M'] + .5/1024*sm['A']).tocsr()
+    J = sm['J']
+    K = sps.bmat([[F, J.T], [J, None]], format='csr')
+    K.sort_indices()
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal(K.shape[1])
+    y, secs, fbytes = sad.spmv_pair(K, F.shape[0], x, reps=3)
+    ref = K @ x
+    assert np.abs(y - ref).max() <= 1e-13*np.abs(ref).max()
+    assert fbytes < 10*K.nnz             # < 8 B value + 2 B offset per non-zero

@@ -537,13 +537,19 @@ def test_streaming_kernels_forced_on_small_systems(sad, monkeypatch):
                                          rhsp=rhsp).reshape(-1)
     v0 = ref[:NV].copy()
     res = {}
-    for mode, thr in (('latency', '1000000000'), ('stream', '1')):
+    # 'stream': K is applied through the pair format (2x2 node blocks,
+    # pair.hpp); 'stream_csr': through the CSR streaming kernel (DNS_PAIR=0)
+    for mode, thr, pair in (('latency', '1000000000', '1'),
+                            ('stream', '1', '1'), ('stream_csr', '1', '0')):
         monkeypatch.setenv('DNS_STREAM_NNZ', thr)
+        monkeypatch.setenv('DNS_PAIR', pair)
         monkeypatch.setenv('DNS_MG_DENSE_MAX', '2000')
         system = sad.SaddleSystem(F, J)
         system.set_schur_mg(prols)
         system.setup_precond(cheb_degree=6, schur='mg', drop_tol=1e-3,
                              factorization='full')
+        pbytes = system.precond_info()['pair_format_bytes']
+        assert (pbytes > 0) == (mode == 'stream'), (mode, pbytes)
         for reorth in (1, 2):
             x = system.solve(rhsv, rhsp, rtol=1e-11, maxiter=400,
                              reorth=reorth, use_graph=(reorth == 2))
@@ -567,9 +573,11 @@ def test_streaming_kernels_forced_on_small_systems(sad, monkeypatch):
         stp.close()
         system.close()
     assert abs(res['stream_its'] - res['latency_its']) <= 1
+    assert abs(res['stream_csr_its'] - res['latency_its']) <= 1
     (vl, pl), (vs, ps) = res['latency'], res['stream']
-    assert np.linalg.norm(vs - vl) <= 1e-9*np.linalg.norm(vl)
-    assert np.linalg.norm(ps - pl) <= 1e-7*np.linalg.norm(pl)
+    for vq, pq in (res['stream'], res['stream_csr']):
+        assert np.linalg.norm(vq - vl) <= 1e-9*np.linalg.norm(vl)
+        assert np.linalg.norm(pq - pl) <= 1e-7*np.linalg.norm(pl)
     # and against the factor-once oracle loop (tiu:104-143, no convection)
     lu = saddle_oracle.SaddleLU(F, J)
     v = v0.reshape((-1, 1))
