@@ -509,7 +509,11 @@ inline StreamEpi stream_epi_plain(double alpha, double beta, const double *b) {
 constexpr int kStreamDots = 8;   // fused dots: at most this many basis vectors
 constexpr int kStreamGrid = 1024;   // workgroups (= partials) of such a launch
 
-template <int G, typename VT>
+// DOTS: instantiation with the fused-dots epilogue; the others keep the dot
+// accumulators out of the register file (58 instead of 80 VGPRs: 8 instead of
+// 5-6 waves per SIMD, which these latency-hiding-by-occupancy kernels turn
+// into bandwidth)
+template <int G, typename VT, bool DOTS = true>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
                  const int *__restrict__ rowptr,
@@ -528,11 +532,11 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
     const int cls = blockIdx.x % 8;
     const int vb = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
     const bool split = ep.x2 != nullptr;
-    const bool dots = ep.part != nullptr;
-    double acc[kStreamDots + 1];
+    const bool dots = DOTS && ep.part != nullptr;
+    double acc[DOTS ? kStreamDots + 1 : 1];
     double accb = 0.0;
 #pragma unroll
-    for (int i = 0; i <= kStreamDots; ++i) acc[i] = 0.0;
+    for (int i = 0; i < (DOTS ? kStreamDots + 1 : 1); ++i) acc[i] = 0.0;
     for (int blk = vb; blk < nblocks; blk += gridDim.x) {
         const int r0 = rowblocks[blk], r1 = rowblocks[blk + 1];
         const int k0 = rowptr[r0], k1 = rowptr[r1];
@@ -613,10 +617,10 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
                                : ep.alpha * s;
                 }
                 y[row] = out;
-                if (dots) srow[r] = out;
+                if (DOTS && dots) srow[r] = out;
             }
         }
-        if (dots) {
+        if (DOTS && dots) {
             // thread t takes row t of the tile: basis loads are coalesced and
             // every lane works (the row results sit in 1 of G lanes)
             __syncthreads();
@@ -626,9 +630,10 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
 #pragma unroll
                 for (int i = 0; i < kStreamDots; ++i)
                     if (i < ep.nvec)
-                        acc[i] = fma(ep.V[(size_t)i * ep.ld + row], out,
-                                     acc[i]);
-                acc[kStreamDots] = fma(out, out, acc[kStreamDots]);
+                        acc[DOTS ? i : 0] = fma(ep.V[(size_t)i * ep.ld + row],
+                                                out, acc[DOTS ? i : 0]);
+                acc[DOTS ? kStreamDots : 0] =
+                    fma(out, out, acc[DOTS ? kStreamDots : 0]);
                 if (ep.part_bb) {
                     const double bv = ep.b[row];
                     accb = fma(bv, bv, accb);
@@ -636,18 +641,18 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
             }
         }
     }
-    if (dots) {
+    if (DOTS && dots) {
         for (int i = 0; i < ep.nvec; ++i) {
             double a = 0.0;
 #pragma unroll
             for (int q = 0; q < kStreamDots; ++q)
-                if (q == i) a = acc[q];
+                if (q == i) a = acc[DOTS ? q : 0];
             a = block_sum(a, red);
             if (threadIdx.x == 0)
                 ep.part[(size_t)i * ep.nparts + blockIdx.x] = a;
         }
         if (ep.with_ww) {
-            const double a = block_sum(acc[kStreamDots], red);
+            const double a = block_sum(acc[DOTS ? kStreamDots : 0], red);
             if (threadIdx.x == 0)
                 ep.part[(size_t)ep.nvec * ep.nparts + blockIdx.x] = a;
         }

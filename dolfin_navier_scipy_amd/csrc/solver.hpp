@@ -256,22 +256,27 @@ inline int launch_stream16x(const CsrDev &A, const VT *vals, const double *x,
     const int nb = A.nrowblocks_t[1];
     const int grid = std::max(1, std::min(nb, grid_cap));
     const int *rbp = A.rowblocks_t[1].p;
+#define DNS_STREAM16X(GG)                                                      \
+    do {                                                                      \
+        if (ep.part)                                                          \
+            hipLaunchKernelGGL((k_spmv_stream16x<GG, VT, true>), grid, kBlock, \
+                               0, s, nb, rbp, A.rowptr.p, A.colidx.p,         \
+                               A.c16.p, A.c16base.p, vals, x, y, ep, guard);  \
+        else                                                                  \
+            hipLaunchKernelGGL((k_spmv_stream16x<GG, VT, false>), grid,       \
+                               kBlock, 0, s, nb, rbp, A.rowptr.p,             \
+                               A.colidx.p, A.c16.p, A.c16base.p, vals, x, y,  \
+                               ep, guard);                                    \
+    } while (0)
     if (avg <= 6)
-        hipLaunchKernelGGL((k_spmv_stream16x<1, VT>), grid, kBlock, 0, s, nb,
-                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                           vals, x, y, ep, guard);
+        DNS_STREAM16X(1);
     else if (avg <= 12)
-        hipLaunchKernelGGL((k_spmv_stream16x<2, VT>), grid, kBlock, 0, s, nb,
-                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                           vals, x, y, ep, guard);
+        DNS_STREAM16X(2);
     else if (avg <= 192)   // (measured on Gc, 115 per row: 4 beats 16)
-        hipLaunchKernelGGL((k_spmv_stream16x<4, VT>), grid, kBlock, 0, s, nb,
-                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                           vals, x, y, ep, guard);
+        DNS_STREAM16X(4);
     else
-        hipLaunchKernelGGL((k_spmv_stream16x<16, VT>), grid, kBlock, 0, s, nb,
-                           rbp, A.rowptr.p, A.colidx.p, A.c16.p, A.c16base.p,
-                           vals, x, y, ep, guard);
+        DNS_STREAM16X(16);
+#undef DNS_STREAM16X
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }
