@@ -289,7 +289,7 @@ struct PairArgs {
 // DIAG != 0 (diagnostic, wrong results by design): 1 = no gather of x
 // DOTS: instantiation with the fused-dots epilogue (the plain product keeps
 // its accumulators out of the register file: 6 instead of 4 waves per SIMD)
-template <int G, int DIAG = 0, bool DOTS = true>
+template <int G, int DIAG = 0, bool DOTS = true, int ND = kStreamDots>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
                double *__restrict__ y, StreamEpi ep,
@@ -312,10 +312,12 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
     const int cls = blockIdx.x % 8;
     const int vb = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
     const bool dots = DOTS && ep.part != nullptr;
-    double acc[DOTS ? kStreamDots + 1 : 1];
+    // ND basis-vector accumulators + <y, y> (ND: what this instance is good
+    // for; the launcher picks the smallest that holds ep.nvec)
+    double acc[DOTS ? ND + 1 : 1];
     double accb = 0.0;
 #pragma unroll
-    for (int i = 0; i < (DOTS ? kStreamDots + 1 : 1); ++i) acc[i] = 0.0;
+    for (int i = 0; i < (DOTS ? ND + 1 : 1); ++i) acc[i] = 0.0;
     for (int blk = vb; blk < A.nblocks; blk += gridDim.x) {
         const int r0 = A.rowblocks[blk], r1 = A.rowblocks[blk + 1];
         const int nr = r1 - r0;
@@ -483,12 +485,11 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
                     vrows ? (size_t)2 * r0 + threadIdx.x
                           : (size_t)A.nv + (r0 - A.nvp) + threadIdx.x;
 #pragma unroll
-                for (int i = 0; i < kStreamDots; ++i)
+                for (int i = 0; i < ND; ++i)
                     if (i < ep.nvec)
                         acc[DOTS ? i : 0] = fma(ep.V[(size_t)i * ep.ld + row],
                                                 out, acc[DOTS ? i : 0]);
-                acc[DOTS ? kStreamDots : 0] =
-                    fma(out, out, acc[DOTS ? kStreamDots : 0]);
+                acc[DOTS ? ND : 0] = fma(out, out, acc[DOTS ? ND : 0]);
                 if (ep.part_bb) {
                     const double bv = ep.b[row];
                     accb = fma(bv, bv, accb);
@@ -500,14 +501,14 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
         for (int i = 0; i < ep.nvec; ++i) {
             double a = 0.0;
 #pragma unroll
-            for (int q = 0; q < kStreamDots; ++q)
+            for (int q = 0; q < ND; ++q)
                 if (q == i) a = acc[DOTS ? q : 0];
             a = block_sum(a, red);
             if (threadIdx.x == 0)
                 ep.part[(size_t)i * ep.nparts + blockIdx.x] = a;
         }
         if (ep.with_ww) {
-            const double a = block_sum(acc[DOTS ? kStreamDots : 0], red);
+            const double a = block_sum(acc[DOTS ? ND : 0], red);
             if (threadIdx.x == 0)
                 ep.part[(size_t)ep.nvec * ep.nparts + blockIdx.x] = a;
         }
@@ -537,9 +538,14 @@ inline int launch_pair16x(const PairDev &A, const double *x, double *y,
     if (diag)
         hipLaunchKernelGGL((k_spmv_pair16x<4, 1, false>), pair_grid(A, grid_cap),
                            kBlock, 0, s, a, x, y, ep, guard);
+    else if (ep.part && ep.nvec <= 3)
+        hipLaunchKernelGGL((k_spmv_pair16x<4, 0, true, 3>),
+                           pair_grid(A, grid_cap), kBlock, 0, s, a, x, y, ep,
+                           guard);
     else if (ep.part)
-        hipLaunchKernelGGL((k_spmv_pair16x<4, 0, true>), pair_grid(A, grid_cap),
-                           kBlock, 0, s, a, x, y, ep, guard);
+        hipLaunchKernelGGL((k_spmv_pair16x<4, 0, true, kStreamDots>),
+                           pair_grid(A, grid_cap), kBlock, 0, s, a, x, y, ep,
+                           guard);
     else
         hipLaunchKernelGGL((k_spmv_pair16x<4, 0, false>),
                            pair_grid(A, grid_cap), kBlock, 0, s, a, x, y, ep,
