@@ -451,6 +451,23 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
 
 def partitioned_child(args, world, rank, local_rank):
     """`--partitioned-only`: the process of one rank of a partitioned run"""
+    if args.dry_run:
+        # (tests: rendezvous of the child ranks over gloo, canned figures)
+        import torch.distributed as dist
+        with stdout_to_stderr():
+            dist.init_process_group('gloo')
+            dist.barrier()
+        res = dict(steps_per_s=100.0/(1 + args.refine), ms_per_step=10.0,
+                   NV=2*args.level, NP=args.level, unknowns=3*args.level,
+                   rows_per_rank=3.*args.level/world, level=args.level,
+                   refine=args.refine, krylov_iters_per_step=1.0,
+                   collectives_timed_window=dict(allreduce=1), dry_run=True,
+                   roofline_step=dict(achieved=1.0, frac=1e-4))
+        if rank == 0:
+            print(json.dumps(res))
+            sys.stdout.flush()
+        dist.destroy_process_group()
+        return res
     dist, one_gpu = None, False
     import faulthandler
     # say where it hangs, shortly before the parent's time limit strikes
@@ -543,6 +560,8 @@ def multi_gpu_main(args, world, rank, local_rank):
               '--check-every', str(args.check_every)]
     if args.eager:
         common.append('--eager')
+    if args.dry_run:
+        common.append('--dry-run')
 
     def partitioned(port_offset, level, refine, nts):
         env = child_env(MASTER_PORT=base_port + port_offset,
@@ -734,6 +753,10 @@ def main():
                     'ranks of this launch; prints its figures')
     ap.add_argument('--partitioned-timeout', type=float, default=300.,
                     help='time limit [s] of a row-partitioned child run')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='(tests) the child processes of a multi-rank launch '
+                    'report canned figures without touching a GPU: exercises '
+                    'the launch / rendezvous / JSON plumbing on CPU')
     ap.add_argument('--force-dist', action='store_true',
                     help='attach an RCCL communicator even with one rank '
                     '(self-test of the multi-GPU code path)')
@@ -746,6 +769,10 @@ def main():
         return partitioned_child(args, world, rank, local_rank)
     if world > 1:
         return multi_gpu_main(args, world, rank, local_rank)
+    if args.dry_run:
+        print(json.dumps(dict(ms_per_step=1.0, dry_run=True,
+                              config=dict(krylov_iters_per_step=1.0))))
+        return None
     device = args.device
 
     from dolfin_navier_scipy_amd import saddle, _capi

@@ -97,3 +97,39 @@ def test_spmv_bytes_of_the_bench_match_the_model():
     import scipy.sparse as sps
     A = sps.random(50, 40, density=0.1, format='csr', random_state=1)
     assert bench.spmv_bytes(A) == perfmodel.spmv_bytes(A.nnz, 50, 40)
+
+
+def test_multi_rank_launch_plumbing_on_cpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run,
+    one process per rank), with `--dry-run` children: parent ranks over gloo,
+    child processes per rank with their own rendezvous port and without the
+    launcher's TORCHELASTIC_* variables, the failure all-reduce, ONE JSON line
+    on rank 0's stdout with the weak-scaling headline, the strong-scaling and
+    the ensemble legs"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '3', '--warmup', '1', '--dry-run',
+           '--partitioned-timeout', '120']
+    env = dict(os.environ, GLOO_SOCKET_IFNAME='lo')
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines()
+             if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak'
+    assert rec['unit'] == 'timesteps/s' and rec['higher_is_better'] is True
+    cfg = rec['config']
+    assert cfg['weak_scaling']['level'] == 3            # the ladder's mesh
+    assert rec['value'] == cfg['weak_scaling']['steps_per_s']
+    assert cfg['strong_scaling']['level'] == 2
+    assert cfg['collectives'] == {'allreduce': 1}
+    assert cfg['ensemble']['error'] is None
+    assert 'FALLBACK' not in cfg['parallelism']
