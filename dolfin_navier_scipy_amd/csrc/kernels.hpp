@@ -495,6 +495,9 @@ struct StreamEpi {
     double *part_bb;             // != nullptr: partials of <b, b> as well (the
                                  // residual r = b - A x of a solve with both
                                  // of its norms in ONE launch)
+    int map_on;                  // row-partitioned solve: the CSR arrays hold
+    RowMap rm;                   // a rank's row block; local row -> global row
+                                 // (y, b, V are indexed by global row)
 };
 
 inline StreamEpi stream_epi_plain(double alpha, double beta, const double *b) {
@@ -603,7 +606,7 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
             for (int k = a0 + g; k < a1; k += G) s += prod[k];
             s = subwave_sum<G>(s);
             if (g == 0) {
-                const int row = r0 + r;
+                const int row = ep.map_on ? map_row(ep.rm, r0 + r) : r0 + r;
                 double out;
                 if (ep.dinv && ep.add_cb) {
                     out = fma(ep.alpha, s,
@@ -626,7 +629,9 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
             __syncthreads();
             if ((int)threadIdx.x < nr) {
                 const double out = srow[threadIdx.x];
-                const size_t row = (size_t)r0 + threadIdx.x;
+                const size_t row =
+                    ep.map_on ? (size_t)map_row(ep.rm, r0 + (int)threadIdx.x)
+                              : (size_t)r0 + threadIdx.x;
 #pragma unroll
                 for (int i = 0; i < kStreamDots; ++i)
                     if (i < ep.nvec)

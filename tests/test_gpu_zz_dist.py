@@ -119,9 +119,12 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
         knobs['DNS_MG_DENSE_MAX'] = '300'
     if fhat in ('mg', 'mgpart'):
         knobs['DNS_MG_DENSE_MAX'] = '100'      # (two levels at least)
+    if fhat == 'cyl3s':
+        # the row blocks through the streaming kernels (bandwidth regime)
+        knobs['DNS_STREAM_NNZ'] = '1'
     three = fhat in ('mg3', 'mg3part')
     mgs = fhat in ('mg', 'mgpart', 'mg3', 'mg3part')
-    cyl3 = fhat == 'cyl3'
+    cyl3 = fhat in ('cyl3', 'cyl3s')
     pr = (_mg3_problem() if three else _mg_problem()) if mgs else (
         _cyl3_problem() if cyl3 else _problem())
     saved = {k: os.environ.get(k) for k in knobs}
@@ -222,7 +225,7 @@ def _worker(rank, world, port, outdir):
     out = {}
     for fhat, reorth in (('explicit', False), ('full', False), ('mg', False),
                          ('mgpart', False), ('mg3', False), ('mg3part', False),
-                         ('cyl3', False)):
+                         ('cyl3', False), ('cyl3s', False)):
         info = {}
         before = cm.stats()
         x, st, v, p = _solve_and_step(saddle, cm, fhat, reorth, info=info)
@@ -311,6 +314,13 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
     assert np.linalg.norm(r0['cyl3_1'] - vc) <= 1e-9*np.linalg.norm(vc)
     assert np.linalg.norm(r0['cyl3_2'] - pc) <= 1e-7*np.linalg.norm(pc)
     assert abs(int(r0['cyl3_3']) - stc['iters']) <= 3
+    # the same with the row blocks going through the streaming kernels
+    assert np.array_equal(r0['cyl3s_0'], r1['cyl3s_0'])
+    assert float(r0['cyl3s_4']) <= 5e-12
+    assert np.linalg.norm(r0['cyl3s_0'] - xc) <= 1e-9*np.linalg.norm(xc)
+    assert np.linalg.norm(r0['cyl3s_1'] - vc) <= 1e-9*np.linalg.norm(vc)
+    assert np.linalg.norm(r0['cyl3s_2'] - pc) <= 1e-7*np.linalg.norm(pc)
+    assert abs(int(r0['cyl3s_3']) - stc['iters']) <= 3
     # per-rank storage: the row blocks, not the matrices
     for rr in (r0, r1):
         assert int(rr['cyl3_5']) < 0.6*info['matrix_bytes'], \
