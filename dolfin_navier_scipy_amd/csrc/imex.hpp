@@ -126,7 +126,7 @@ struct dns_imex {
     int run_captures = 0;          // graphs captured inside the last run
     // knobs read ONCE, when the stepper is created
     bool env_step_history = false, env_debug = false, env_slack_adapt = true;
-    int env_group = 4;
+    int env_group = 8;
     struct HostState {
         int cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos;
         long steps_enqueued;
