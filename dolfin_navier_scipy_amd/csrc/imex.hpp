@@ -127,6 +127,9 @@ struct dns_imex {
     // knobs read ONCE, when the stepper is created
     bool env_step_history = false, env_debug = false, env_slack_adapt = true;
     int env_group = 8;
+    double env_noslack_maxrel = 0.85;   // DNS_NOSLACK_MAXREL: no slack step
+                                        // while the batch maximum of
+                                        // residual / tolerance stays below
     struct HostState {
         int cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos;
         long steps_enqueued;
