@@ -143,3 +143,23 @@ def test_pipelined_run_512_steps_bench_settings(wake):
     print('pipelined 512 steps: v', ev, 'p', ep)
     assert ev <= VTOL, ev
     assert ep <= PTOL, ep
+
+
+def test_sbdf2_256_steps_default_settings(wake):
+    """the drop-in `time_int_utils.sbdftwo` (tiu:260-355) over the first 256
+    steps of the same configuration, host convection callback as in the
+    reference, against the oracle's factor-once SBDF2 loop"""
+    from dolfin_navier_scipy_amd import time_int_utils as gtiu
+    M = wake['sm']['M']
+    ro, rg = scenarios.Recorder(), scenarios.Recorder()
+    kwo = wake['make_kw'](ro, nts=256)
+    kwo.pop('verbose')
+    vo, po, _ = imex_oracle.sbdftwo(**kwo)
+    kwg = wake['make_kw'](rg, nts=256)
+    vg, pg, ff = gtiu.sbdftwo(**kwg)
+    assert ff == 0
+    ev = _mnorm(M, vg - vo)/_mnorm(M, vo)
+    ep = np.linalg.norm(pg - po)/np.linalg.norm(po)
+    print('sbdf2 256 steps (SOLVER defaults): v', ev, 'p', ep)
+    assert ev <= VTOL, ev
+    assert ep <= PTOL, ep
