@@ -130,25 +130,38 @@ class ResidentOperator(object):
             pass
 
 
-def make_applybcs(A, J, M, loccntbcinds, locinvinds, device=0):
+def make_applybcs(A, J, M, loccntbcinds, locinvinds, device=0,
+                  reference_literal=True):
     """the `applybcs(bcs_n)` closure of `solve_nse` (snu:1103-1115)
 
-    QUIRK of the reference: snu:1112 has the assignment
-    `cauxvec[loccntbcinds, 0] = bcs_n` commented out, so its closure returns
-    zeros whatever the control does; the values ARE written here (the evident
-    intent, and what the golden `movingbc` scenarios exercise)."""
+    `reference_literal=True` (default): what the reference EXECUTES.  snu:1112
+    has the assignment `cauxvec[loccntbcinds, 0] = bcs_n` commented out, so
+    its closure multiplies `A`, `J`, `M` with a vector that stays zero and
+    returns zero columns of the shapes `(len(locinvinds), 1)`, `(NP, 1)`,
+    `(len(locinvinds), 1)` whatever the control does (the controlled values
+    reach the flow through `appndbcs` / the convection only).
+    `reference_literal=False`: the values ARE written -- what the commented
+    line evidently meant: `(-A[:, cnt] vals, -J[:, cnt] vals, M[:, cnt] vals)`
+    from one resident operator, one launch per call."""
     if loccntbcinds is None or len(loccntbcinds) == 0:
         def applybcs(bcs_n):
             return 0., 0., 0.              # snu:1104-1105
         return applybcs
     cnt = np.asarray(loccntbcinds)
     inv = np.asarray(locinvinds)
+    NV, NP = A.shape[0], J.shape[0]
+    if reference_literal:
+        zv, zp = np.zeros((inv.size, 1)), np.zeros((NP, 1))
+
+        def applybcs(bcs_n):               # snu:1111-1115 as it runs
+            return -zv, -zp, zv.copy()
+        applybcs.operator = None
+        return applybcs
     # only the controlled columns matter: [A; J; M][:, cnt] as ONE resident
     # operator -- a single launch per call
     stack = sps.vstack([sps.csr_matrix(A)[:, cnt], sps.csr_matrix(J)[:, cnt],
                         sps.csr_matrix(M)[:, cnt]], format='csr')
     op = ResidentOperator(stack, device=device)
-    NV, NP = A.shape[0], J.shape[0]
 
     def applybcs(bcs_n):
         out = op.apply(np.asarray(bcs_n, dtype=np.float64))

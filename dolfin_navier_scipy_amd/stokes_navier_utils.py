@@ -343,7 +343,8 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
               check_ff_maxv=1e8, verbose=False, start_ssstokes=False,
               closed_loop=False, dynamic_feedback=False, static_feedback=False,
               vp_output=False, vp_out_fun=None, vp_output_dict=None,
-              solver=None, device=0, bcs_time_only=False, **kw):
+              solver=None, device=0, bcs_time_only=False,
+              applybcs_literal=True, **kw):
     """time-dependent Navier-Stokes on the device (reference snu:548-1600)
 
     Keyword names and meaning follow the reference.  `V`: object with the P2
@@ -352,7 +353,10 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
     SURVEY section 2: out of scope) raises.  Extra keywords: `solver`
     (overrides `time_int_utils.SOLVER`), `device`, `bcs_time_only` (the
     control functions `diricontfuncs` ignore `vel`/`p`: the explicit loop may
-    then run device resident over whole time slices).
+    then run device resident over whole time slices), `applybcs_literal`
+    (default True: the `applybcs` closure returns zeros exactly as the
+    reference's does with snu:1112 commented out; False: the controlled values
+    are written into the auxiliary vector, see `bcs.make_applybcs`).
     """
     if closed_loop or dynamic_feedback or static_feedback:
         raise NotImplementedError('feedback loops / observers are outside the '
@@ -452,7 +456,8 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
     # =====================================================================
     if lin_vel_point is None:
         applybcs = dbc.make_applybcs(Afull, Jfull, Mfull, loccnt, locinv,
-                                     device=device)
+                                     device=device,
+                                     reference_literal=applybcs_literal)
         if fvtd is None:
             def rhsv(t):
                 return cfv

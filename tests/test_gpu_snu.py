@@ -71,7 +71,14 @@ def test_resident_operator_and_applybcs(toy_prob):
     inv = toy_prob['invinds']
     cnt = dbcinds[np.abs(dbcvals) > 0]
     vals = rng.standard_normal(cnt.size)
-    app = bcs.make_applybcs(A, J, M, cnt.tolist(), inv.tolist())
+    # the reference as it runs (snu:1112 commented out): zero columns
+    lit = bcs.make_applybcs(A, J, M, cnt.tolist(), inv.tolist())
+    zfv, zfp, zmb = lit(vals)
+    assert zfv.shape == (inv.size, 1) and zfp.shape == (J.shape[0], 1)
+    assert zmb.shape == (inv.size, 1)
+    assert not zfv.any() and not zfp.any() and not zmb.any()
+    app = bcs.make_applybcs(A, J, M, cnt.tolist(), inv.tolist(),
+                            reference_literal=False)
     bfv, bfp, mbc = app(vals)
     caux = np.zeros((A.shape[0], 1))
     caux[cnt, 0] = vals
@@ -241,18 +248,31 @@ def _controlled_setup(prob, amplitude):
     return kwargs
 
 
+@pytest.mark.parametrize('literal', [True, False])
 @pytest.mark.parametrize('resident', [False, True])
-def test_solve_nse_explicit_controlled_dirichlet(snu, toy_prob, resident):
+def test_solve_nse_explicit_controlled_dirichlet(snu, toy_prob, resident,
+                                                 literal):
     """time-varying controlled Dirichlet values (snu:729-770, 1103-1157):
     step-by-step with the callbacks, and device resident through the per-step
     tables (`bcs_time_only`: rhs table + boundary-value table of the
     convection operator, no host round trip inside a time slice)"""
     mk = _controlled_setup(toy_prob, amplitude=0.3)
-    vo, po, _ = so.solve_nse(**mk())
+    # `literal`: `applybcs` returns zeros as the reference's does (snu:1112
+    # commented out) -- the default of product and oracle; False: the values
+    # are written
+    vo, po, _ = so.solve_nse(write_applybcs=not literal, **mk())
+    vd, pd, _ = so.solve_nse(**mk())
     vg, pg = snu.solve_nse(return_final_vp=True, bcs_time_only=resident,
-                           **mk())
+                           applybcs_literal=literal, **mk())
     assert vg.shape == vo.shape
     assert _rel(vg, vo) <= VTOL and _rel(pg, po) <= PTOL
+    if literal:                              # the defaults ARE the literal form
+        assert np.array_equal(vd, vo) and np.array_equal(pd, po)
+        vgd, pgd = snu.solve_nse(return_final_vp=True,
+                                 bcs_time_only=resident, **mk())
+        assert np.array_equal(vgd, vg) and np.array_equal(pgd, pg)
+    else:                                    # and the two forms do differ
+        assert _rel(vd, vo) > 1e-6
 
 
 def test_solve_nse_time_dependent_forcing(snu, toy_prob):

@@ -104,7 +104,10 @@ def test_solve_nse_explicit_equals_integrator_oracle(toy_prob):
 
 def test_solve_nse_controlled_boundary_restriction(toy_prob):
     """snu:729-770: controlled Dirichlet dofs leave the system; with the
-    control held at its base value the run equals the static one"""
+    control held at its base value AND `applybcs` writing the values (the
+    opt-in `write_applybcs=True`, what snu:1112 evidently meant) the run equals
+    the static one; the reference as it runs (zeros from `applybcs`) loses the
+    stiffness / divergence columns of the controlled dofs and differs"""
     th, stms = toy_prob['th'], toy_prob['stms']
     dbcinds, dbcvals = toy_prob['dbcinds'], toy_prob['dbcvals']
     from dolfin_navier_scipy_amd.fem import condense_sysmatsbybcs
@@ -128,7 +131,15 @@ def test_solve_nse_controlled_boundary_restriction(toy_prob):
         trange=trange, V=th, invinds=inv_s, dbcinds=statinds.tolist(),
         dbcvals=statvals.tolist(), diricontbcinds=[cntinds.tolist()],
         diricontbcvals=[cntvals.tolist()], diricontfuncs=[ufunc],
+        diricontfuncmems=[None], write_applybcs=True)
+    v1l, p1l, _ = so.solve_nse(
+        A=smc_s['A'], M=smc_s['M'], J=smc_s['J'], fv=rhs_s['fv'],
+        fp=rhs_s['fp'], iniv=full0, inip=np.zeros((smc_s['J'].shape[0], 1)),
+        trange=trange, V=th, invinds=inv_s, dbcinds=statinds.tolist(),
+        dbcvals=statvals.tolist(), diricontbcinds=[cntinds.tolist()],
+        diricontbcvals=[cntvals.tolist()], diricontfuncs=[ufunc],
         diricontfuncmems=[None])
+    assert np.linalg.norm(v1l - v1) > 1e-6*np.linalg.norm(v1)
     v2, p2, _ = so.solve_nse(
         A=toy_prob['smc']['A'], M=toy_prob['smc']['M'],
         J=toy_prob['smc']['J'], fv=toy_prob['rhsd']['fv'],
