@@ -79,7 +79,7 @@ class dns_imex_coeffs(ct.Structure):
     _fields_ = [('a_c', ct.c_double), ('a_p', ct.c_double),
                 ('cn_c', ct.c_double), ('cn_o', ct.c_double),
                 ('pscale', ct.c_double), ('extrapolate_x0', ct.c_int32),
-                ('pad', ct.c_int32)]
+                ('carry_residual', ct.c_int32)]
 
 
 # every symbol include/dns_amd.h declares: name -> (restype, argtypes)

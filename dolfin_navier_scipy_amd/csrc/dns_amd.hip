@@ -1436,9 +1436,27 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     dns_solve_opts oo = *o;
     // (eight solves in a row that fell back: stop trying on this system)
     if (gs_fallbacks >= 8 && oo.reorth == 2) oo.reorth = 0;
+    // the tail kernel of EVERY cycle writes the next time step's warm start
+    // (tail_extrap): its coefficients and pointers are baked into the captured
+    // node, so they are part of every cycle's key -- a second cycle captured
+    // while the history was still filling (cubic coefficients) must not be
+    // replayed once it is full (the carry-over front kernel relies on x0
+    // being exactly the combination it computes K x0 for)
+    uint64_t tek = 0x7e;
+    {
+        const double te_c[5] = {tail_extrap.e0, tail_extrap.e1, tail_extrap.e2,
+                                tail_extrap.e3, tail_extrap.e4};
+        for (int i = 0; i < 5; ++i) {
+            uint64_t u;
+            memcpy(&u, &te_c[i], sizeof(u));
+            tek ^= u + 0x9e3779b97f4a7c15ULL + (tek << 6) + (tek >> 2);
+        }
+        tek ^= (uint64_t)(uintptr_t)tail_extrap.out + 0x9e3779b97f4a7c15ULL +
+               (tek << 6) + (tek >> 2);
+    }
     while (true) {
         std::vector<uint64_t> key = {
-            1u, (uint64_t)(uintptr_t)b, (uint64_t)(uintptr_t)x, (uint64_t)c,
+            1u, tek, (uint64_t)(uintptr_t)b, (uint64_t)(uintptr_t)x, (uint64_t)c,
             (uint64_t)oo.reorth, (uint64_t)oo.maxiter, bits_of(oo.rtol),
             bits_of(oo.atol), first ? prologue_key : 0u,
             (uint64_t)popts.cheb_degree, (uint64_t)popts.schur,

@@ -39,6 +39,14 @@ struct dns_imex {
     // `pre_sig` = extrap_sig(nsol, order)
     bool pre_ok = false;
     int pre_sig = -1;
+    // residual carry-over (dns_imex_coeffs.carry_residual, k_step_front MODE 2):
+    // K xs[i] per ring slot and the velocity residual of the previous solve;
+    // `b_valid`: b holds the right-hand side whose solution is xs[cur];
+    // `carry_ok`: kxs[prev..p4] are K times the ring as it stands (primed by
+    // prime_carry or kept current by carry steps)
+    dns::DevBuf<double> kxs[6], rcarry, ckb, ckr;
+    bool b_valid = false, carry_ok = false;
+    int prime_carry(bool zero_r);
     // coefficients of the polynomial warm start from `nsol_` solutions
     static int extrap_coeffs(int nsol_, int order, double e[5]) {
         e[0] = 1.0;
@@ -135,10 +143,11 @@ struct dns_imex {
         long steps_enqueued;
         bool pre_ok;
         int pre_sig;
+        bool b_valid, carry_ok;
     };
     HostState host_state() const {
         return {cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos,
-                steps_enqueued, pre_ok, pre_sig};
+                steps_enqueued, pre_ok, pre_sig, b_valid, carry_ok};
     }
     void set_host_state(const HostState &s) {
         cur = s.cur; prev = s.prev; pprev = s.pprev; p3 = s.p3; p4 = s.p4;
@@ -147,6 +156,8 @@ struct dns_imex {
         steps_enqueued = s.steps_enqueued;
         pre_ok = s.pre_ok;
         pre_sig = s.pre_sig;
+        b_valid = s.b_valid;
+        carry_ok = s.carry_ok;
     }
     std::vector<uint64_t> group_key(const dns_imex_coeffs *cf,
                                     const dns_solve_opts *o, int group) const;

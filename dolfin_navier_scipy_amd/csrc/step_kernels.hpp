@@ -17,10 +17,32 @@
 
 namespace dns {
 
-// PRE: the warm start x0 has been written into `x0` by the previous step's
-// tail kernel (TailExtrap): the K chain gathers that ONE vector (x0 is not
-// stored again)
-template <int LPR, bool PRE>
+// MODE 0: x0 = extrapolation of up to five ring vectors, gathered per entry
+// MODE 1 (PRE): the warm start x0 has been written into `x0` by the previous
+//   step's tail kernel (TailExtrap): the K chain gathers that ONE vector (x0
+//   is not stored again)
+// MODE 2 (PRE + residual carry-over): the K chain gathers the CURRENT solution
+//   x_c instead; K x_c is kept per ring slot (`cr.kx_c`), so that
+//     K x0 = e_c K x_c + e_p K x_p + ...          (row-local, no gather) and
+//     r_c  = b_prev - K x_c                       (the TRUE residual of the
+//                                                  previous step's solve)
+//   cost nothing beyond a few row-local loads.  The velocity part of r_c
+//   (weighted like the state it belongs to: a_c r_c + a_p r_p) is added to
+//   this step's right-hand side.  A Krylov solve stopped after one step leaves
+//   an error delta = K^-1 r of the same sign step after step, which the next
+//   step propagates as R1 delta_v = r_v - JT delta_p - theta dt A delta_v:
+//   carrying r_v cancels the leading term, what is left of a step's error in
+//   the NEXT state is K^-1 [theta dt A delta_v; 0] (small for the smooth
+//   components that would add up) -- the distance to the direct-solve
+//   trajectory stops growing with the number of steps
+//   (scratch/comp_proto.py: 10-20x at 800 steps of the wake at Re = 100).
+struct CarryRef {
+    double *kx_c;                       // out: K x_c (ring slot of x_c)
+    const double *kx_p, *kx_pp, *kx_p3, *kx_p4;
+    double *rprev;                      // in: r of the step before, out: r_c
+};
+
+template <int LPR, int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_step_front(int nconv_blocks,
              // --- convection half
@@ -38,7 +60,9 @@ k_step_front(int nconv_blocks,
              const double *__restrict__ x_pp, const double *__restrict__ x_p3,
              const double *__restrict__ x_p4, double e_c, double e_p,
              double e_pp, double e_p3, double e_p4, double a_c, double a_p,
-             double *x0, double *__restrict__ kx, double *__restrict__ rs) {
+             double *x0, double *__restrict__ kx, double *rs, CarryRef cr) {
+    constexpr bool PRE = MODE == 1;
+    constexpr bool CARRY = MODE == 2;
     if ((int)blockIdx.x < nconv_blocks) {
         if (ncells > 0)
             conv_cells_block(blockIdx.x, ncells, cellmap, glam, area, x_c,
@@ -71,9 +95,24 @@ k_step_front(int nconv_blocks,
             rc = r_colidx[rk];
             rval = r_vals[rk];
         }
+        // carry-over: the row's own entries of the ring of K x products, of the
+        // previous right-hand side and of the previous residual (none of them
+        // depends on the gathers: they go out with the first pass)
+        double h_p = 0.0, h_pp = 0.0, h_p3 = 0.0, h_p4 = 0.0, b_old = 0.0,
+               r_old = 0.0;
+        if (CARRY && sublane == 0) {
+            if (e_p != 0.0) h_p = cr.kx_p[row];
+            if (e_pp != 0.0) h_pp = cr.kx_pp[row];
+            if (e_p3 != 0.0) h_p3 = cr.kx_p3[row];
+            if (e_p4 != 0.0) h_p4 = cr.kx_p4[row];
+            if (isv) b_old = rs[row];   // (the step before left its b here)
+            if (isv && a_p != 0.0) r_old = cr.rprev[row];
+        }
         double ks = 0.0, rsum = 0.0;
         if (k_on && PRE) {
             ks = kval * x0[kc];
+        } else if (k_on && CARRY) {
+            ks = kval * x_c[kc];
         } else if (k_on) {
             double xv = e_c * x_c[kc];
             if (e_p != 0.0) xv = fma(e_p, x_p[kc], xv);
@@ -93,6 +132,10 @@ k_step_front(int nconv_blocks,
                 ks = fma(k_vals[kk], x0[c], ks);
                 continue;
             }
+            if (CARRY) {
+                ks = fma(k_vals[kk], x_c[c], ks);
+                continue;
+            }
             double xv = e_c * x_c[c];
             if (e_p != 0.0) xv = fma(e_p, x_p[c], xv);
             if (e_pp != 0.0) xv = fma(e_pp, x_pp[c], xv);
@@ -109,7 +152,7 @@ k_step_front(int nconv_blocks,
         ks = subwave_sum<LPR>(ks);
         rsum = subwave_sum<LPR>(rsum);
         if (sublane == 0) {
-            if (!PRE) {
+            if (MODE == 0) {
                 double xv = e_c * x_c[row];
                 if (e_p != 0.0) xv = fma(e_p, x_p[row], xv);
                 if (e_pp != 0.0) xv = fma(e_pp, x_pp[row], xv);
@@ -117,8 +160,23 @@ k_step_front(int nconv_blocks,
                 if (e_p4 != 0.0) xv = fma(e_p4, x_p4[row], xv);
                 x0[row] = xv;
             }
-            kx[row] = ks;
-            if (isv) rs[row] = rsum;
+            if (CARRY) {
+                cr.kx_c[row] = ks;                   // K x_c, kept
+                double k0 = e_c * ks;                // K x0 by linearity
+                k0 = fma(e_p, h_p, k0);
+                k0 = fma(e_pp, h_pp, k0);
+                k0 = fma(e_p3, h_p3, k0);
+                k0 = fma(e_p4, h_p4, k0);
+                kx[row] = k0;
+                if (isv) {
+                    const double r_c = b_old - ks;   // true residual, step k-1
+                    cr.rprev[row] = r_c;
+                    rs[row] = rsum + fma(a_c, r_c, a_p * r_old);
+                }
+            } else {
+                kx[row] = ks;
+                if (isv) rs[row] = rsum;
+            }
         }
     }
 }
@@ -192,9 +250,9 @@ k_step_back(int n, int nv, double *__restrict__ nfc_c,
 // block -- eight hipMemcpyAsync + two hipMemsetAsync cost the host ~50 us per
 // batch, which a 20-step window sees.
 struct CopyList {
-    const double *src[8];
-    double *dst[8];
-    int n[8];
+    const double *src[12];
+    double *dst[12];
+    int n[12];
     int count;
 };
 

@@ -263,10 +263,16 @@ class ImexStepper(object):
         return pos.value, left.value
 
     @staticmethod
-    def coeffs(a_c=1., a_p=0., cn_c=0., cn_o=0., pscale=1., extrapolate=True):
+    def coeffs(a_c=1., a_p=0., cn_c=0., cn_o=0., pscale=1., extrapolate=True,
+               carry_residual=True):
+        """`carry_residual`: the velocity residual of a step's inexact solve
+        goes into the next step's right-hand side (include/dns_amd.h): the
+        distance to the direct-solve trajectory stays at the size of ONE
+        solve's error instead of adding up step after step"""
         return C.dns_imex_coeffs(a_c=a_c, a_p=a_p, cn_c=cn_c, cn_o=cn_o,
                                  pscale=pscale,
-                                 extrapolate_x0=int(extrapolate), pad=0)
+                                 extrapolate_x0=int(extrapolate),
+                                 carry_residual=int(bool(carry_residual)))
 
     def step(self, cf, nfc_new=None, opts=None, raise_on_fail=True):
         o = solve_opts() if opts is None else opts

@@ -30,7 +30,7 @@ __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 SOLVER = dict(method='gmres', rtol=1e-12, maxiter=400, restart=60,
               cheb_degree=6, drop_tol=1e-3, factorization='full', reorth=2,
               schur='auto', extrapolate=4, device=0, check_every=2,
-              use_graph=True)
+              use_graph=True, carry_residual=True)
 
 
 def _checkuniformgrid(trange):
@@ -194,7 +194,8 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
     system, opts = _device_system((M + .5*dt*A).tocsr(), J, prm)
     stepper = ImexStepper(system, (M - .5*dt*A).tocsr())
     cf = ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
-                            pscale=scalep/dt, extrapolate=prm['extrapolate'])
+                            pscale=scalep/dt, extrapolate=prm['extrapolate'],
+                            carry_residual=prm['carry_residual'])
     stepper.set_state(v_n, ptilde_c=p_n*dt/scalep, nfc_c=nfc_c)
     rsd = dict(resident or {})
     statvals = list(rsd.get('static_dbcvals', []) or [])
@@ -309,7 +310,8 @@ def sbdftwo(trange=None, inivel=None, inip=None, bcs_ini=[],
     system, opts = _device_system((M + 2./3*dt*A).tocsr(), J, prm)
     stepper = ImexStepper(system, M)
     cf = ImexStepper.coeffs(a_c=4./3, a_p=-1./3, cn_c=4./3*dt, cn_o=-2./3*dt,
-                            pscale=scalep/dt, extrapolate=prm['extrapolate'])
+                            pscale=scalep/dt, extrapolate=prm['extrapolate'],
+                            carry_residual=prm['carry_residual'])
     stepper.set_state(v_n, v_p=v_c, ptilde_c=p_n*dt/scalep, nfc_c=nfc_c)
     ffflag = 0
     try:
@@ -355,7 +357,8 @@ def semi_implicit_euler(iniv=None, jmat=None, mmat=None, amat=None, rhsv=None,
     system, opts = _device_system((mmat + dt*amat).tocsr(), jmat, prm)
     stepper = ImexStepper(system, mmat)
     cf = ImexStepper.coeffs(a_c=1., a_p=0., cn_c=dt, cn_o=0., pscale=1.,
-                            extrapolate=prm['extrapolate'])
+                            extrapolate=prm['extrapolate'],
+                            carry_residual=prm['carry_residual'])
     stepper.set_state(iniv)
     stepper.set_rhs(np.zeros((NV, 1)), fpz)
     out = [iniv]

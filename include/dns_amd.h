@@ -270,7 +270,14 @@ typedef struct dns_imex_coeffs {
                                     2: 3 x_c - 3 x_p + x_pp (quadratic),
                                     3: 4 x_c - 6 x_p + 4 x_pp - x_ppp (cubic),
                                     4: 5, -10, 10, -5, 1 (quartic)            */
-    int32_t pad;
+    int32_t carry_residual;      /* 1: the velocity residual b - K x of a step's
+                                    (inexact) solve is added to the next
+                                    step's right-hand side, so that the
+                                    distance to the direct-solve trajectory
+                                    does not grow with the number of steps
+                                    (pipelined GMRES steps of dns_imex_run on
+                                    one GPU below the streaming threshold;
+                                    ignored elsewhere)                       */
 } dns_imex_coeffs;
 
 int dns_imex_create(dns_saddle *sys, const dns_csr *r1, dns_imex **out);
