@@ -13,7 +13,7 @@ GPU raises.
 
 Differences to a sparse direct solve, by construction: the answer is the
 limit of a block-preconditioned Krylov iteration, stopped at
-`||K x - b|| <= tol * ||b||` (`tol` from `krpslvprms['tol']`, default 1e-12
+`||K x - b|| <= tol * ||b||` (`tol` from `krpslvprms['tol']`, default 1e-13
 when `krylov` is None, i.e. where the reference would factorise).
 """
 import hashlib
@@ -27,7 +27,7 @@ from .saddle import SaddleSystem, solve_opts
 __all__ = ['solve_sadpnt_smw', 'app_prj_via_sadpnt', 'apply_massinv',
            'SpslaKrylovCounter', 'clear_cache', 'DEFAULTS']
 
-DEFAULTS = dict(direct_tol=1e-12, maxiter=3000, restart=60, cheb_degree=6,
+DEFAULTS = dict(direct_tol=1e-13, maxiter=3000, restart=60, cheb_degree=6,
                 factorization='full', schur='auto', schur_dense_max=6000,
                 refresh_tol=0.1, device=0, cache_size=4)
 

@@ -27,7 +27,10 @@ from .saddle import SaddleSystem, ImexStepper, solve_opts
 __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 
 # solver settings of the time loops; `rtol` is relative to ||rhs||
-SOLVER = dict(method='gmres', rtol=1e-12, maxiter=400, restart=60,
+# (1e-13: BASELINE config 5 adds a Robin penalty of 1/alpha = 1e5 to A, which
+# inflates ||rhs||; its pressure meets 1e-8 against the direct solve at 1e-13
+# (1.7e-10), not at 1e-12 (1e-8) -- tests/test_gpu_config5.py)
+SOLVER = dict(method='gmres', rtol=1e-13, maxiter=400, restart=60,
               cheb_degree=6, drop_tol=1e-3, factorization='full', reorth=2,
               schur='auto', extrapolate=4, device=0, check_every=2,
               use_graph=True, carry_residual=True)

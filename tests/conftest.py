@@ -10,6 +10,11 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
+# a fatal glibc diagnostic (heap consistency check, abort message) goes to
+# /dev/tty unless this is set -- an abort in the native library must leave its
+# message in the captured stderr
+os.environ.setdefault('LIBC_FATAL_STDERR_', '1')
+
 
 def pytest_configure(config):
     config.addinivalue_line(
