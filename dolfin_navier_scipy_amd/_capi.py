@@ -16,6 +16,7 @@ LIBPATH = os.path.join(HERE, 'csrc', 'libdnsamd.so')
 
 DNS_OK, DNS_NOT_CONVERGED, DNS_BREAKDOWN = 0, 1, 2
 DNS_ERR_HIP, DNS_ERR_BAD_ARGUMENT, DNS_ERR_NOT_READY, DNS_ERR_COMM = 3, 4, 5, 6
+DNS_ERR_HOST = 7
 DNS_METHOD_GMRES, DNS_METHOD_BICGSTAB = 0, 1
 DNS_SCHUR_DENSE, DNS_SCHUR_JACOBI = 0, 1
 DNS_SPMV_VECTOR, DNS_SPMV_STREAM = 0, 1

@@ -1,5 +1,7 @@
 // Shared host-side plumbing for the gfx950 saddle-point library.
 #pragma once
+#include <exception>
+#include <new>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -26,6 +28,21 @@ inline int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_last_error = buf;
     return code;
+}
+
+// the C-ABI is an exception barrier: `body` (a lambda returning a status) runs
+// inside try/catch, a C++ exception becomes DNS_ERR_HOST with its message
+template <typename Body>
+inline int guarded(Body body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(DNS_ERR_HOST, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(DNS_ERR_HOST, "host-side exception: %s", e.what());
+    } catch (...) {
+        return fail(DNS_ERR_HOST, "host-side exception");
+    }
 }
 
 #define DNS_HIP(call)                                                        \

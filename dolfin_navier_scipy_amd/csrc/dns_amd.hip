@@ -1655,13 +1655,14 @@ const char *dns_status_string(int status) {
         case DNS_ERR_BAD_ARGUMENT: return "bad argument";
         case DNS_ERR_NOT_READY: return "not ready";
         case DNS_ERR_COMM: return "communication error";
+        case DNS_ERR_HOST: return "host-side failure";
         default: return "unknown status";
     }
 }
 
 const char *dns_last_error(void) { return g_last_error.c_str(); }
 
-int dns_device_count(int *count) {
+static int dns_device_count_impl(int *count) {
     if (!count) return fail(DNS_ERR_BAD_ARGUMENT, "null count");
     int c = 0;
     hipError_t e = hipGetDeviceCount(&c);
@@ -1674,7 +1675,11 @@ int dns_device_count(int *count) {
     return DNS_OK;
 }
 
-int dns_device_name(int device, char *buf, size_t buflen) {
+int dns_device_count(int *count) {
+    return dns::guarded([&]() -> int { return dns_device_count_impl(count); });
+}
+
+static int dns_device_name_impl(int device, char *buf, size_t buflen) {
     if (!buf || buflen == 0) return fail(DNS_ERR_BAD_ARGUMENT, "null buffer");
     hipDeviceProp_t prop;
     DNS_HIP(hipGetDeviceProperties(&prop, device));
@@ -1683,10 +1688,18 @@ int dns_device_name(int device, char *buf, size_t buflen) {
     return DNS_OK;
 }
 
-int dns_device_synchronize(int device) {
+int dns_device_name(int device, char *buf, size_t buflen) {
+    return dns::guarded([&]() -> int { return dns_device_name_impl(device, buf, buflen); });
+}
+
+static int dns_device_synchronize_impl(int device) {
     DNS_HIP(hipSetDevice(device));
     DNS_HIP(hipDeviceSynchronize());
     return DNS_OK;
+}
+
+int dns_device_synchronize(int device) {
+    return dns::guarded([&]() -> int { return dns_device_synchronize_impl(device); });
 }
 
 void dns_default_precond_opts(dns_precond_opts *o) {
@@ -1714,7 +1727,7 @@ void dns_default_solve_opts(dns_solve_opts *o) {
     o->use_graph = 0;
 }
 
-int dns_saddle_create(int device, const dns_csr *f, const dns_csr *j,
+static int dns_saddle_create_impl(int device, const dns_csr *f, const dns_csr *j,
                       const dns_csr *jt, dns_saddle **out) {
     if (!out) return fail(DNS_ERR_BAD_ARGUMENT, "null output handle");
     *out = nullptr;
@@ -1729,6 +1742,11 @@ int dns_saddle_create(int device, const dns_csr *f, const dns_csr *j,
     return DNS_OK;
 }
 
+int dns_saddle_create(int device, const dns_csr *f, const dns_csr *j,
+                      const dns_csr *jt, dns_saddle **out) {
+    return dns::guarded([&]() -> int { return dns_saddle_create_impl(device, f, j, jt, out); });
+}
+
 void dns_saddle_destroy(dns_saddle *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -1736,12 +1754,16 @@ void dns_saddle_destroy(dns_saddle *h) {
     delete h;
 }
 
-int dns_saddle_update_values(dns_saddle *h, const double *f_vals) {
+static int dns_saddle_update_values_impl(dns_saddle *h, const double *f_vals) {
     if (!h || !f_vals) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     return h->update_values(f_vals);
 }
 
-int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
+int dns_saddle_update_values(dns_saddle *h, const double *f_vals) {
+    return dns::guarded([&]() -> int { return dns_saddle_update_values_impl(h, f_vals); });
+}
+
+static int dns_saddle_set_schur_mg_impl(dns_saddle *h, int32_t nprol, const dns_csr *prol,
                             int32_t smooth_steps) {
     if (!h || nprol < 0 || (nprol > 0 && !prol) || smooth_steps < 1 ||
         smooth_steps > 8)
@@ -1767,12 +1789,21 @@ int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
     return DNS_OK;
 }
 
-int dns_saddle_setup_precond(dns_saddle *h, const dns_precond_opts *opts) {
+int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
+                            int32_t smooth_steps) {
+    return dns::guarded([&]() -> int { return dns_saddle_set_schur_mg_impl(h, nprol, prol, smooth_steps); });
+}
+
+static int dns_saddle_setup_precond_impl(dns_saddle *h, const dns_precond_opts *opts) {
     if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "null handle");
     return h->setup_precond(opts);
 }
 
-int dns_saddle_solve(dns_saddle *h, const double *rhs_v, const double *rhs_p,
+int dns_saddle_setup_precond(dns_saddle *h, const dns_precond_opts *opts) {
+    return dns::guarded([&]() -> int { return dns_saddle_setup_precond_impl(h, opts); });
+}
+
+static int dns_saddle_solve_impl(dns_saddle *h, const double *rhs_v, const double *rhs_p,
                      const double *x0, double *out_vp,
                      const dns_solve_opts *opts, dns_solve_stats *stats) {
     if (!h || !rhs_v || !out_vp)
@@ -1805,7 +1836,13 @@ int dns_saddle_solve(dns_saddle *h, const double *rhs_v, const double *rhs_p,
     return DNS_OK;
 }
 
-int dns_saddle_residual_history(dns_saddle *h, double *out, int32_t cap,
+int dns_saddle_solve(dns_saddle *h, const double *rhs_v, const double *rhs_p,
+                     const double *x0, double *out_vp,
+                     const dns_solve_opts *opts, dns_solve_stats *stats) {
+    return dns::guarded([&]() -> int { return dns_saddle_solve_impl(h, rhs_v, rhs_p, x0, out_vp, opts, stats); });
+}
+
+static int dns_saddle_residual_history_impl(dns_saddle *h, double *out, int32_t cap,
                                 int32_t *count) {
     if (!h || !count) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     const int32_t nh = (int32_t)h->history.size();
@@ -1815,7 +1852,12 @@ int dns_saddle_residual_history(dns_saddle *h, double *out, int32_t cap,
     return DNS_OK;
 }
 
-int dns_saddle_apply(dns_saddle *h, const double *x, double *y) {
+int dns_saddle_residual_history(dns_saddle *h, double *out, int32_t cap,
+                                int32_t *count) {
+    return dns::guarded([&]() -> int { return dns_saddle_residual_history_impl(h, out, cap, count); });
+}
+
+static int dns_saddle_apply_impl(dns_saddle *h, const double *x, double *y) {
     if (!h || !x || !y) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     DNS_HIP(hipSetDevice(h->device));
     DNS_TRY(h->xdev.upload(x, (size_t)h->n, h->stream));
@@ -1826,7 +1868,11 @@ int dns_saddle_apply(dns_saddle *h, const double *x, double *y) {
     return DNS_OK;
 }
 
-int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
+int dns_saddle_apply(dns_saddle *h, const double *x, double *y) {
+    return dns::guarded([&]() -> int { return dns_saddle_apply_impl(h, x, y); });
+}
+
+static int dns_saddle_apply_precond_impl(dns_saddle *h, const double *r, double *z) {
     if (!h || !r || !z) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     if (!h->precond_ready)
         return fail(DNS_ERR_NOT_READY, "preconditioner not set up");
@@ -1839,7 +1885,11 @@ int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
     return DNS_OK;
 }
 
-int dns_comm_unique_id(char *out) {
+int dns_saddle_apply_precond(dns_saddle *h, const double *r, double *z) {
+    return dns::guarded([&]() -> int { return dns_saddle_apply_precond_impl(h, r, z); });
+}
+
+static int dns_comm_unique_id_impl(char *out) {
     if (!out) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     static_assert(sizeof(ncclUniqueId) <= DNS_UNIQUE_ID_BYTES, "id size");
     ncclUniqueId id;
@@ -1851,7 +1901,11 @@ int dns_comm_unique_id(char *out) {
     return DNS_OK;
 }
 
-int dns_comm_create_rccl(int device, int32_t nranks, int32_t rank,
+int dns_comm_unique_id(char *out) {
+    return dns::guarded([&]() -> int { return dns_comm_unique_id_impl(out); });
+}
+
+static int dns_comm_create_rccl_impl(int device, int32_t nranks, int32_t rank,
                          const char *uid, dns_comm **out) {
     if (!out || !uid || nranks < 1 || rank < 0 || rank >= nranks)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
@@ -1874,7 +1928,12 @@ int dns_comm_create_rccl(int device, int32_t nranks, int32_t rank,
     return DNS_OK;
 }
 
-int dns_comm_create_callbacks(int device, int32_t nranks, int32_t rank,
+int dns_comm_create_rccl(int device, int32_t nranks, int32_t rank,
+                         const char *uid, dns_comm **out) {
+    return dns::guarded([&]() -> int { return dns_comm_create_rccl_impl(device, nranks, rank, uid, out); });
+}
+
+static int dns_comm_create_callbacks_impl(int device, int32_t nranks, int32_t rank,
                               dns_allreduce_cb allreduce,
                               dns_allgatherv_cb allgatherv, void *ctx,
                               dns_comm **out) {
@@ -1893,16 +1952,27 @@ int dns_comm_create_callbacks(int device, int32_t nranks, int32_t rank,
     return DNS_OK;
 }
 
+int dns_comm_create_callbacks(int device, int32_t nranks, int32_t rank,
+                              dns_allreduce_cb allreduce,
+                              dns_allgatherv_cb allgatherv, void *ctx,
+                              dns_comm **out) {
+    return dns::guarded([&]() -> int { return dns_comm_create_callbacks_impl(device, nranks, rank, allreduce, allgatherv, ctx, out); });
+}
+
 void dns_comm_destroy(dns_comm *c) { delete c; }
 
-int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather) {
+static int dns_comm_stats_impl(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather) {
     if (!c) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     if (n_allreduce) *n_allreduce = c->n_allreduce;
     if (n_allgather) *n_allgather = c->n_allgather;
     return DNS_OK;
 }
 
-int dns_saddle_set_comm(dns_saddle *h, dns_comm *c) {
+int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather) {
+    return dns::guarded([&]() -> int { return dns_comm_stats_impl(c, n_allreduce, n_allgather); });
+}
+
+static int dns_saddle_set_comm_impl(dns_saddle *h, dns_comm *c) {
     if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "null handle");
     h->drop_graphs();
     DNS_HIP(hipSetDevice(h->device));
@@ -1917,7 +1987,11 @@ int dns_saddle_set_comm(dns_saddle *h, dns_comm *c) {
     return DNS_OK;
 }
 
-int dns_partition_range(int32_t n, int32_t nranks, int32_t rank,
+int dns_saddle_set_comm(dns_saddle *h, dns_comm *c) {
+    return dns::guarded([&]() -> int { return dns_saddle_set_comm_impl(h, c); });
+}
+
+static int dns_partition_range_impl(int32_t n, int32_t nranks, int32_t rank,
                         int32_t *start, int32_t *end) {
     if (!start || !end || n < 0 || nranks < 1 || rank < 0 || rank >= nranks)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
@@ -1927,21 +2001,34 @@ int dns_partition_range(int32_t n, int32_t nranks, int32_t rank,
     return DNS_OK;
 }
 
-int dns_device_read(int device, const void *dev, void *host, size_t bytes) {
+int dns_partition_range(int32_t n, int32_t nranks, int32_t rank,
+                        int32_t *start, int32_t *end) {
+    return dns::guarded([&]() -> int { return dns_partition_range_impl(n, nranks, rank, start, end); });
+}
+
+static int dns_device_read_impl(int device, const void *dev, void *host, size_t bytes) {
     if (!dev || !host) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     DNS_HIP(hipSetDevice(device));
     DNS_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
     return DNS_OK;
 }
 
-int dns_device_write(int device, void *dev, const void *host, size_t bytes) {
+int dns_device_read(int device, const void *dev, void *host, size_t bytes) {
+    return dns::guarded([&]() -> int { return dns_device_read_impl(device, dev, host, bytes); });
+}
+
+static int dns_device_write_impl(int device, void *dev, const void *host, size_t bytes) {
     if (!dev || !host) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     DNS_HIP(hipSetDevice(device));
     DNS_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
     return DNS_OK;
 }
 
-int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
+int dns_device_write(int device, void *dev, const void *host, size_t bytes) {
+    return dns::guarded([&]() -> int { return dns_device_write_impl(device, dev, host, bytes); });
+}
+
+static int dns_saddle_probe_impl(dns_saddle *h, int32_t which, int32_t chain,
                      int32_t reps, double *us_per_launch) {
     if (!h || !us_per_launch || chain < 1 || reps < 1)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
@@ -2085,14 +2172,23 @@ int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
     return DNS_OK;
 }
 
-int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi) {
+int dns_saddle_probe(dns_saddle *h, int32_t which, int32_t chain,
+                     int32_t reps, double *us_per_launch) {
+    return dns::guarded([&]() -> int { return dns_saddle_probe_impl(h, which, chain, reps, us_per_launch); });
+}
+
+static int dns_saddle_cheb_bounds_impl(dns_saddle *h, double *lo, double *hi) {
     if (!h || !lo || !hi) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     *lo = h->lam_lo;
     *hi = h->lam_hi;
     return DNS_OK;
 }
 
-int dns_saddle_precond_info(dns_saddle *h, int32_t cap, int64_t *out,
+int dns_saddle_cheb_bounds(dns_saddle *h, double *lo, double *hi) {
+    return dns::guarded([&]() -> int { return dns_saddle_cheb_bounds_impl(h, lo, hi); });
+}
+
+static int dns_saddle_precond_info_impl(dns_saddle *h, int32_t cap, int64_t *out,
                             int32_t *count) {
     if (!h || !count) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     if (!h->precond_ready)
@@ -2125,6 +2221,11 @@ int dns_saddle_precond_info(dns_saddle *h, int32_t cap, int64_t *out,
     return DNS_OK;
 }
 
+int dns_saddle_precond_info(dns_saddle *h, int32_t cap, int64_t *out,
+                            int32_t *count) {
+    return dns::guarded([&]() -> int { return dns_saddle_precond_info_impl(h, cap, out, count); });
+}
+
 // ---- standalone kernels ----------------------------------------------------
 struct ScopedStream {
     hipStream_t s = nullptr;
@@ -2133,7 +2234,7 @@ struct ScopedStream {
     }
 };
 
-int dns_spmv(int device, const dns_csr *a, const double *x, double *y,
+static int dns_spmv_impl(int device, const dns_csr *a, const double *x, double *y,
              double alpha, double beta, int32_t variant) {
     DNS_TRY(check_csr(a, "A"));
     if (!x || !y) return fail(DNS_ERR_BAD_ARGUMENT, "null vector");
@@ -2155,7 +2256,12 @@ int dns_spmv(int device, const dns_csr *a, const double *x, double *y,
     return DNS_OK;
 }
 
-int dns_dot(int device, int64_t n, const double *x, const double *y,
+int dns_spmv(int device, const dns_csr *a, const double *x, double *y,
+             double alpha, double beta, int32_t variant) {
+    return dns::guarded([&]() -> int { return dns_spmv_impl(device, a, x, y, alpha, beta, variant); });
+}
+
+static int dns_dot_impl(int device, int64_t n, const double *x, const double *y,
             double *out) {
     if (!x || !y || !out || n < 0)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
@@ -2179,7 +2285,12 @@ int dns_dot(int device, int64_t n, const double *x, const double *y,
     return DNS_OK;
 }
 
-int dns_axpy(int device, int64_t n, double a, const double *x, double *y) {
+int dns_dot(int device, int64_t n, const double *x, const double *y,
+            double *out) {
+    return dns::guarded([&]() -> int { return dns_dot_impl(device, n, x, y, out); });
+}
+
+static int dns_axpy_impl(int device, int64_t n, double a, const double *x, double *y) {
     if (!x || !y || n < 0) return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
     DNS_HIP(hipSetDevice(device));
     ScopedStream ss;
@@ -2197,7 +2308,11 @@ int dns_axpy(int device, int64_t n, double a, const double *x, double *y) {
     return DNS_OK;
 }
 
-int dns_gemv(int device, int32_t n, const double *a_rowmajor, const double *x,
+int dns_axpy(int device, int64_t n, double a, const double *x, double *y) {
+    return dns::guarded([&]() -> int { return dns_axpy_impl(device, n, a, x, y); });
+}
+
+static int dns_gemv_impl(int device, int32_t n, const double *a_rowmajor, const double *x,
              double *y, double alpha) {
     if (!a_rowmajor || !x || !y || n < 0)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
@@ -2220,7 +2335,12 @@ int dns_gemv(int device, int32_t n, const double *a_rowmajor, const double *x,
     return DNS_OK;
 }
 
-int dns_dense_inverse(int device, int32_t n, double *a_rowmajor) {
+int dns_gemv(int device, int32_t n, const double *a_rowmajor, const double *x,
+             double *y, double alpha) {
+    return dns::guarded([&]() -> int { return dns_gemv_impl(device, n, a_rowmajor, x, y, alpha); });
+}
+
+static int dns_dense_inverse_impl(int device, int32_t n, double *a_rowmajor) {
     if (!a_rowmajor || n < 1)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
     DNS_HIP(hipSetDevice(device));
@@ -2236,7 +2356,11 @@ int dns_dense_inverse(int device, int32_t n, double *a_rowmajor) {
     return DNS_OK;
 }
 
-int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
+int dns_dense_inverse(int device, int32_t n, double *a_rowmajor) {
+    return dns::guarded([&]() -> int { return dns_dense_inverse_impl(device, n, a_rowmajor); });
+}
+
+static int dns_spmv_bench_impl(int device, const dns_csr *a, int32_t variant, int32_t reps,
                    int32_t warmup, double *avg_seconds, double *checksum) {
     DNS_TRY(check_csr(a, "A"));
     if (!avg_seconds || reps < 1)
@@ -2280,10 +2404,15 @@ int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
     return DNS_OK;
 }
 
+int dns_spmv_bench(int device, const dns_csr *a, int32_t variant, int32_t reps,
+                   int32_t warmup, double *avg_seconds, double *checksum) {
+    return dns::guarded([&]() -> int { return dns_spmv_bench_impl(device, a, variant, reps, warmup, avg_seconds, checksum); });
+}
+
 // y = K x through the pair format (pair.hpp); DNS_ERR_BAD_ARGUMENT for odd
 // sizes.  reps > 0: timed like dns_spmv_bench
 // (HIP events on the launch stream), *avg_seconds = seconds per launch
-int dns_spmv_pair(int device, const dns_csr *k, int32_t nv, const double *x,
+static int dns_spmv_pair_impl(int device, const dns_csr *k, int32_t nv, const double *x,
                   double *y, int32_t reps, int32_t warmup, double *avg_seconds,
                   int64_t *format_bytes) {
     DNS_TRY(check_csr(k, "K"));
@@ -2334,7 +2463,13 @@ int dns_spmv_pair(int device, const dns_csr *k, int32_t nv, const double *x,
     return DNS_OK;
 }
 
-int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
+int dns_spmv_pair(int device, const dns_csr *k, int32_t nv, const double *x,
+                  double *y, int32_t reps, int32_t warmup, double *avg_seconds,
+                  int64_t *format_bytes) {
+    return dns::guarded([&]() -> int { return dns_spmv_pair_impl(device, k, nv, x, y, reps, warmup, avg_seconds, format_bytes); });
+}
+
+static int dns_hbm_probe_impl(int device, int64_t bytes, int32_t kind, int32_t reps,
                   double *gbytes_per_s) {
     if (!gbytes_per_s || reps < 1 || bytes < 4096 || kind < 0 || kind > 8)
         return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
@@ -2393,6 +2528,11 @@ int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
     DNS_HIP(hipGetLastError());
     *gbytes_per_s = (double)(16 * n2 * narr) * reps / (1e-3 * ms) * 1e-9;
     return DNS_OK;
+}
+
+int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
+                  double *gbytes_per_s) {
+    return dns::guarded([&]() -> int { return dns_hbm_probe_impl(device, bytes, kind, reps, gbytes_per_s); });
 }
 
 }  // extern "C"

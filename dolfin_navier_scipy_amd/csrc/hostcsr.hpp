@@ -4,10 +4,49 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <exception>
 #include <thread>
 #include <vector>
 
 #include "../../include/dns_amd.h"
+
+// fn(0) .. fn(nt-1) on host threads.  A thread that cannot be created (EAGAIN
+// under a task limit shared with other processes of the user) must not take
+// the process down -- std::thread's constructor throws, and unwinding past
+// joinable threads is std::terminate: its share runs on the calling thread
+// instead; every started thread is joined; an exception out of `fn` (a
+// std::bad_alloc of a worker's scratch vectors) is rethrown by the caller
+// after the join.
+template <typename Fn>
+inline void dns_run_threads(int nt, Fn fn) {
+    if (nt <= 1) {
+        fn(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err((size_t)nt);
+    auto guarded = [&](int t) {
+        try {
+            fn(t);
+        } catch (...) {
+            err[(size_t)t] = std::current_exception();
+        }
+    };
+    th.reserve((size_t)nt);
+    std::vector<int> inline_work;
+    for (int t = 1; t < nt; ++t) {
+        try {
+            th.emplace_back(guarded, t);
+        } catch (...) {
+            inline_work.push_back(t);
+        }
+    }
+    guarded(0);
+    for (int t : inline_work) guarded(t);
+    for (auto &x : th) x.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+}
 
 namespace dns {
 
@@ -106,17 +145,9 @@ inline HostCsr host_spgemm(const HostCsr &A, const HostCsr &B) {
         start[t] = std::max(start[t], start[t - 1]);
     }
     start[nt] = A.nrows;
-    if (nt == 1) {
-        host_spgemm_rows(A, B, 0, A.nrows, rl[0], cis[0], vas[0]);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t)
-            th.emplace_back([&, t]() {
-                host_spgemm_rows(A, B, start[t], start[t + 1], rl[t], cis[t],
-                                 vas[t]);
-            });
-        for (auto &x : th) x.join();
-    }
+    dns_run_threads(nt, [&](int t) {
+        host_spgemm_rows(A, B, start[t], start[t + 1], rl[t], cis[t], vas[t]);
+    });
     size_t total = 0;
     for (int t = 0; t < nt; ++t) total += cis[t].size();
     C.colidx.reserve(total);
@@ -265,13 +296,7 @@ inline HostCsr host_cheb_poly(const HostCsr &DF, const std::vector<double> &dv,
             rl[t][i - r0] = cnt;
         }
     };
-    if (nt == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
-        for (auto &q : th) q.join();
-    }
+    dns_run_threads(nt, work);
     size_t total = 0;
     for (int t = 0; t < nt; ++t) total += cis[t].size();
     G.colidx.reserve(total);

@@ -255,6 +255,9 @@ struct PairDev {
             }
             nentA = (int64_t)ne;
             DNS_TRY(up_d(vA, soa));
+            // `soa` dies with this block: an asynchronous copy out of a freed
+            // (and possibly unmapped) host buffer is a GPU memory fault
+            DNS_HIP(hipStreamSynchronize(s));
         }
         DNS_TRY(up_d(vB, P.vB));
         DNS_TRY(up_d(vC, P.vC));

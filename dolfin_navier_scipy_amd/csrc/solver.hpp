@@ -116,6 +116,9 @@ inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
             DNS_TRY(c16base.alloc(bases.size()));
             DNS_TRY(c16.upload(cc.data(), cc.size(), s));
             DNS_TRY(c16base.upload(bases.data(), bases.size(), s));
+            // `cc`, `bases` die with this block: an asynchronous copy out of a
+            // freed (and possibly unmapped) host buffer is a GPU memory fault
+            DNS_HIP(hipStreamSynchronize(s));
         }
         DNS_HIP(hipStreamSynchronize(s));       // `rb` is a loop temporary
     }

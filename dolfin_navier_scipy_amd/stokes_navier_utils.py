@@ -499,16 +499,17 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
                    solver=solver)
         if time_int_scheme == 'cnab':
             icd.update(f_tvdp=fvtvd)
-            static_bcs = len(loccnt) == 0
-            if cvop is not None and (static_bcs or bcs_time_only):
-                # the loop may evaluate N(v)v itself and, the callbacks being
-                # functions of the time only, run whole time slices resident
-                icd.update(device_convection=cvop, invinds=dbcnt,
-                           resident=dict(
-                               bcs_time_only=bcs_time_only,
-                               static_dbcvals=list(dbcvals),
-                               savevp_times=(None if return_vp_dict
-                                             else list(datatrange))))
+        static_bcs = len(loccnt) == 0
+        if cvop is not None and (static_bcs or bcs_time_only):
+            # the loop may evaluate N(v)v itself and, the callbacks being
+            # functions of the time only, run whole time slices resident
+            # (CNAB and SBDF2 alike)
+            icd.update(device_convection=cvop, invinds=dbcnt,
+                       resident=dict(
+                           bcs_time_only=bcs_time_only,
+                           static_dbcvals=list(dbcvals),
+                           savevp_times=(None if return_vp_dict
+                                         else list(datatrange))))
         v_end, p_end, ffflag = timintsc(trange=trange, inip=inip, scalep=-1.,
                                         g_tdp=rhsp, bcs_ini=inicdbcvals,
                                         check_ff_maxv=check_ff_maxv, **icd)

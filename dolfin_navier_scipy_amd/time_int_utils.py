@@ -290,12 +290,21 @@ def sbdftwo(trange=None, inivel=None, inip=None, bcs_ini=[],
             check_ff=False, check_ff_maxv=None, scalep=-1.,
             getbcs=None, applybcs=None, appndbcs=None, savevp=None,
             dynamic_rhs=None, dynamic_rhs_memory={},
-            ntimeslices=10, verbose=True, solver=None):
+            ntimeslices=10, verbose=True, solver=None,
+            device_convection=None, invinds=None, resident=None):
     """SBDF2 on the GPU (reference tiu:260-355, quirks kept: pressure scaled
-    by `1/dt`, blow-up guard on the previous velocity)"""
+    by `1/dt`, blow-up guard on the previous velocity)
+
+    `device_convection`, `invinds`, `resident`: as in `cnab` -- `-N(v)v` from
+    the device operator, and whole time slices without a host round trip per
+    step when the callbacks depend on the time only (rhs / boundary-value
+    tables)."""
     prm = _solver_settings(solver)
+    state_dependent = dynamic_rhs is not None
     dt, listofts = _inittimegrid(trange, ntimeslices=ntimeslices)
     NP, NV = J.shape
+    if device_convection is not None and f_vdp is None:
+        f_vdp = device_convection.host_callback(invinds)   # Heun start only
     dynamic_rhs, f_vdp = _wrap_callbacks(NV, dynamic_rhs, None, f_vdp)
     dfv_c, drm = dynamic_rhs(trange[0], vc=inivel, memory=dynamic_rhs_memory,
                              mode='init')
@@ -316,6 +325,18 @@ def sbdftwo(trange=None, inivel=None, inip=None, bcs_ini=[],
                             pscale=scalep/dt, extrapolate=prm['extrapolate'],
                             carry_residual=prm['carry_residual'])
     stepper.set_state(v_n, v_p=v_c, ptilde_c=p_n*dt/scalep, nfc_c=nfc_c)
+    rsd = dict(resident or {})
+    statvals = list(rsd.get('static_dbcvals', []) or [])
+    moving = len(bcs_ini) > 0
+    if device_convection is not None:
+        stepper.set_convection(device_convection, scale=-1.0)
+        if moving or statvals:
+            device_convection.set_dbcvals(statvals + list(bcs_n))
+    on_device = (device_convection is not None and resident is not None
+                 and not state_dependent
+                 and (not moving or rsd.get('bcs_time_only', False)))
+    savetimes = rsd.get('savevp_times', None)
+    savetimes = None if savetimes is None else set(savetimes)
     ffflag = 0
     try:
         for kck, ctrange in enumerate(listofts):
@@ -323,12 +344,59 @@ def sbdftwo(trange=None, inivel=None, inip=None, bcs_ini=[],
             if nrmvc > check_ff_maxv or np.isnan(nrmvc):
                 ffflag = 1
                 break
+            if on_device and len(ctrange) > 0:
+                ns = len(ctrange)
+                gvt, gpt = np.empty((ns, NV)), np.empty((ns, NP))
+                dbt = np.empty((ns, len(statvals) + len(bcs_n))) \
+                    if moving else None
+                for s, ctime in enumerate(ctrange):
+                    mbc_p = mbc_c
+                    bcs_c, mbc_c = bcs_n, mbc_n
+                    bcs_n = getbcs(ctime, None, None, mode='abtwo')
+                    bfv_n, bfp_n, mbc_n = applybcs(bcs_n)
+                    fv_n, fp_n = f_tdp(ctime), g_tdp(ctime)
+                    gvt[s] = _col(-(mbc_n - 4/3*mbc_c + 1/3*mbc_p)
+                                  + 2/3*dt*bfv_n + 2/3*dt*fv_n, NV)[:, 0]
+                    gpt[s] = _col(fp_n + bfp_n, NP)[:, 0]
+                    if moving:
+                        dbt[s] = statvals + list(bcs_c)
+                stepper.set_rhs_table(gvt, gpt)
+                if moving:
+                    device_convection.set_dbc_table(dbt)
+                done = 0
+                v_start = v_n
+                for s, ctime in enumerate(ctrange):
+                    wanted = savetimes is None or ctime in savetimes
+                    # the blow-up guard of the next slice looks at the velocity
+                    # BEFORE this slice's last step (tiu:317,322)
+                    if not (wanted or s >= ns - 2):
+                        continue
+                    stepper.run(s + 1 - done, cf, opts)
+                    done = s + 1
+                    v_s, p_s = stepper.get_state()
+                    if s == ns - 2:
+                        v_c = v_s
+                    if s == ns - 1:
+                        v_n, p_n = v_s, p_s
+                    if wanted:
+                        bcs_at = dbt[s + 1][len(statvals):].tolist() \
+                            if (moving and s + 1 < ns) else bcs_n
+                        savevp(appndbcs(v_s, bcs_at), p_s, time=ctime)
+                if ns == 1:
+                    v_c = v_start
+                if moving:
+                    device_convection.set_dbcvals(statvals + list(bcs_n))
+                stepper.set_rhs(_col(0., NV), _col(0., NP))
+                continue
             for ctime in ctrange:
                 v_p, mbc_p = v_c, mbc_c
                 v_c, p_c = v_n, p_n
                 bcs_c, mbc_c = bcs_n, mbc_n
                 dfv_c = dfv_n
-                nfc_new = f_vdp(appndbcs(v_c, bcs_c))
+                if device_convection is not None and (moving or statvals):
+                    device_convection.set_dbcvals(statvals + list(bcs_c))
+                nfc_new = None if device_convection is not None \
+                    else f_vdp(appndbcs(v_c, bcs_c))
                 bcs_n = getbcs(ctime, appndbcs(v_c, bcs_c), p_c, mode='abtwo')
                 bfv_n, bfp_n, mbc_n = applybcs(bcs_n)
                 fv_n, fp_n = f_tdp(ctime), g_tdp(ctime)
@@ -347,9 +415,15 @@ def sbdftwo(trange=None, inivel=None, inip=None, bcs_ini=[],
 
 
 def semi_implicit_euler(iniv=None, jmat=None, mmat=None, amat=None, rhsv=None,
-                        trange=None, data_trange=None, fp=None, solver=None):
+                        trange=None, data_trange=None, fp=None, solver=None,
+                        device_convection=None, constant_rhs=None):
     """`M v' + A v + J^T p = rhs(t, v)`, `J v = fp` with the linear part
-    implicit (reference tiu:566-635); list of velocities at `data_trange`"""
+    implicit (reference tiu:566-635); list of velocities at `data_trange`
+
+    `device_convection` (a `convection.ConvectionP2` over the inner dofs) with
+    `constant_rhs` (NV x 1 or None): the right-hand side is
+    `rhs(t, v) = constant_rhs - N(v)v`, evaluated on the device -- `rhsv` is
+    not called and the loop runs resident between the data points."""
     prm = _solver_settings(solver)
     record = list(np.copy(trange if data_trange is None else data_trange))
     record.pop(0)
@@ -367,6 +441,21 @@ def semi_implicit_euler(iniv=None, jmat=None, mmat=None, amat=None, rhsv=None,
     out = [iniv]
     cv = iniv
     try:
+        if device_convection is not None:
+            stepper.set_convection(device_convection, scale=-1.0)
+            if constant_rhs is not None:
+                stepper.set_rhs(dt*_col(constant_rhs, NV), fpz)
+            todo = 0
+            for ct in trange[1:]:
+                todo += 1
+                if len(record) > 0 and ct == record[0]:
+                    stepper.run(todo, cf, opts)
+                    todo = 0
+                    out.append(stepper.get_state()[0])
+                    record.pop(0)
+            if todo:
+                stepper.run(todo, cf, opts)
+            return out
         for ct in trange[1:]:
             # b_v = M v + dt*rhs(t, v): `rhs` plays the role of the convection
             stepper.step(cf, nfc_new=rhsv(ct, cv), opts=opts)

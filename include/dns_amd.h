@@ -38,6 +38,9 @@ extern "C" {
 #define DNS_ERR_BAD_ARGUMENT 4
 #define DNS_ERR_NOT_READY    5   /* e.g. solve before the preconditioner     */
 #define DNS_ERR_COMM         6   /* RCCL failure                             */
+#define DNS_ERR_HOST         7   /* host-side failure inside the library (out
+                                    of memory, a thread that cannot start):
+                                    no C++ exception crosses this boundary   */
 
 #define DNS_METHOD_GMRES     0
 #define DNS_METHOD_BICGSTAB  1

@@ -89,7 +89,7 @@ def test_cnab_with_device_convection_matches_oracle(conv_setup):
     t2, v2, p2 = rec2.arrays()
     for k in range(times.size):
         assert np.linalg.norm(vels[k] - v2[k]) <= 1e-8*np.linalg.norm(v2[k])
-    assert np.linalg.norm(p - po) <= 1e-6*np.linalg.norm(po)
+    assert np.linalg.norm(p - po) <= 1e-8*np.linalg.norm(po)
 
 
 def test_resident_run_with_convection_matches_stepwise(conv_setup):
@@ -128,6 +128,6 @@ def test_resident_run_with_convection_matches_stepwise(conv_setup):
         st_b.step(cf, nfc_new=nfc, opts=opts)
         vb, pb = st_b.get_state()
     assert np.linalg.norm(va - vb) <= 1e-9*np.linalg.norm(vb)
-    assert np.linalg.norm(pa - pb) <= 1e-7*np.linalg.norm(pb)
+    assert np.linalg.norm(pa - pb) <= 1e-8*np.linalg.norm(pb)
     for obj in (st_a, st_b, sys_a, sys_b):
         obj.close()
