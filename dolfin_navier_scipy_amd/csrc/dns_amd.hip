@@ -107,6 +107,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     if (const char *sn = getenv("DNS_MG_FUSED")) mg_fused_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
     if (const char *sn = getenv("DNS_PAIR")) pair_knob = sn[0] != '0';
+    if (const char *sn = getenv("DNS_DIST_GRAPH")) dist_graph_ok = sn[0] != '0';
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
@@ -1136,16 +1137,47 @@ int dns_saddle::run_cached(const std::vector<uint64_t> &key, bool use_graph,
     if (!use_graph || capturing) return body();
     for (auto &g : graphs)
         if (g.key == key) {
-            if (launch) DNS_HIP(hipGraphLaunch(g.exec, stream));
+            if (launch) {
+                DNS_HIP(hipGraphLaunch(g.exec, stream));
+                if (comm) {
+                    comm->n_allreduce += g.d_allreduce;
+                    comm->n_allgather += g.d_allgather;
+                    comm->n_alltoall += g.d_alltoall;
+                    comm->bytes_alltoall += g.d_bytes_a2a;
+                    comm->bytes_allgather += g.d_bytes_ag;
+                }
+            }
             return DNS_OK;
         }
     GraphEntry ge;
     ge.key = key;
-    DNS_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    const int64_t c0[5] = {comm ? comm->n_allreduce : 0,
+                           comm ? comm->n_allgather : 0,
+                           comm ? comm->n_alltoall : 0,
+                           comm ? comm->bytes_alltoall : 0,
+                           comm ? comm->bytes_allgather : 0};
+    // (RCCL may register memory / start proxies lazily inside a call: the
+    // relaxed mode lets it; nothing else of this thread runs meanwhile)
+    DNS_HIP(hipStreamBeginCapture(stream, dist() ? hipStreamCaptureModeRelaxed
+                                                 : hipStreamCaptureModeThreadLocal));
     capturing = true;
     const int rc = body();
     capturing = false;
     hipError_t e = hipStreamEndCapture(stream, &ge.graph);
+    if (comm) {
+        ge.d_allreduce = comm->n_allreduce - c0[0];
+        ge.d_allgather = comm->n_allgather - c0[1];
+        ge.d_alltoall = comm->n_alltoall - c0[2];
+        ge.d_bytes_a2a = comm->bytes_alltoall - c0[3];
+        ge.d_bytes_ag = comm->bytes_allgather - c0[4];
+        if (!launch) {           // captured only: nothing was communicated
+            comm->n_allreduce = c0[0];
+            comm->n_allgather = c0[1];
+            comm->n_alltoall = c0[2];
+            comm->bytes_alltoall = c0[3];
+            comm->bytes_allgather = c0[4];
+        }
+    }
     if (rc != DNS_OK) {
         if (ge.graph) (void)hipGraphDestroy(ge.graph);
         return rc;
@@ -1419,8 +1451,9 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
                       uint64_t prologue_key, bool prologue_has_resid) {
     const int m = std::max(1, std::min(o->restart, kMaxRestart));
     DNS_TRY(ensure_solver_buffers(o));
-    // RCCL calls are issued eagerly between the kernels (no graph capture)
-    const bool graph = o->use_graph != 0 && !dist();
+    // (RCCL calls are captured with the kernels; host-callback communicators
+    // need plain launches)
+    const bool graph = o->use_graph != 0 && graph_capable();
     // first cycle length: what the previous solve needed plus slack (time
     // stepping repeats itself), rounded to the polling granularity
     const int gran = std::max(1, o->check_every);

@@ -306,6 +306,9 @@ struct GraphEntry {
     std::vector<uint64_t> key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // collectives the captured body issued (a replay counts them again)
+    int64_t d_allreduce = 0, d_allgather = 0, d_alltoall = 0;
+    int64_t d_bytes_a2a = 0, d_bytes_ag = 0;
 };
 
 }  // namespace dns
@@ -384,6 +387,16 @@ struct dns_saddle {
                                       // pressure rows over the ranks
     dns::DevBuf<double> dsum;         // all-reduced scalars
     bool dist() const { return comm != nullptr && dist_active; }
+    // RCCL calls are stream-ordered and capturable: a cycle (and a whole time
+    // step with its halo exchanges) of a row-partitioned handle is replayed as
+    // a hipGraph like on one GPU.  Host-callback communicators (the gloo-staged
+    // test stand-in) synchronise the stream and are not.  `dist_graph_ok`
+    // goes false when a capture with collectives failed once (DNS_DIST_GRAPH=0
+    // starts that way): plain launches from then on.
+    bool dist_graph_ok = true;
+    bool graph_capable() const {
+        return !dist() || (comm->nccl != nullptr && dist_graph_ok);
+    }
     int *step_counter = nullptr;      // device step counter of the attached
                                       // stepper (tables of per-step data);
                                       // bumped by the first head kernel of

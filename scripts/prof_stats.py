@@ -5,7 +5,7 @@ import sys
 
 pat = sys.argv[1] if len(sys.argv) > 1 else '*/*kernel_stats.csv'
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-f = sorted(glob.glob(pat))[-1]
+f = sorted(glob.glob(pat, recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 print(f)
 for r in rows[:top]:

@@ -188,6 +188,82 @@ def system_levels(info):
     return info['precond'].get('mg_levels', [])
 
 
+CFG4_NTS = 256
+
+
+def _config4_setup():
+    """BASELINE config 4 (`tests/time_dep_nse_krylov.py:4-7,52`): cylinder
+    wake on `cylinder_3`, Re=40, tE=0.5, Nts=256, Stokes start"""
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    from oracle import saddle_oracle
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=3, Re=40)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    th, inv = femp['V'], femp['invinds']
+    dbcinds, dbcvals = femp['dbcinds'], femp['dbcvals']
+    vp0 = saddle_oracle.solve_sadpnt_smw(amat=A, jmat=J, rhsv=rhsd['fv'],
+                                         rhsp=rhsd['fp'])
+    inivel, inip = vp0[:NV], -vp0[NV:]
+
+    def appnd(vvec, bcs):
+        full = np.full((th.vdim, 1), np.nan)
+        full[inv] = vvec
+        full[dbcinds, 0] = dbcvals
+        return full
+
+    def f_vdp(vf):
+        return -th.convection_vec(vf)[inv, :]
+
+    def make_kw(rec, nts=CFG4_NTS):
+        return dict(trange=np.linspace(0, .5, CFG4_NTS + 1)[:nts + 1],
+                    inivel=inivel, inip=inip, bcs_ini=[], M=M, A=A, J=J,
+                    f_vdp=f_vdp, f_tdp=lambda t: rhsd['fv'],
+                    g_tdp=lambda t: rhsd['fp'], scalep=-1.,
+                    getbcs=lambda t, v, p, mode=None: [],
+                    applybcs=lambda b: (0., 0., 0.), appndbcs=appnd,
+                    savevp=rec, check_ff_maxv=1e8)
+    return femp, sm, rhsd, make_kw
+
+
+def _config4_partitioned(sad, comm):
+    """Heun start on the host (oracle arithmetic, identical on every rank),
+    then the remaining 255 CNAB steps device resident on the row-partitioned
+    system with the device convection"""
+    import scenarios
+    from oracle import imex_oracle
+    from dolfin_navier_scipy_amd import convection
+    femp, sm, rhsd, make_kw = _config4_setup()
+    M, A, J = sm['M'], sm['A'], sm['J']
+    dt = .5/CFG4_NTS
+    kw = make_kw(scenarios.Recorder(), nts=2)
+    (v1, p1, _, _, _, _, _, nfc0, nfc1, _, _) = imex_oracle.heun_start(
+        vc=kw['inivel'], pc=kw['inip'], tc=0., tn=dt, M=M, A=A, J=J,
+        scalep=-1., dfv_c=0., dynamic_rhs=lambda t, vc=None, memory={},
+        mode=None: (np.zeros_like(kw['inivel']), memory), drm={}, bcs_c=[],
+        applybcs=kw['applybcs'], appndbcs=kw['appndbcs'], getbcs=kw['getbcs'],
+        f_tdp=kw['f_tdp'], f_vdp=kw['f_vdp'], g_tdp=kw['g_tdp'])
+    system = sad.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    if comm is not None:
+        system.set_comm(comm)
+    system.setup_precond(cheb_degree=6, schur='dense', fhat='explicit',
+                         factorization='full', drop_tol=1e-3)
+    stp = sad.ImexStepper(system, (M - .5*dt*A).tocsr())
+    stp.set_state(v1, ptilde_c=-dt*p1, nfc_c=nfc0)
+    stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+    stp.set_convection(cvop, scale=-1.0)
+    cf = sad.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                pscale=-1./dt, extrapolate=4)
+    opts = sad.solve_opts(rtol=1e-13, maxiter=400, reorth=2, use_graph=True)
+    _, its, _ = stp.run(CFG4_NTS - 1, cf, opts)
+    v, p = stp.get_state()
+    stp.close()
+    cvop.close()
+    system.close()
+    return v, p, its
+
+
 def test_rccl_world_size_one_equals_plain_solve():
     from dolfin_navier_scipy_amd import saddle, comm as dcomm, _capi
     assert _capi.device_count() > 0
@@ -334,3 +410,55 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
           info['matrix_bytes'], '; halo bytes per exchange', per_exchange,
           'of', 8*NVc, '; all-reduces', int(r0['cyl3_8']), 'for',
           int(r0['cyl3_3']), 'Krylov steps + 5 time steps')
+
+
+def test_config4_256_steps_partitioned_over_two_ranks(tmp_path):
+    """config 4's own horizon (Nts = 256, `tests/time_dep_nse_krylov.py:52`)
+    on `cylinder_3`, row-partitioned over two ranks (gloo-staged on one GPU):
+    velocity AND pressure within 1e-8 of the oracle's factor-once
+    CNAB loop; both ranks bitwise equal"""
+    import scenarios
+    from oracle import imex_oracle
+    from spawn_util import spawn_ranks
+    spawn_ranks(_worker_cfg4, 2, str(tmp_path))
+    r0 = np.load(tmp_path / 'cfg4_rank0.npz')
+    r1 = np.load(tmp_path / 'cfg4_rank1.npz')
+    assert np.array_equal(r0['v'], r1['v']) and np.array_equal(r0['p'], r1['p'])
+    femp, sm, rhsd, make_kw = _config4_setup()
+    vo, po, ff = imex_oracle.cnab(**make_kw(scenarios.Recorder()))
+    assert ff == 0
+    M = sm['M']
+    mn = lambda x: float(np.sqrt((x.T @ (M @ x)).item()))
+    ev = mn(r0['v'].reshape((-1, 1)) - vo)/mn(vo)
+    ep = np.linalg.norm(r0['p'].reshape((-1, 1)) - po)/np.linalg.norm(po)
+    print('config 4, 256 steps over 2 ranks: v', ev, 'p', ep, 'Krylov steps',
+          int(r0['its']), 'halo exchanges', int(r0['halo']), 'all-reduces',
+          int(r0['allreduce']))
+    assert ev <= 1e-8, ev
+    assert ep <= 1e-8, ep
+    assert int(r0['halo']) > 0 and int(r0['allreduce']) > 0
+
+
+def _worker_cfg4(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      GLOO_SOCKET_IFNAME='lo')
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+    import faulthandler
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(200, exit=True)   # never hang a GPU box
+    dist.init_process_group('gloo', rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=120))
+    from dolfin_navier_scipy_amd import saddle, comm as dcomm
+    cm = dcomm.Comm.gloo(0)
+    before = cm.stats()
+    v4, p4, its4 = _config4_partitioned(saddle, cm)
+    after = cm.stats()
+    np.savez(os.path.join(outdir, 'cfg4_rank{0}.npz'.format(rank)), v=v4, p=p4,
+             its=its4, halo=after['halo_exchange'] - before['halo_exchange'],
+             allreduce=after['allreduce'] - before['allreduce'])
+    cm.close()
+    dist.destroy_process_group()
