@@ -954,7 +954,6 @@ def main():
             # bandwidth regime, end to end: the same CNAB loop on the mesh
             # refined twice (n = 173k, multigrid Schur block, dt/4) next to
             # the prefactored SuperLU step on the host
-            sys.path.insert(0, os.path.join(ROOT, 'scripts'))
             import refined_bench
             refined = refined_bench.run(refine=2, nts=4*args.nts, nsteps=200,
                                         with_cpu=not args.no_cpu, Re=args.Re)

@@ -107,6 +107,9 @@ struct CsrDev {
     int lpr = 16;                 // lanes per row of the vector kernel
     DevBuf<int> rowptr, colidx;
     DevBuf<double> vals;
+    // fp32 copy of the values (operators of the PRECONDITIONER in the
+    // bandwidth regime: 6 instead of 10 bytes per non-zero cross the HBM)
+    DevBuf<float> vals32;
     // row-block table of the LDS-streaming kernel (built on the host)
     DevBuf<int> rowblocks_t[3];   // tiles of 1024 / 2048 / 4096 non-zeros
     int nrowblocks_t[3] = {0, 0, 0};
@@ -122,6 +125,7 @@ struct CsrDev {
         rowptr.release();
         colidx.release();
         vals.release();
+        vals32.release();
         for (int t = 0; t < 3; ++t) {
             rowblocks_t[t].release();
             nrowblocks_t[t] = 0;

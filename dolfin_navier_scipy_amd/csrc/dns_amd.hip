@@ -108,6 +108,13 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
     if (const char *sn = getenv("DNS_PAIR")) pair_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_DIST_GRAPH")) dist_graph_ok = sn[0] != '0';
+    if (const char *sn = getenv("DNS_MG_CHEB")) mg_cheb = sn[0] != '0';
+    if (const char *sn = getenv("DNS_MG_CYCLES"))
+        mg_cycles = std::max(1, std::min(2, atoi(sn)));
+    if (const char *sn = getenv("DNS_MG_RHO"))
+        mg_rho = std::max(0.01, std::min(0.95, atof(sn)));
+    if (const char *sn = getenv("DNS_MG_CHEB_ALPHA"))
+        mg_cheb_alpha = std::max(1.5, atof(sn));
     DNS_HIP(hipEventCreate(&ev0));
     DNS_HIP(hipEventCreate(&ev1));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&hdr_host),
@@ -523,6 +530,8 @@ int dns_saddle::build_explicit(bool dense_schur) {
         if (!comm) {
             dns_csr jv = JGh.view();
             DNS_TRY(JG.upload(&jv, stream));
+            if (fp32_store && streams(JG))
+                DNS_TRY(to_f32(JG.vals.p, JG.vals32, (size_t)JG.nnz + 2));
         }
         DNS_TRY(tau.alloc((size_t)std::max(1, np)));
         have_jg = true;
@@ -675,7 +684,19 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
                 if (Sl.colidx[k] == i) d += Sl.vals[k];
             dv[i] = (d != 0.0) ? 1.0 / d : 1.0;
         }
-        lv.omega = 4.0 / (3.0 * std::max(1e-300, host_jacobi_lmax(Sl)));
+        {
+            const double lmax = std::max(1e-300, host_jacobi_lmax(Sl));
+            lv.omega = lv.omega2 = 4.0 / (3.0 * lmax);
+            if (mg_cheb && mg_nu == 2) {
+                // two Richardson steps at the Chebyshev roots of
+                // [lmax / alpha, 1.05 lmax]
+                const double hi = 1.05 * lmax, lo = lmax / mg_cheb_alpha;
+                const double mid = 0.5 * (hi + lo), rad = 0.5 * (hi - lo);
+                const double c = 0.70710678118654752;    // cos(pi / 4)
+                lv.omega = 1.0 / (mid + rad * c);
+                lv.omega2 = 1.0 / (mid - rad * c);
+            }
+        }
         HostCsr PT = host_transpose(P);
         dns_csr sv = Sl.view(), pv = P.view(), tv = PT.view();
         DNS_TRY(lv.S.upload(&sv, stream));
@@ -687,15 +708,18 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
         const HostCsr SP = host_spgemm(Sl, P);
         if (mg_fused) {
             // the operators of the fused cycle (solver.hpp, MgLevel)
+            // first sweep of a pair with w1 = omega, second with w2 = omega2:
+            //   T   = I - w1 D^-1 S
+            //   pre = ((w1 + w2) I - w2 (w1 D^-1 S)) D^-1   (two sweeps from 0)
             std::vector<double> wd((size_t)lv.n);
             for (int i = 0; i < lv.n; ++i) wd[i] = lv.omega * dv[i];
             const HostCsr I = host_diag(std::vector<double>((size_t)lv.n, 1.0));
             HostCsr WS = Sl;
-            host_scale_rows(wd, WS);                       // w D^-1 S
+            host_scale_rows(wd, WS);                       // w1 D^-1 S
             const HostCsr T = host_add(1.0, I, -1.0, WS);
-            HostCsr Ap = host_add(2.0, I, -1.0, WS);       // (I + T) ...
-            for (size_t k = 0; k < Ap.vals.size(); ++k)    // ... w D^-1
-                Ap.vals[k] *= wd[Ap.colidx[k]];
+            HostCsr Ap = host_add(lv.omega + lv.omega2, I, -lv.omega2, WS);
+            for (size_t k = 0; k < Ap.vals.size(); ++k)    // ... D^-1
+                Ap.vals[k] *= dv[Ap.colidx[k]];
             HostCsr mPTS = host_spgemm(PT, Sl);
             for (double &v : mPTS.vals) v = -v;
             const HostCsr Rr = host_hstack(PT, mPTS);
@@ -706,6 +730,14 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
             DNS_TRY(lv.Apre.upload(&av, stream));
             DNS_TRY(lv.Rr.upload(&rv, stream));
             DNS_TRY(lv.Qq.upload(&qv, stream));
+            if (fp32_store && !comm) {
+                // the cycle is part of the preconditioner: its operators cross
+                // the HBM as fp32 where they are streamed (6 B per non-zero)
+                for (CsrDev *op : {&lv.Apre, &lv.Rr, &lv.Qq, &lv.S})
+                    if (streams(*op))
+                        DNS_TRY(to_f32(op->vals.p, op->vals32,
+                                       (size_t)op->nnz + 2));
+            }
             DNS_HIP(hipStreamSynchronize(stream));
             // the prolongation itself is not applied by the fused cycle
             lv.nnz_P = lv.P.nnz;
@@ -743,7 +775,7 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
                 StreamEpi ep = stream_epi_plain(1.0, 0.0, b);
                 ep.dinv = lv.dinv.p;
                 ep.xin = xin;
-                ep.omega = lv.omega;
+                ep.omega = (sweep & 1) ? lv.omega2 : lv.omega;
                 if (launch_stream16x<double>(lv.S, lv.S.vals.p, xin, nxt, ep,
                                              stream, guard) != DNS_OK)
                     return (double *)nullptr;
@@ -754,7 +786,8 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
                                        grid_for_rows(lv.n, lv.S.lpr), kBlock, 0,
                                        stream, lv.n, lv.S.rowptr.p,
                                        lv.S.colidx.p, lv.S.vals.p, lv.dinv.p,
-                                       lv.omega, b, xin, nxt, guard));
+                                       (sweep & 1) ? lv.omega2 : lv.omega, b,
+                                       xin, nxt, guard));
             }
             cur = nxt;
         }
@@ -831,6 +864,9 @@ int dns_saddle::mg_op(const CsrDev &A, const double *xa, int nsplit,
             ep.omega = add->omega;
             ep.add_cb = 1;
         }
+        if (A.vals32.p)
+            return launch_stream16x<float>(A, A.vals32.p, xa, out, ep, stream,
+                                           guard);
         return launch_stream16x<double>(A, A.vals.p, xa, out, ep, stream, guard);
     }
     DNS_LPR_SWITCH(
@@ -847,8 +883,9 @@ int dns_saddle::mg_op(const CsrDev &A, const double *xa, int nsplit,
 // the V(2,2) cycle on the fused operators: per level two launches down
 // (x_pre = Apre b; b_c = Rr [b; x_pre]) and two up (x' = Qq [x_pre; e] + c(b);
 // one more sweep -- the finest level's writes zp = -x'' itself)
-int dns_saddle::schur_mg_apply_fused(const double *in, double *zp, double *xacc,
-                                     const int *guard) {
+int dns_saddle::mg_cycle_fused(const double *in, double *zp, double *xacc,
+                                const int *guard, double scale) {
+    // zp = -scale * V(in)  (and xacc += zp)
     const int L = (int)mg.size();
     for (int l = 0; l + 1 < L; ++l) {
         MgLevel &lv = mg[l];
@@ -878,14 +915,18 @@ int dns_saddle::schur_mg_apply_fused(const double *in, double *zp, double *xacc,
                       guard));
         // the second post-sweep; on the finest level it delivers zp = -x''
         double *out = (l == 0) ? zp : lv.x.p;
-        const double osc = (l == 0) ? -1.0 : 1.0;
+        const double osc = (l == 0) ? -scale : 1.0;
         if (!dist() && streams(lv.S)) {
             StreamEpi ep = stream_epi_plain(osc, 0.0, b);
             ep.dinv = lv.dinv.p;
             ep.xin = lv.x2.p;
-            ep.omega = lv.omega;
-            DNS_TRY(launch_stream16x<double>(lv.S, lv.S.vals.p, lv.x2.p, out,
-                                             ep, stream, guard));
+            ep.omega = lv.omega2;
+            if (lv.S.vals32.p)
+                DNS_TRY(launch_stream16x<float>(lv.S, lv.S.vals32.p, lv.x2.p,
+                                                out, ep, stream, guard));
+            else
+                DNS_TRY(launch_stream16x<double>(lv.S, lv.S.vals.p, lv.x2.p,
+                                                 out, ep, stream, guard));
             if (l == 0 && xacc)
                 hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0,
                                    stream, (int64_t)np, 1.0, zp, 1.0, xacc);
@@ -895,9 +936,42 @@ int dns_saddle::schur_mg_apply_fused(const double *in, double *zp, double *xacc,
                 hipLaunchKernelGGL(k_mg_sweep<L>, grid_for_rows(lv.n, lv.S.lpr),
                                    kBlock, 0, stream, lv.n, lv.S.rowptr.p,
                                    lv.S.colidx.p, lv.S.vals.p, lv.dinv.p,
-                                   lv.omega, b, lv.x2.p, out, guard, osc,
+                                   lv.omega2, b, lv.x2.p, out, guard, osc,
                                    (l == 0) ? xacc : (double *)nullptr));
         }
+    }
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+// one cycle, or two as Richardson steps with Chebyshev weights:
+//   x1 = a1 V(in);  x2 = x1 + a2 V(in - S x1);  zp = -x2
+int dns_saddle::schur_mg_apply_fused(const double *in, double *zp, double *xacc,
+                                     const int *guard) {
+    if (mg_cycles < 2 || dist())
+        return mg_cycle_fused(in, zp, xacc, guard, 1.0);
+    const double mid = 1.0 - 0.5 * mg_rho, rad = 0.5 * mg_rho;
+    const double c = 0.70710678118654752;
+    const double a1 = 1.0 / (mid + rad * c), a2 = 1.0 / (mid - rad * c);
+    MgLevel &l0 = mg[0];
+    if (mg_r2.n < (size_t)l0.n) {
+        // (first use: outside any capture -- ensure_solver_buffers sizes them)
+        DNS_TRY(mg_r2.alloc((size_t)l0.n));
+        DNS_TRY(mg_z2.alloc((size_t)l0.n));
+    }
+    DNS_TRY(mg_cycle_fused(in, zp, nullptr, guard, a1));
+    // r = in - S x1 = in + S zp
+    DNS_TRY(launch_spmv(l0.S, zp, mg_r2.p, 1.0, 1.0, in,
+                        streams(l0.S) ? DNS_SPMV_STREAM16 : DNS_SPMV_VECTOR,
+                        stream, guard));
+    // zp += -a2 V(r)
+    DNS_TRY(mg_cycle_fused(mg_r2.p, mg_z2.p, zp, guard, a2));
+    if (xacc) {
+        if (guard)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "two multigrid cycles: no guarded accumulate");
+        hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
+                           (int64_t)np, 1.0, zp, 1.0, xacc);
     }
     DNS_HIP(hipGetLastError());
     return DNS_OK;
@@ -1342,8 +1416,15 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             if (have_jg && streams(JG)) {
                 // tau = V_j,p - JG V_j,v through the streaming kernel
                 const double *vj = V.p + (size_t)j * ld;
-                DNS_TRY(launch_spmv(JG, vj, tau.p, -1.0, 1.0, vj + nv,
-                                    DNS_SPMV_STREAM16, stream, done_ptr()));
+                if (JG.vals32.p)
+                    DNS_TRY(launch_stream16x<float>(
+                        JG, JG.vals32.p, vj, tau.p,
+                        stream_epi_plain(-1.0, 1.0, vj + nv), stream,
+                        done_ptr()));
+                else
+                    DNS_TRY(launch_spmv(JG, vj, tau.p, -1.0, 1.0, vj + nv,
+                                        DNS_SPMV_STREAM16, stream,
+                                        done_ptr()));
                 sin = tau.p;
             } else if (have_jg) {
                 DNS_LPR_SWITCH(
@@ -1436,6 +1517,10 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
 int dns_saddle::ensure_solver_buffers(const dns_solve_opts *o) {
     const int m = std::max(1, std::min(o->restart, kMaxRestart));
     DNS_TRY(ensure_workspace(m));
+    if (mg_cycles > 1 && !mg.empty() && mg_r2.n < (size_t)mg[0].n) {
+        DNS_TRY(mg_r2.alloc((size_t)mg[0].n));
+        DNS_TRY(mg_z2.alloc((size_t)mg[0].n));
+    }
     const size_t need_hist = (size_t)o->maxiter + 2 * kMaxRestart + 8;
     if (histdev.n < need_hist) {
         DNS_HIP(hipStreamSynchronize(stream));

@@ -425,7 +425,13 @@ struct dns_saddle {
     // multigrid Schur block (DNS_SCHUR_MG): level 0 = the pressure space
     struct MgLevel {
         int n = 0;
-        double omega = 0.6;               // Jacobi damping, 4 / (3 lambda_max)
+        // damping of the first / second sweep of a smoothing pair: equal
+        // (4 / (3 lambda_max): damped Jacobi) or the reciprocals of the two
+        // Chebyshev roots on [lambda_max / alpha, lambda_max] (mg_cheb) -- the
+        // same two products, error polynomial (1 - w1 t)(1 - w2 t) uniformly
+        // small on the upper part of the spectrum (0.22 for alpha = 4, where
+        // two Jacobi sweeps leave 0.44 at lambda_max / 4)
+        double omega = 0.6, omega2 = 0.6;
         dns::CsrDev S, P, PT;             // operator, prolongation from l+1, P^T
         // fused V(2,2) cycle (mg_fused): with T = I - w D^-1 S, c(b) = w D^-1 b
         //   Apre = (I + T) w D^-1     x_pre = Apre b       (two sweeps from 0)
@@ -452,6 +458,9 @@ struct dns_saddle {
     dns::DevBuf<float> mg_cinv32;         // ... its fp32 copy (fp32_store)
     int mg_dense_max = 2000;              // first level <= this: dense inverse
     int mg_nu = 2;
+    bool mg_cheb = true;                  // DNS_MG_CHEB (read once, at create)
+    double mg_cheb_alpha = 3.0;           // DNS_MG_CHEB_ALPHA (measured: 3
+                                          // beats 4 and 8 at refine 2-4)
     bool mg_ready = false, mg_set = false;
     int build_mg_schur(const dns::HostCsr &S0);
     int mg_op(const dns::CsrDev &A, const double *xa, int nsplit,
@@ -459,6 +468,15 @@ struct dns_saddle {
               double *out, const int *guard);
     int schur_mg_apply_fused(const double *in, double *zp, double *xacc,
                              const int *guard);
+    int mg_cycle_fused(const double *in, double *zp, double *xacc,
+                       const int *guard, double scale);
+    // cycles per application of the Schur block (DNS_MG_CYCLES): two cycles
+    // as two Richardson steps at the Chebyshev roots of [1 - rho, 1]
+    // (DNS_MG_RHO: bound of the cycle's contraction number) -- a LINEAR map
+    // of its input like one cycle (the fused Gram-Schmidt relies on that)
+    int mg_cycles = 1;
+    double mg_rho = 0.3;
+    dns::DevBuf<double> mg_r2, mg_z2;
     int schur_mg_apply(const double *in, double *zp, double *xacc,
                        const int *guard);
     // full block factorisation: J Fh^-1 as one CSR matrix, tau = r_p - JG r_v

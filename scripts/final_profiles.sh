@@ -11,8 +11,8 @@ cd $R
 echo "== bench (default)"; timeout -k 10 500 python bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
 echo "== bench (driver window)"; timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_window.json 2> $OUT/bench_driver_window.err || echo "driver window failed"
 echo "== refined legs"
-timeout -k 10 300 python scripts/refined_bench.py 2 2048 200 0 > $OUT/refine2_bench.json 2> $OUT/refine2.err || echo "refine2 failed"
-timeout -k 10 300 python scripts/refined_bench.py 3 4096 100 0 > $OUT/refine3_bench.json 2> $OUT/refine3.err || echo "refine3 failed"
+timeout -k 10 300 python refined_bench.py 2 2048 200 0 > $OUT/refine2_bench.json 2> $OUT/refine2.err || echo "refine2 failed"
+timeout -k 10 300 python refined_bench.py 3 4096 100 0 > $OUT/refine3_bench.json 2> $OUT/refine3.err || echo "refine3 failed"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 kernel stats of the bench command (graph replay)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $R/bench.py --no-cpu --no-refined --no-picard > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err || echo "profiled bench failed"
