@@ -7,9 +7,8 @@ One "step" = one pass of the hot path of `time_int_utils.cnab` (reference
 tiu:104-143) with everything resident in HBM: convection vector N(v)v (device
 element kernel -- the reference's host FEniCS callback, tiu:113), fused
 right-hand-side SpMV, block-preconditioned GMRES solve of
-`[[M + dt/2 A, J^T],[J, 0]]`, pressure rescale.  The same loop with the
-convection history frozen (the linear algebra alone, SURVEY.md 8d "convection
-excluded") is timed as well and reported in `config`.
+`[[M + dt/2 A, J^T],[J, 0]]`, pressure rescale.  `--scheme sbdf2` times the
+resident SBDF2 loop (tiu:320-353) instead.
 
 Workload at N=1: Schaefer-Turek cylinder wake, mesh level N=2 (NV=9356,
 NP=1289), Re=100, dt=1/512, Taylor-Hood, CNAB -- the configuration
@@ -30,6 +29,10 @@ the timed window from `dns_comm_stats2`.  Secondary figures on the same ranks:
 reported as it is -- at n ~ 1e4 a step is ~45 us of work on one GPU and every
 collective costs 10-20 us, so this is SLOWER than one GPU) and
 `config.ensemble` (N independent simulations, one per GPU, no collective).
+`config.weak_scaling_bandwidth` is the same partitioned loop in the BANDWIDTH
+regime (`BANDWIDTH_LADDER`: >= 7e5 rows per rank -- refine 3 on 1 rank, level 3
+refined 3x on 2, refine 4 on 4, level 3 refined 4x on 8), whose N=1 point is
+`config.weak_scaling_bandwidth_base` of the N=1 line.
 The partitioned runs execute in child processes (one per rank, their own
 rendezvous) under a time limit, so that a collective that never completes
 leaves an error in the JSON line instead of a hung benchmark; if the headline
@@ -67,6 +70,20 @@ DEFAULTS = dict(cheb=6, rtol=1e-10, extrap=4, fp32=1, drop=1e-3, fact='full',
 # (mesh level, red refinements): unknowns relative to the N=1 workload
 WEAK_LADDER = [((2, 0), 1.0), ((3, 0), 2.07), ((2, 1), 4.04), ((3, 1), 8.34),
                ((2, 2), 16.2), ((3, 2), 33.5)]
+
+
+# bandwidth regime: (mesh level, red refinements) with >= 7e5 rows per rank
+# (n = 693k / 1.43M / 2.78M; 8 ranks stay on the 2.78M mesh -- 347k rows per
+# rank -- because the set-up is still replicated per rank: the next mesh would
+# not fit the child run's time limit); multigrid Schur block, explicit degree-8
+# polynomial from 1e6 unknowns on
+BANDWIDTH_LADDER = {1: (2, 3), 2: (3, 3), 4: (2, 4), 8: (2, 4)}
+
+
+def bandwidth_ladder(world):
+    keys = sorted(BANDWIDTH_LADDER)
+    best = min(keys, key=lambda k: abs(k - world))
+    return BANDWIDTH_LADDER[best]
 
 
 def weak_ladder(world):
@@ -125,7 +142,18 @@ def initial_state(sm, rhsd, system_factory):
     return vp[:NV].reshape((-1, 1)), vp[NV:].reshape((-1, 1)), stats
 
 
-def cpu_baseline(sm, rhsd, v0, nfc0, dt, conv_host, nsteps):
+def scheme_setup(scheme, M, A, dt):
+    """system matrix, rhs matrix and step coefficients of the resident loop:
+    CNAB (tiu:104-143) or SBDF2 (tiu:320-353)"""
+    if scheme == 'sbdf2':
+        return ((M + 2./3*dt*A).tocsr(), M.tocsr(),
+                dict(a_c=4./3, a_p=-1./3, cn_c=4./3*dt, cn_o=-2./3*dt),
+                2./3*dt)
+    return ((M + .5*dt*A).tocsr(), (M - .5*dt*A).tocsr(),
+            dict(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt), dt)
+
+
+def cpu_baseline(sm, rhsd, v0, nfc0, dt, conv_host, nsteps, scheme='cnab'):
     """oracle leg: the reference's CNAB step (tiu:125-137) with the SuperLU
     factorisation done once (untimed, as the reference does once per run).
     The convection vector is the host callback in the reference (FEniCS, not
@@ -135,34 +163,41 @@ def cpu_baseline(sm, rhsd, v0, nfc0, dt, conv_host, nsteps):
     from oracle.saddle_oracle import SaddleLU
     M, A, J = sm['M'], sm['A'], sm['J']
     NP, NV = J.shape
+    F, R1, cfd, gdt = scheme_setup(scheme, M, A, dt)
     t0 = time.perf_counter()
-    klu = SaddleLU((M + .5*dt*A).tocsc(), J)
+    klu = SaddleLU(F.tocsc(), J)
     tfac = time.perf_counter() - t0
     v = v0.copy()
+    vprev = v0.copy()
     fv, fp = rhsd['fv'], rhsd['fp']
     nfc_c = nfc0
     el = 0.
     for k in range(nsteps):
         nfc_o, nfc_c = nfc_c, conv_host(v)           # untimed (host callback)
         t0 = time.perf_counter()
-        rhs = M @ v - .5*dt*(A @ v) + .5*dt*(3*nfc_c - nfc_o) + dt*fv
+        rhs = R1 @ (cfd['a_c']*v + cfd['a_p']*vprev) + cfd['cn_c']*nfc_c \
+            + cfd['cn_o']*nfc_o + gdt*fv
         vp = klu(np.vstack([rhs, fp]).flatten())
+        vprev = v
         v = vp[:NV].reshape((NV, 1))
         p = -1./dt*vp[NV:].reshape((NP, 1))
         el += time.perf_counter() - t0
     return dict(value=nsteps/el, unit='timesteps/s', cores=1, kind='port',
-                sample='{0} CNAB steps with the oracle: SuperLU factor once '
+                sample='{0} {2} steps with the oracle: SuperLU factor once '
                 '({1:.3f} s, untimed) + per-step rhs, 2 triangular solves, '
                 'rescale; convection callback evaluated on the host but not '
-                'timed'.format(nsteps, tfac)), v, p
+                'timed'.format(nsteps, tfac, scheme.upper())), v, p
 
 
-def cpu_baseline_extras(sm, rhsd, v0, nfc0, dt, nsteps_gmres=3,
+def cpu_baseline_extras(sm, rhsd, v0, nfc0, dt, nsteps_gmres=1,
                         nsteps_threads=40):
     """the other two CPU lines of SURVEY 8d:
     (iii) un-preconditioned `scipy.sparse.linalg.gmres(rtol=1e-3,
           maxiter=800)` per step -- the stand-in for the reference's krypy path
-          (`tests/time_dep_nse_krylov.py:4-7`: tol 1e-3, maxiter 800);
+          (`tests/time_dep_nse_krylov.py:4-7`: tol 1e-3, maxiter 800); a cold
+          start needs ~700 inner iterations = ~11 s per time step on one core,
+          so the sample is ONE step (with the initial Stokes solve below a
+          bounded ~25 s of CPU work);
     "all cores": the prefactored SuperLU step again with every host core the
           process may use handed to the BLAS/OpenMP runtimes (SuperLU's
           triangular solves and SciPy's CSR products are single-threaded, so
@@ -177,32 +212,61 @@ def cpu_baseline_extras(sm, rhsd, v0, nfc0, dt, nsteps_gmres=3,
     K = sps.bmat([[F, J.T], [J, None]], format='csr')
     fv, fp = rhsd['fv'], rhsd['fp']
     out = {}
-    # (iii) Krylov stand-in
+    # (iii) Krylov stand-in: what `krylov='Gmres'` with `tol 1e-3, maxiter 800`
+    # (tests/time_dep_nse_krylov.py:4-7) asks of every boundary solve; COLD
+    # start (x0 = 0), as krypy starts at snu:903-907 when no `x0` is handed over
     v = v0.copy()
-    el, its = 0., 0
-    x0 = np.zeros(NV + NP)
-    x0[:NV] = v0[:, 0]
-    cnt = [0]
+    el, cnt = 0., [0]
 
     def cb(_):
         cnt[0] += 1
+    relres = []
+    # one core, as the line says: the BLAS pool of a 256-core host makes the
+    # orthogonalisation of 10 645-entry vectors five times SLOWER
+    try:
+        from threadpoolctl import threadpool_limits
+        one_core = threadpool_limits(limits=1)
+    except ImportError:
+        one_core = None
     for k in range(nsteps_gmres):
         t0 = time.perf_counter()
         rhs = M @ v - .5*dt*(A @ v) + dt*nfc0 + dt*fv
         b = np.vstack([rhs, fp]).flatten()
-        x, info = spsla.gmres(K, b, x0=x0, rtol=1e-3, atol=0., restart=800,
-                              maxiter=1, callback=cb, callback_type='pr_norm')
+        x, info = spsla.gmres(K, b, x0=np.zeros(NV + NP), rtol=1e-3, atol=0.,
+                              restart=800, maxiter=1, callback=cb,
+                              callback_type='pr_norm')
         el += time.perf_counter() - t0
-        x0 = x
+        relres.append(float(np.linalg.norm(K @ x - b)/np.linalg.norm(b)))
         v = x[:NV].reshape((NV, 1))
     out['krylov_unpreconditioned'] = dict(
         value=nsteps_gmres/el, unit='timesteps/s', cores=1, kind='port',
         inner_iterations_per_step=cnt[0]/float(nsteps_gmres),
+        relres_reached_max=max(relres),
         sample='{0} CNAB steps, each solved by scipy.sparse.linalg.gmres('
-        'rtol=1e-3, 800 inner iterations at most, no preconditioner, warm '
-        'start from the previous step) -- stand-in for the krypy path of '
+        'rtol=1e-3, 800 inner iterations at most, no preconditioner, cold '
+        'start x0 = 0) -- stand-in for the krypy path of '
         'tests/time_dep_nse_krylov.py (tol 1e-3, maxiter 800); convection '
         'frozen'.format(nsteps_gmres))
+    # ... and the place the `krylov=` keywords reach in the reference: the
+    # initial Stokes solve (snu:903-907), same call on `[[A, JT], [J, 0]]`
+    Ks = sps.bmat([[A, J.T], [J, None]], format='csr')
+    bs = np.vstack([fv, fp]).flatten()
+    cnt[0] = 0
+    t0 = time.perf_counter()
+    xs, info = spsla.gmres(Ks, bs, x0=np.zeros(NV + NP), rtol=1e-3, atol=0.,
+                           restart=800, maxiter=1, callback=cb,
+                           callback_type='pr_norm')
+    ts = time.perf_counter() - t0
+    out['initial_stokes_krylov'] = dict(
+        seconds=ts, inner_iterations=cnt[0], converged=bool(info == 0),
+        relres_reached=float(np.linalg.norm(Ks @ xs - bs)/np.linalg.norm(bs)),
+        cores=1, kind='port',
+        sample='the initial Stokes solve (snu:903-907) by '
+        'scipy.sparse.linalg.gmres(rtol=1e-3, one cycle of at most 800 '
+        'iterations, no preconditioner, x0 = 0); the device solves the same '
+        'system to 1e-9 (config.initial_stokes)')
+    if one_core is not None:
+        one_core.restore_original_limits()
     # all cores
     ncores = len(os.sched_getaffinity(0))
     try:
@@ -287,15 +351,32 @@ def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64):
     return out
 
 
+def kernel_sources_sha256():
+    """fingerprint of the sources the roofline kernels are compiled from"""
+    import hashlib
+    out = {}
+    for name in ('pair.hpp', 'kernels.hpp'):
+        path = os.path.join(ROOT, 'dolfin_navier_scipy_amd', 'csrc', name)
+        out[name] = hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]
+    return out
+
+
 def pmc_traffic(Kmat, kernel='k_spmv_stream16'):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes
     (profiles/spmv_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950) -- only if they were taken on this very matrix"""
+    prescribes for gfx950) -- only if they were taken on this very matrix AND
+    on these very kernel sources (the record is stamped with the hashes of
+    pair.hpp / kernels.hpp by scripts/stamp_traffic.py; a stale record is not
+    printed)"""
     path = os.path.join(ROOT, 'profiles', 'spmv_traffic.json')
     if not os.path.exists(path):
         return None
     rec = json.load(open(path))
     if rec.get('nnz') != int(Kmat.nnz) or rec.get('rows') != Kmat.shape[0]:
+        return None
+    if rec.get('sources_sha256') != kernel_sources_sha256():
+        sys.stderr.write('profiles/spmv_traffic.json was taken on other '
+                         'kernel sources: roofline.traffic withheld\n')
         return None
     if kernel.startswith('k_spmv_pair'):
         return (rec.get('pair_format') or {}).get('hbm_bytes_per_launch')
@@ -367,8 +448,12 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
     if prols is not None:
         system.set_schur_mg(prols)
     t_setup = time.perf_counter()
-    system.setup_precond(cheb_degree=args.cheb, schur=schur_kind,
-                         fhat=args.fhat, fp32_store=bool(args.fp32),
+    # bandwidth regime: the partitioned solve needs the explicit polynomial
+    # matrix; degree 8 from 1e6 unknowns on (refined_bench.py's setting)
+    fhat = 'explicit' if (args.fhat == 'auto' and NV > 200000) else args.fhat
+    cheb = max(args.cheb, 8) if NV + NP > 1000000 else args.cheb
+    system.setup_precond(cheb_degree=cheb, schur=schur_kind,
+                         fhat=fhat, fp32_store=bool(args.fp32),
                          drop_tol=args.drop, factorization=args.fact)
     _capi.device_synchronize(device)
     t_setup = time.perf_counter() - t_setup
@@ -434,6 +519,8 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
         dof_steps_per_s=(NV + NP)*args.steps/wall, schur=schur_kind,
         krylov_iters_per_step=its/float(args.steps),
         true_relres_last=lst['true_relres'],
+        cheb_degree=cheb, fhat=fhat,
+        run_record=dict(stp.last_run),
         collectives_timed_window={k: int(c1[k] - c0[k]) for k in c1},
         matrix_bytes_per_rank_max=int(mb), precond_setup_s=t_setup,
         backend='gloo, host staged (one-GPU rehearsal)' if one_gpu
@@ -587,6 +674,12 @@ def multi_gpu_main(args, world, rank, local_rank):
     # stability limit there -- the run blows up within 200 steps)
     nts_w = args.nts*2**refine*(2 if level >= 3 else 1)
     weak = partitioned(17, level, refine, nts_w)
+    # the same loop in the bandwidth regime (>= 7e5 rows per rank)
+    bandwidth = None
+    if not args.no_bandwidth:
+        blevel, brefine = bandwidth_ladder(world)
+        nts_b = args.nts*2**brefine*(2 if blevel >= 3 else 1)
+        bandwidth = partitioned(41, blevel, brefine, nts_b)
     strong = None
     if not args.no_strong and (level, refine) != (args.level, 0):
         strong = partitioned(29, args.level, 0, args.nts)
@@ -673,6 +766,7 @@ def multi_gpu_main(args, world, rank, local_rank):
                         collectives=(weak.get('collectives_timed_window')
                                      if ok else None),
                         weak_scaling=weak, strong_scaling=strong,
+                        weak_scaling_bandwidth=bandwidth,
                         ensemble=ensemble, spinup_steps=args.spinup,
                         method='gmres', cheb_degree=args.cheb,
                         factorization=args.fact, drop_tol=args.drop,
@@ -702,8 +796,14 @@ def main():
     ap.add_argument('--Re', type=float, default=100.)
     ap.add_argument('--nts', type=int, default=512, help='dt = 1/nts')
     ap.add_argument('--method', default='gmres')
+    ap.add_argument('--scheme', default='cnab', choices=['cnab', 'sbdf2'],
+                    help='the resident loop that is timed: CNAB (tiu:104-143, '
+                    'BASELINE headline) or SBDF2 (tiu:320-353)')
     ap.add_argument('--cheb', type=int, default=DEFAULTS['cheb'])
     ap.add_argument('--rtol', type=float, default=DEFAULTS['rtol'])
+    ap.add_argument('--carry', type=int, default=1,
+                    help='1: the residual of every solve is carried into the '
+                    'next right-hand side (dns_imex_coeffs.carry_residual)')
     ap.add_argument('--extrap', type=int, default=DEFAULTS['extrap'],
                     help='warm start: 0 none, 1 linear, 2 quadratic, 3 cubic, '
                     '4 quartic')
@@ -738,6 +838,8 @@ def main():
                     help='skip the secondary Newton/Picard sweep figures')
     ap.add_argument('--no-strong', action='store_true',
                     help='N>1: skip the secondary strong-scaling leg')
+    ap.add_argument('--no-bandwidth', action='store_true',
+                    help='N > 1: skip the bandwidth-regime weak-scaling leg')
     ap.add_argument('--no-ensemble', action='store_true',
                     help='N>1: skip the secondary ensemble leg')
     ap.add_argument('--refine', type=int, default=0,
@@ -811,8 +913,7 @@ def main():
     vfull[femp['dbcinds'], 0] = femp['dbcvals']
     nfc = -th.convection_vec(vfull)[inv, :]      # snu:1136-1140
 
-    F = (M + .5*dt*A).tocsr()
-    R1 = (M - .5*dt*A).tocsr()
+    F, R1, cfd, gdt = scheme_setup(args.scheme, M, A, dt)
     t_setup = time.perf_counter()
     system = factory(F, J)
     mode, scaling = ('single', 'weak')
@@ -833,8 +934,8 @@ def main():
         full[femp['dbcinds'], 0] = femp['dbcvals']
         return -th.convection_vec(full)[inv, :]          # snu:1136-1140
 
-    cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
-                                   pscale=-1./dt, extrapolate=args.extrap)
+    cf = saddle.ImexStepper.coeffs(pscale=-1./dt, extrapolate=args.extrap,
+                                   carry_residual=bool(args.carry), **cfd)
     opts = saddle.solve_opts(method=args.method, rtol=args.rtol, maxiter=400,
                              restart=60, check_every=args.check_every,
                              use_graph=not args.eager,
@@ -848,15 +949,14 @@ def main():
         nwarm = args.warmup if nwarm is None else nwarm
         spinup = args.spinup if spinup is None else spinup
         stp = saddle.ImexStepper(system, R1)
-        stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
-        stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+        stp.set_state(v0, v_p=(v0 if args.scheme == 'sbdf2' else None),
+                      nfc_c=nfc, nfc_o=nfc)
+        stp.set_rhs(gdt*rhsd['fv'], rhsd['fp'])
         cvop = convection.ConvectionP2.from_taylor_hood(
             th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
         stp.set_convection(cvop, scale=-1.0)
         if spinup > 0:
-            stp.run(spinup, cf, opts)        # always with the convection
-        if not with_convection:
-            stp.set_convection(None)         # history frozen from here on
+            stp.run(spinup, cf, opts)
         stp.run(nwarm, cf, opts)
         barrier()
         t0 = time.perf_counter()
@@ -872,10 +972,8 @@ def main():
     # headline: the complete time step, convection evaluated on the device
     wall, dev_s, iters, last, v_gpu, p_gpu = timed_run(True)
     if args.profile_step:
-        wall_fr, iters_fr, wall_et, iters_et = wall, iters, wall, iters
+        wall_et, iters_et = wall, iters
     else:
-        # secondary: convection history frozen (the linear algebra alone)
-        wall_fr, _, iters_fr, _, _, _ = timed_run(False)
         # secondary: the same window right behind the impulsive start (Stokes
         # state, no spin-up): the solves need about two Krylov steps there
         wall_et, _, iters_et, _, _, _ = timed_run(True, spinup=0)
@@ -939,9 +1037,14 @@ def main():
                         traffic=traffic,
                         kernel=main_roof['kernel'], detail=main_roof,
                         attainable_GBs=attain,
+                        # like by like: PHYSICAL bytes (PMC traffic) per second
+                        # over the physical read rate of a plain streaming
+                        # kernel; `achieved` counts the algorithmic bytes
+                        physical_GBs=(traffic/main_roof['avg_us']/1e3
+                                      if traffic else None),
                         frac_of_attainable_read=(
-                            main_roof['achieved']/attain['read']
-                            if attain else None),
+                            traffic/main_roof['avg_us']/1e3/attain['read']
+                            if (attain and traffic) else None),
                         at_benchmark_size=roof,
                         # the whole time step against the same peak: published
                         # op list x measured Krylov steps / measured time
@@ -950,6 +1053,7 @@ def main():
         if world == 1 and not args.eager and not args.no_picard:
             picard = picard_sweep_figures(femp, sm, rhsd, v0, dt, device)
         refined = None
+        bw_base = None
         if world == 1 and not args.eager and not args.no_refined:
             # bandwidth regime, end to end: the same CNAB loop on the mesh
             # refined twice (n = 173k, multigrid Schur block, dt/4) next to
@@ -958,12 +1062,30 @@ def main():
             refined = refined_bench.run(refine=2, nts=4*args.nts, nsteps=200,
                                         with_cpu=not args.no_cpu, Re=args.Re)
             roofline['step_refined'] = refined.pop('roofline_step', None)
+            # N=1 point of the bandwidth-regime weak ladder (n = 693k): the
+            # un-partitioned loop and the SAME run through the partitioned code
+            # path on one RCCL rank (what the N > 1 lines time)
+            lvl, ref = BANDWIDTH_LADDER[1]
+            bw_base = refined_bench.run(refine=ref, nts=args.nts*2**ref,
+                                        nsteps=100, with_cpu=False, Re=args.Re)
+            bw_base['roofline_step'].pop('ops', None)
+            if args.force_dist or os.environ.get('DNS_BENCH_BW_DIST', '1') == '1':
+                import copy
+                a2 = copy.copy(args)
+                a2.level, a2.refine, a2.nts = lvl, ref, args.nts*2**ref
+                a2.steps, a2.warmup, a2.spinup = 100, 20, 256
+                a2.dense_max = 6000
+                try:
+                    bw_base['partitioned_one_rank'] = partitioned_run(
+                        a2, 1, 0, device, None, False)
+                except Exception as exc:     # reported, never fatal
+                    bw_base['partitioned_one_rank'] = dict(error=str(exc))
         cpu = None
         parity = None
         if not args.no_cpu and world == 1:     # rank 0 at N=1 only
             nall = args.spinup + args.warmup + args.steps
             cpu, v_cpu, p_cpu = cpu_baseline(
-                sm, rhsd, v0, nfc, dt, conv_host, nall)
+                sm, rhsd, v0, nfc, dt, conv_host, nall, scheme=args.scheme)
             cpu['other_lines'] = cpu_baseline_extras(sm, rhsd, v0, nfc, dt)
             # same steps, same nonlinear trajectory on both sides
             mn = lambda x: float(np.sqrt((x.T @ (M @ x)).item()))
@@ -973,15 +1095,16 @@ def main():
                                / np.linalg.norm(p_cpu)),
                 steps=args.spinup + args.warmup + args.steps)
         out = dict(
-            metric='timesteps/sec, 2D cylinder wake Re={0:g} (CNAB step: device '
+            metric='timesteps/sec, 2D cylinder wake Re={0:g} ({1} step: device '
                    'convection + rhs SpMV + preconditioned Krylov saddle solve '
                    '+ p rescale)'
-                   .format(args.Re),
+                   .format(args.Re, args.scheme.upper()),
             value=value, unit='timesteps/s', n_gpus=world, steps=args.steps,
             warmup=args.warmup, ms_per_step=1e3*wall/args.steps,
             higher_is_better=True, scaling=scaling, vs_baseline=None,
             dtype='f64', data='synthetic',
-            config=dict(workload='cylinderwake N={0} Re={1:g} CNAB dt=1/{2} '
+            config=dict(workload='cylinderwake N={0} Re={1:g} ' +
+                        args.scheme.upper() + ' dt=1/{2} '
                         'Taylor-Hood NV={3} NP={4}; convection N(v)v '
                         'evaluated on the device every step; state: Stokes '
                         'solution advanced {5} untimed spin-up steps'
@@ -996,15 +1119,14 @@ def main():
                                 args.warmup, args.warmup + args.steps)),
                         parallelism=mode, collectives=None,
                         row_partitioned=partitioned,
+                        scheme=args.scheme,
+                        carry_residual=bool(args.carry),
+                        weak_scaling_bandwidth_base=bw_base,
                         method=args.method, cheb_degree=args.cheb,
                         factorization=args.fact, drop_tol=args.drop,
                         schur='dense', rtol=args.rtol,
                         launch='eager' if args.eager else 'hipGraph',
                         krylov_iters_per_step=iters/float(args.steps),
-                        steps_per_s_convection_frozen=(
-                            world*args.steps/wall_fr),
-                        krylov_iters_per_step_frozen=(
-                            iters_fr/float(args.steps)),
                         true_relres_last=last['true_relres'],
                         timed_run_record=last['run_record'],
                         newton_picard_sweeps=picard,

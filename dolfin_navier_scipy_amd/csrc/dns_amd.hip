@@ -730,9 +730,11 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
             DNS_TRY(lv.Apre.upload(&av, stream));
             DNS_TRY(lv.Rr.upload(&rv, stream));
             DNS_TRY(lv.Qq.upload(&qv, stream));
-            if (fp32_store && !comm) {
+            if (fp32_store) {
                 // the cycle is part of the preconditioner: its operators cross
-                // the HBM as fp32 where they are streamed (6 B per non-zero)
+                // the HBM as fp32 where they are streamed (6 B per non-zero;
+                // a level that is row-partitioned later uploads its row blocks,
+                // which drops the copy: those levels stream fp64)
                 for (CsrDev *op : {&lv.Apre, &lv.Rr, &lv.Qq, &lv.S})
                     if (streams(*op))
                         DNS_TRY(to_f32(op->vals.p, op->vals32,

@@ -40,6 +40,7 @@ inline int grid_for_elems(int64_t n) {
 }
 
 inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
+    vals32.release();     // (a copy of OTHER values: whoever wants one remakes it)
     nrows = a->nrows;
     ncols = a->ncols;
     nnz = a->nnz;
