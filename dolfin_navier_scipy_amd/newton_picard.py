@@ -279,34 +279,100 @@ class TrapezoidalStepper(object):
                                                       device_seconds=secs)
 
 
+def time_sections(trange, nsects=1, addfullsweep=False):
+    """local time ranges of the sweeps: `nsects` sections of
+    `floor(len(trange)/nsects)` steps sharing their end points, the last one
+    takes the rest; `addfullsweep` appends the whole range (snu:1076-1086)"""
+    trange = np.asarray(trange, dtype=np.float64)
+    if nsects == 1:
+        return [trange]
+    lensect = int(np.floor(trange.size/nsects))
+    out = [trange[k*lensect:(k+1)*lensect+1] for k in range(nsects-1)]
+    out.append(trange[(nsects-1)*lensect:])
+    if addfullsweep:
+        out.append(trange)
+    return out
+
+
 def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
                   vel_nwtn_stps=2, vel_nwtn_tol=1e-14, opts=None,
-                  extrapolate=2, rhs_table=None):
+                  extrapolate=2, rhs_table=None, nsects=1,
+                  loc_nwtn_tol=5e-15, loc_pcrd_stps=True, addfullsweep=False,
+                  tables=None):
     """Picard sweeps first, then Newton sweeps, each linearised about the
     previous sweep's trajectory (snu:1304-1334, 1562-1587).  `linpoints0`:
-    `{t: v_inner}` for the first sweep.  `rhs_table (NV, len(trange))`: the
-    momentum rhs per time instance (`cfv + fvtd(t)`).  Returns `(vdict,
-    pdict, hist)`."""
+    `{t: v_inner}` for the first sweep (key `None`: the value for every time
+    without one of its own, snu:1427-1431).  `rhs_table (NV, len(trange))`:
+    the momentum rhs per time instance (`cfv + fvtd(t)`).  `tables`: dict of
+    per-time-instance data, one COLUMN per entry of `trange` -- `fv` (NV),
+    `fp` (NP), `mbc` (NV; `condense_velmatsbybcs(M, ..., get_rhs_only=True)`
+    of the controlled boundary values, snu:1438-1441) and `dbc` (the
+    convection operator's Dirichlet values): controlled Dirichlet values that
+    are functions of the time (snu:1433-1466).
+
+    `nsects`, `loc_nwtn_tol`, `loc_pcrd_stps`, `addfullsweep` as in the
+    reference (snu:1076-1091, 1576-1587): the time range is cut into sections
+    that are iterated one after the other -- each starts from the end of the
+    one before, has its own Picard count and tolerance -- and an optional last
+    sweep over the whole range restarts from the initial value.  Returns
+    `(vdict, pdict, hist)` over all times computed."""
     trange = np.asarray(trange, dtype=np.float64)
+    sections = time_sections(trange, nsects, addfullsweep)
+    if nsects == 1:
+        loc_nwtn_tol, addfullsweep = vel_nwtn_tol, False
+    tabs_all = {k: np.asarray(v).T for k, v in (tables or {}).items()
+                if v is not None}
     if rhs_table is not None:
-        tab = np.zeros((stepper.nslots, stepper.NV))
-        tab[:trange.size] = np.asarray(rhs_table).T
-        stepper.set_tables(fv_tab=tab)
-    which = 0
-    for k, t in enumerate(trange):
-        stepper.write_linpoint(which, k, linpoints0[t])
+        tabs_all['fv'] = np.asarray(rhs_table).T
+    index = {t: k for k, t in enumerate(trange)}
+    plain = len(sections) == 1
+    vel_loc_pcrd_steps = vel_pcrd_stps
+    realiniv = np.array(iniv, dtype=np.float64).reshape((-1, 1))
+    cur = dict(linpoints0)
     newtk, norm_nwtnupd = 0, 1.
     hist = []
-    vdict = pdict = None
-    while newtk < vel_nwtn_stps and norm_nwtnupd > vel_nwtn_tol:
-        if vel_pcrd_stps > 0:
-            vel_pcrd_stps -= 1
-            picard = True
-        else:
-            picard = False
-            newtk += 1
-        vdict, pdict, norm_nwtnupd, _ = stepper.sweep(
-            trange, iniv, which, picard, opts=opts, extrapolate=extrapolate)
-        hist.append(('picard' if picard else 'newton', norm_nwtnupd))
-        which = 1 - which           # the new trajectory = next lin. points
-    return vdict, pdict, hist
+    vall, pall = {}, {}
+    for si, loctrng in enumerate(sections):
+        if tabs_all:
+            rows = [index[t] for t in loctrng]
+            sect = {}
+            for name, full in tabs_all.items():
+                tab = np.zeros((stepper.nslots, full.shape[1]))
+                tab[:len(rows)] = full[rows]
+                tab[len(rows):] = full[rows[-1]]
+                sect[name + '_tab'] = tab
+            stepper.set_tables(**sect)
+        which = 0
+        first = True
+        while newtk < vel_nwtn_stps and norm_nwtnupd > loc_nwtn_tol:
+            if vel_pcrd_stps > 0:
+                vel_pcrd_stps -= 1
+                picard = True
+            else:
+                picard = False
+                newtk += 1
+            if first or not plain:
+                # slot k <-> loctrng[k]; later sweeps of the ONE section of a
+                # plain run read the trajectory the sweep before has left on
+                # the device, sectioned runs hand the points over per sweep
+                which = 0
+                for k, t in enumerate(loctrng):
+                    stepper.write_linpoint(
+                        which, k, cur[t] if t in cur else cur[None])
+                first = False
+            vdict, pdict, norm_nwtnupd, _ = stepper.sweep(
+                loctrng, iniv, which, picard, opts=opts,
+                extrapolate=extrapolate)
+            hist.append(('picard' if picard else 'newton', norm_nwtnupd))
+            which = 1 - which       # the new trajectory = next lin. points
+            cur.update(vdict)
+            vall.update(vdict)
+            pall.update(pdict)
+        iniv = vall[loctrng[-1]]
+        if addfullsweep and si == len(sections) - 2:
+            iniv = realiniv
+            loc_nwtn_tol = vel_nwtn_tol
+        elif loc_pcrd_stps:
+            vel_pcrd_stps = vel_loc_pcrd_steps
+        norm_nwtnupd, newtk = 1., 0
+    return vall, pall, hist

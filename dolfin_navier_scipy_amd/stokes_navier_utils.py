@@ -539,19 +539,45 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
     # Newton / Picard trapezoidal sweeps (snu:1304-1587)
     # =====================================================================
     from . import newton_picard as dnp
-    if len(loccnt) > 0 or nsects != 1 or addfullsweep:
-        raise NotImplementedError(
-            'Newton/Picard sweeps with controlled Dirichlet values or time '
-            'sections: use `newton_picard.TrapezoidalStepper` directly')
-    cvop = _conv_operator(V, dbcnt, list(dbcinds), device=device)
-    cvop.set_dbcvals(dbcvals)
+    tables = None
+    if len(loccnt) > 0:
+        # controlled Dirichlet values in the sweeps (snu:1433-1466): per time
+        # instance the stiffness / divergence / mass columns of the controlled
+        # dofs go to the right-hand sides and the convection sees the values
+        # -- tabulated, the sweeps stay on the device
+        if not bcs_time_only:
+            raise NotImplementedError(
+                'Newton/Picard sweeps with controlled Dirichlet values that '
+                'depend on the state: pass `bcs_time_only=True` if the control '
+                'functions depend on the time only')
+        cdbs = [_comp_cntrl_bcvals(time=t, vel=None, p=None, **cdict)
+                for t in trange]
+        fvt, fpt, mbt, dbt = [], [], [], []
+        for t, cdb in zip(trange, cdbs):
+            ccfv_t, ccfp_t = _cntrl_stffnss_rhs(cntrlldbcvals=cdb, **cdict)
+            ft = cfv + ccfv_t
+            if fvtd is not None:
+                ft = ft + np.asarray(fvtd(t)).reshape((-1, 1))
+            fvt.append(ft)
+            fpt.append(cfp + ccfp_t)
+            mbt.append(dbc.condense_velmatsbybcs_rhs(
+                Mfull, invinds=locinv, dbcinds=loccnt, dbcvals=cdb))
+            dbt.append(np.array(list(dbcvals) + list(cdb)).reshape((-1, 1)))
+        tables = dict(fv=np.hstack(fvt), fp=np.hstack(fpt),
+                      mbc=np.hstack(mbt), dbc=np.hstack(dbt))
+        cvop = _conv_operator(V, dbcnt, list(dbcinds) + list(glb),
+                              device=device)
+        cvop.set_dbcvals(list(dbcvals) + list(cdbs[0]))
+    else:
+        cvop = _conv_operator(V, dbcnt, list(dbcinds), device=device)
+        cvop.set_dbcvals(dbcvals)
     dt = trange[1] - trange[0]
     ts = dnp.TrapezoidalStepper(cmmat, camat, cj, cvop,
                                 nslots=trange.size, dt=dt, device=device,
                                 precond=(solver or {}).get('precond'))
     try:
         fvtab = None
-        if fvtd is not None:
+        if fvtd is not None and tables is None:
             fvtab = np.hstack([cfv + np.asarray(fvtd(t)).reshape((-1, 1))
                                for t in trange])
         ts.set_rhs(cfv, cfp)
@@ -564,21 +590,29 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
             val = np.asarray(val, dtype=np.float64).reshape((-1, 1))
             return val[dbcnt] if val.shape[0] == vdim else val
         linpoints = {t: _lp(t) for t in trange}
+        try:
+            if None in cur_linvel_point:
+                linpoints[None] = _lp(None)
+        except TypeError:
+            pass
         vdict, pdict_, hist = dnp.newton_picard(
             ts, trange, iniv, linpoints, vel_pcrd_stps=vel_pcrd_stps,
             vel_nwtn_stps=vel_nwtn_stps, vel_nwtn_tol=vel_nwtn_tol,
-            rhs_table=fvtab,
-            opts=(solver or {}).get('opts'))
+            rhs_table=fvtab, nsects=nsects, loc_nwtn_tol=loc_nwtn_tol,
+            loc_pcrd_stps=loc_pcrd_stps, addfullsweep=addfullsweep,
+            tables=tables, opts=(solver or {}).get('opts'))
     finally:
         ts.close()
     tlast = trange[-1]
     v_old, p_old = vdict[tlast], pdict_[tlast]
+    cat = {t: [] for t in trange} if tables is None else \
+        {t: cdb for t, cdb in zip(trange, cdbs)}
     if return_final_vp:
-        return (_appbcs(v_old, []), p_old)
+        return (_appbcs(v_old, cat[tlast]), p_old)
     if return_dictofvelstrs:
-        vfull = {t: _appbcs(v, []) for t, v in vdict.items()}
+        vfull = {t: _appbcs(v, cat[t]) for t, v in vdict.items()}
         return (vfull, pdict_) if return_dictofpstrs else vfull
     if return_vp_dict:
-        return {t: dict(v=_appbcs(vdict[t], []), p=pdict_.get(t))
+        return {t: dict(v=_appbcs(vdict[t], cat[t]), p=pdict_.get(t))
                 for t in vdict}
     return hist

@@ -185,33 +185,75 @@ def _sweep_timedep(trange, iniv, M, A, J, JT, fv, fp, conv, appndbcs,
     return vdict, pdict, norm_nwtnupd
 
 
+def time_sections(trange, nsects=1, addfullsweep=False):
+    """the local time ranges of the sweeps (snu:1076-1086): `nsects` sections
+    of `floor(len(trange)/nsects)` steps that share their end points, the
+    last one taking the rest; `addfullsweep` appends the whole range"""
+    trange = np.asarray(trange)
+    lensect = int(np.floor(trange.size/nsects))
+    loctrngs = [trange[k*lensect:(k+1)*lensect+1] for k in range(nsects-1)]
+    loctrngs.append(trange[(nsects-1)*lensect:])
+    if addfullsweep:
+        loctrngs.append(trange)
+    if nsects == 1:
+        loctrngs = [trange]
+    return loctrngs
+
+
 def newton_picard(trange, iniv, linpoints0, vel_pcrd_stps=1, vel_nwtn_stps=2,
-                  vel_nwtn_tol=1e-14, invinds=None, **kw):
+                  vel_nwtn_tol=1e-14, invinds=None, nsects=1,
+                  loc_nwtn_tol=5e-15, loc_pcrd_stps=True, addfullsweep=False,
+                  **kw):
     """Picard sweeps first, then Newton sweeps, each linearised about the
-    previous sweep's trajectory (snu:1304-1334, 1574)"""
-    linpoints = linpoints0
+    previous sweep's trajectory (snu:1304-1334, 1574), section by section
+    (snu:1076-1090): every section starts from the end of the one before,
+    iterates until `loc_nwtn_tol` with its own Picard count (`loc_pcrd_stps`)
+    and the optional full sweep at the end restarts from the true initial
+    value with `vel_nwtn_tol` (snu:1579-1587).  Linearisation points of times
+    not yet computed come from `linpoints0[None]` (snu:1427-1431)."""
+    def appnd(v, t):
+        try:
+            return kw['appndbcs'](v, t)          # time-dependent boundary values
+        except TypeError:
+            return kw['appndbcs'](v)
+    loctrngs = time_sections(trange, nsects, addfullsweep)
+    if nsects == 1:
+        loc_nwtn_tol, addfullsweep = vel_nwtn_tol, False            # snu:1087
+    vel_loc_pcrd_steps = vel_pcrd_stps                               # snu:1091
+    realiniv = np.copy(iniv)
+    cur = dict(linpoints0)
     newtk, norm_nwtnupd = 0, 1.
     hist = []
-    vdict = pdict = None
-    while newtk < vel_nwtn_stps and norm_nwtnupd > vel_nwtn_tol:
-        if vel_pcrd_stps > 0:
-            vel_pcrd_stps -= 1
-            picard = True
-        else:
-            picard = False
-            newtk += 1
-        inner = {t: (v if v.shape[0] == len(invinds) else v[invinds, :])
-                 for t, v in linpoints.items()}
-        vdict, pdict, _ = trapezoidal_sweep(trange, iniv, linpoints=linpoints,
-                                            picard=picard, **kw)
-        norm_nwtnupd = sum(
-            (trange[k+1]-trange[k])*m_innerproduct(
-                kw['M'], vdict[trange[k+1]] - inner[trange[k+1]]).item()
-            for k in range(len(trange)-1))                          # snu:1557-1560
-        hist.append(('picard' if picard else 'newton', norm_nwtnupd))
-        appnd = kw['appndbcs']
-        linpoints = {t: appnd(v) for t, v in vdict.items()}        # snu:1574
-    return vdict, pdict, hist
+    vall, pall = {}, {}
+    for si, loctrng in enumerate(loctrngs):
+        while newtk < vel_nwtn_stps and norm_nwtnupd > loc_nwtn_tol:
+            if vel_pcrd_stps > 0:
+                vel_pcrd_stps -= 1
+                picard = True
+            else:
+                picard = False
+                newtk += 1
+            lin = {t: (cur[t] if t in cur else cur[None]) for t in loctrng}
+            inner = {t: (v if v.shape[0] == len(invinds) else v[invinds, :])
+                     for t, v in lin.items()}
+            vdict, pdict, _ = trapezoidal_sweep(loctrng, iniv, linpoints=lin,
+                                                picard=picard, **kw)
+            norm_nwtnupd = sum(
+                (loctrng[k+1]-loctrng[k])*m_innerproduct(
+                    kw['M'], vdict[loctrng[k+1]] - inner[loctrng[k+1]]).item()
+                for k in range(len(loctrng)-1))                     # snu:1557-1560
+            hist.append(('picard' if picard else 'newton', norm_nwtnupd))
+            cur.update({t: appnd(v, t) for t, v in vdict.items()})  # snu:1574
+            vall.update(vdict)
+            pall.update(pdict)
+        iniv = vall[loctrng[-1]]                                     # snu:1576
+        if addfullsweep and si == len(loctrngs) - 2:                 # snu:1579
+            iniv = realiniv
+            loc_nwtn_tol = vel_nwtn_tol
+        elif loc_pcrd_stps:
+            vel_pcrd_stps = vel_loc_pcrd_steps
+        norm_nwtnupd, newtk = 1., 0                                  # snu:1586
+    return vall, pall, hist
 
 
 def get_pfromv(v=None, M=None, A=None, J=None, fv=None, conv=None,

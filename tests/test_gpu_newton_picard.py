@@ -231,6 +231,43 @@ def test_device_newton_picard_driver_matches_oracle(setup, cvop):
     stp.close()
 
 
+def test_device_time_sections_and_full_sweep_match_oracle(setup, cvop):
+    """`nsects = 3`, `addfullsweep` (snu:1076-1090, 1576-1587) through the
+    device stepper: same sweep sequence, update norms and iterates as the
+    oracle's restatement"""
+    from dolfin_navier_scipy_amd import newton_picard as dnp, saddle
+    s = setup
+    tr = s['trange']
+    lin_full = {t: s['appnd'](v) for t, v in s['lin0'].items()}
+    lin_full[None] = lin_full[tr[0]]
+    kw = dict(vel_pcrd_stps=1, vel_nwtn_stps=2, nsects=3, loc_nwtn_tol=1e-13,
+              addfullsweep=True)
+    ref_v, ref_p, ref_hist = npo.newton_picard(
+        tr, s['iniv'], lin_full, invinds=s['inv'], M=s['M'], A=s['A'],
+        J=s['J'], fv=s['fv'], fp=s['fp'], conv=s['conv'],
+        appndbcs=s['appnd'], **kw)
+    stp = dnp.TrapezoidalStepper(s['M'], s['A'], s['J'], cvop, nslots=tr.size,
+                                 dt=tr[1] - tr[0], precond=dict(cheb_degree=4))
+    stp.set_rhs(s['fv'], s['fp'])
+    opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True)
+    lin0 = dict(s['lin0'])
+    lin0[None] = s['lin0'][tr[0]]
+    got_v, got_p, hist = dnp.newton_picard(stp, tr, s['iniv'], lin0,
+                                           opts=opts, **kw)
+    assert [h[0] for h in hist] == [h[0] for h in ref_hist]
+    # one Picard sweep per section, none in the full sweep (the `elif` at
+    # snu:1583 does not refill its Picard count); a section stops early once
+    # its update norm is below `loc_nwtn_tol`
+    assert [h[0] for h in hist].count('picard') == 3 and len(hist) >= 8
+    for (_, a), (_, b) in zip(hist, ref_hist):
+        assert abs(a - b) <= 1e-5*abs(b) + 1e-15
+    for t in tr[1:]:
+        ev = np.linalg.norm(got_v[t] - ref_v[t])/np.linalg.norm(ref_v[t])
+        ep = np.linalg.norm(got_p[t] - ref_p[t])/np.linalg.norm(ref_p[t])
+        assert ev <= 1e-8 and ep <= 1e-8, (t, ev, ep)
+    stp.close()
+
+
 def test_full_size_picard_and_newton_sweep_against_oracle():
     """cylinder wake N=2 (NV=9356, NP=1289), Re=100, dt=1/512: a Picard and a
     Newton sweep of 6 steps, device path vs the oracle's restatement with the

@@ -333,6 +333,74 @@ def test_solve_nse_newton_picard_branch(snu, toy_prob):
                            toy_prob['dbcvals'])
 
 
+def test_solve_nse_newton_picard_sections_and_full_sweep(snu, toy_prob):
+    """`nsects`, `addfullsweep`, `loc_pcrd_stps` (snu:1076-1091, 1576-1587)
+    through the product `solve_nse` against the oracle"""
+    kw, rec, _ = scenarios.build(variant='plain', seed=0, Nts=9, tE=0.045,
+                                 prob=toy_prob)
+    imex_oracle.cnab(**kw)
+    times, vels, _ = rec.arrays()
+    lin0 = {t: vels[k].reshape((-1, 1)) for k, t in enumerate(times)}
+    lin0[None] = lin0[times[0]]
+    skw = _static_kwargs(toy_prob, kw)
+    sect = dict(nsects=3, loc_nwtn_tol=1e-13, addfullsweep=True,
+                vel_pcrd_stps=1, vel_nwtn_stps=2)
+    vdo, pdo, histo = so.solve_nse(lin_vel_point=lin0, **sect, **skw)
+    vdg, pdg = snu.solve_nse(lin_vel_point=lin0, treat_nonl_explicit=False,
+                             return_dictofvelstrs=True,
+                             return_dictofpstrs=True, **sect, **skw)
+    # one Picard sweep per section, none in the full sweep (snu:1583)
+    assert [h[0] for h in histo].count('picard') == 3
+    inv = toy_prob['invinds']
+    for t in kw['trange'][1:]:
+        assert _rel(vdg[t][inv], vdo[t]) <= VTOL, t
+        assert _rel(pdg[t], pdo[t]) <= PTOL, t
+
+
+def test_solve_nse_newton_picard_controlled_dirichlet(snu, toy_prob):
+    """controlled Dirichlet values (functions of the time) INSIDE the sweeps
+    (snu:1433-1466): stiffness / divergence / mass columns of the controlled
+    dofs per time instance in the right-hand sides, the values in the
+    convection matrices -- device tables against the oracle"""
+    mk = _controlled_setup(toy_prob, amplitude=0.3)
+    base = mk()
+    trange = base['trange'][:7]
+    # linearisation points: the explicit run with the same boundary motion
+    rec = scenarios.Recorder()
+    so.solve_nse(**dict(mk(), trange=trange, savevp=rec))
+    times, vels, _ = rec.arrays()
+    lin0 = {t: vels[k].reshape((-1, 1)) for k, t in enumerate(times)}
+    kw = dict(mk(), trange=trange, lin_vel_point=lin0, vel_pcrd_stps=1,
+              vel_nwtn_stps=2)
+    vdo, pdo, histo = so.solve_nse(**kw)
+    kw = dict(mk(), trange=trange, lin_vel_point=lin0, vel_pcrd_stps=1,
+              vel_nwtn_stps=2)
+    vdg, pdg = snu.solve_nse(treat_nonl_explicit=False, bcs_time_only=True,
+                             return_dictofvelstrs=True,
+                             return_dictofpstrs=True, **kw)
+    # the oracle's velocities live on the inner dofs of the system with the
+    # controlled dofs removed
+    cnt = set(kw['diricontbcinds'][0])
+    dbcnt = np.array([i for i in kw['invinds'] if i not in cnt])
+    assert [h[0] for h in histo] == ['picard', 'newton', 'newton']
+    for t in trange[1:]:
+        assert vdo[t].shape[0] == dbcnt.size
+        assert not np.isnan(vdg[t]).any()
+        assert _rel(vdg[t][dbcnt], vdo[t]) <= VTOL, t
+        assert _rel(pdg[t], pdo[t]) <= PTOL, t
+    # the boundary motion matters: held at its initial value the flow differs
+    still = dict(mk(), trange=trange, lin_vel_point=lin0, vel_pcrd_stps=1,
+                 vel_nwtn_stps=2)
+    still['diricontfuncs'] = [lambda t, vel=None, p=None, mode=None,
+                              memory=None: (1.0, memory)]
+    vds, _, _ = so.solve_nse(**still)
+    assert _rel(vds[trange[-1]], vdo[trange[-1]]) > 1e-4
+    # state-dependent controls need a host round trip per step: not offered
+    with pytest.raises(NotImplementedError):
+        snu.solve_nse(treat_nonl_explicit=False, **dict(
+            mk(), trange=trange, lin_vel_point=lin0))
+
+
 # ---- f2: per-step tables of the resident loops --------------------------------
 def test_imex_rhs_table_equals_per_step_uploads(toy_prob):
     """`dns_imex_set_rhs_table` + pipelined `run` == `set_rhs` + `step` per

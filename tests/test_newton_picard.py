@@ -84,6 +84,36 @@ def test_oracle_trapezoidal_residual_and_newton_convergence(setup):
         assert np.abs(J @ vn - s['fp']).max() <= 1e-10
 
 
+def test_oracle_time_sections_and_full_sweep(setup):
+    """`nsects`, `addfullsweep` (snu:1076-1090, 1576-1587): the sections share
+    their end points and cover the range; the sectioned iteration converges to
+    the SAME discrete trapezoidal solution as the plain one"""
+    s = setup
+    tr = s['trange']
+    secs = npo.time_sections(tr, nsects=3, addfullsweep=True)
+    assert len(secs) == 4 and np.array_equal(secs[-1], tr)
+    assert secs[0][0] == tr[0] and secs[2][-1] == tr[-1]
+    assert secs[0][-1] == secs[1][0] and secs[1][-1] == secs[2][0]
+    assert len(npo.time_sections(tr, 1, True)) == 1           # snu:1087-1090
+    plain_v, plain_p, _ = npo.newton_picard(
+        tr, s['iniv'], s['lin0'], vel_pcrd_stps=1, vel_nwtn_stps=5,
+        invinds=s['inv'], **_sweep_kwargs(s))
+    lin0 = dict(s['lin0'])
+    lin0[None] = s['lin0'][tr[0]]
+    sec_v, sec_p, hist = npo.newton_picard(
+        tr, s['iniv'], lin0, vel_pcrd_stps=1, vel_nwtn_stps=5,
+        invinds=s['inv'], nsects=3, loc_nwtn_tol=1e-14, addfullsweep=True,
+        **_sweep_kwargs(s))
+    # every section has its own Picard sweep (loc_pcrd_stps); the full sweep
+    # has none (the `elif` at snu:1583 does not refill the Picard count)
+    assert [h[0] for h in hist].count('picard') == 3
+    for t in tr[1:]:
+        assert np.linalg.norm(sec_v[t] - plain_v[t]) <= \
+            1e-8*np.linalg.norm(plain_v[t]), t
+        assert np.linalg.norm(sec_p[t] - plain_p[t]) <= \
+            1e-6*np.linalg.norm(plain_p[t]), t
+
+
 def test_oracle_get_pfromv_consistency(setup):
     """reference tests/test_units_pfromv.py:45 in algebraic form: the pressure
     recomputed from a velocity satisfies the momentum equation's projection"""
