@@ -167,8 +167,11 @@ class TaylorHood(object):
     def _vel_at_qp(self, uvec):
         """velocity `(nc,nq,2)` and its gradient `(nc,nq,2,2)` [i, j]=d_j u_i"""
         uloc = np.asarray(uvec).reshape(-1)[self._vdofs()]         # (nc,6,2)
-        uq = np.einsum('qa,cai->cqi', self._phi, uloc)
-        guq = np.einsum('cqaj,cai->cqij', self._gphi, uloc)
+        # (batched matrix products instead of einsum: 5x faster, the host
+        # convection callback of the oracle legs runs thousands of times)
+        uq = np.matmul(self._phi[None, :, :], uloc)                # cqi
+        guq = np.matmul(uloc.transpose(0, 2, 1)[:, None, :, :],
+                        self._gphi)                                # cqij
         return uq, guq
 
     def convection_vec(self, uvec, utwo=None):
@@ -177,10 +180,11 @@ class TaylorHood(object):
         if utwo is not None:
             uq, _ = self._vel_at_qp(utwo)
         w = _QW[None, :]*self.area[:, None]
-        conv = np.einsum('cqij,cqj->cqi', guq, uq)               # (nc,nq,2)
-        floc = np.einsum('cq,qa,cqi->cai', w, self._phi, conv)   # (nc,6,2)
-        fvec = np.zeros(self.vdim)
-        np.add.at(fvec, self._vdofs().ravel(), floc.ravel())
+        conv = np.matmul(guq, uq[:, :, :, None])[:, :, :, 0]     # (nc,nq,2)
+        floc = np.matmul(self._phi.T[None, :, :],
+                         w[:, :, None]*conv)                      # (nc,6,2)
+        fvec = np.bincount(self._vdofs().ravel(), weights=floc.ravel(),
+                           minlength=self.vdim)
         return fvec.reshape((-1, 1))
 
     def convection_mats(self, u0vec, keep_pattern=False):
