@@ -35,7 +35,7 @@ namespace dns {
 //   the NEXT state is K^-1 [theta dt A delta_v; 0] (small for the smooth
 //   components that would add up) -- the distance to the direct-solve
 //   trajectory stops growing with the number of steps
-//   (scratch/comp_proto.py: 10-20x at 800 steps of the wake at Re = 100).
+//   (scripts/carry_over_model.py: 10-20x at 800 steps of the wake at Re = 100).
 struct CarryRef {
     double *kx_c;                       // out: K x_c (ring slot of x_c)
     const double *kx_p, *kx_pp, *kx_p3, *kx_p4;
