@@ -30,11 +30,85 @@ __constant__ ConvTables c_conv;
 // the twelve local sums are reduced over the eight lanes with xor shuffles and
 // lane l stores slots l and l + 8.  (One thread per cell left the kernel with
 // 18 workgroups and a serial chain of ~700 fp64 operations: ~10 us at N=2.)
+// where the value of inner dof m comes from: a vector, or -- in the tail kernel
+// of a resident time step, where the new solution is still being written by
+// other workgroups -- its definition x0 + sum_j y_j Z_j evaluated per entry
+struct ConvFromVec {
+    const double *__restrict__ v;
+    __device__ __forceinline__ double at(int m) const { return v[m]; }
+};
+
+struct ConvFromCombo {
+    const double *__restrict__ x0;      // warm start of the solve
+    const double *__restrict__ Z;       // kept preconditioned basis, column j
+    size_t ld;
+    const double *y;                    // coefficients (LDS)
+    int ncols;
+    __device__ __forceinline__ double at(int m) const {
+        double s = x0[m];
+        for (int j = 0; j < ncols; ++j) s = fma(y[j], Z[(size_t)j * ld + m], s);
+        return s;
+    }
+};
+
+// The element computation on twelve local values already in registers
+__device__ __forceinline__ void
+conv_cells_compute(const double (&ul)[6][2], int ncells, int cc, int c, int q,
+                   bool live, const double *__restrict__ glam,
+                   const double *__restrict__ area,
+                   double *__restrict__ cellvals) {
+    const int qq = (q < 7) ? q : 0;
+    double gl[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gl[k][0] = glam[(size_t)(2 * k) * ncells + cc];
+        gl[k][1] = glam[(size_t)(2 * k + 1) * ncells + cc];
+    }
+    double uq[2] = {0.0, 0.0};
+    double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    double ph[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        ph[a] = c_conv.phi[qq][a];
+        const double d0 = c_conv.dphi[qq][a][0], d1 = c_conv.dphi[qq][a][1],
+                     d2 = c_conv.dphi[qq][a][2];
+        const double gx = d0 * gl[0][0] + d1 * gl[1][0] + d2 * gl[2][0];
+        const double gy = d0 * gl[0][1] + d1 * gl[1][1] + d2 * gl[2][1];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uq[i] = fma(ph[a], ul[a][i], uq[i]);
+            g[i][0] = fma(gx, ul[a][i], g[i][0]);
+            g[i][1] = fma(gy, ul[a][i], g[i][1]);
+        }
+    }
+    const double wq = (q < 7 && live) ? c_conv.qw[qq] * area[cc] : 0.0;
+    const double cv0 = wq * (g[0][0] * uq[0] + g[0][1] * uq[1]);
+    const double cv1 = wq * (g[1][0] * uq[0] + g[1][1] * uq[1]);
+    double mine = 0.0, mine8 = 0.0;
+#pragma unroll
+    for (int sl = 0; sl < 12; ++sl) {
+        double v = ph[sl >> 1] * ((sl & 1) ? cv1 : cv0);
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        if (sl < 8) {
+            if (q == sl) mine = v;
+        } else {
+            if (q == sl - 8) mine8 = v;
+        }
+    }
+    if (live) {
+        cellvals[(size_t)q * ncells + c] = mine;
+        if (q < 4) cellvals[(size_t)(q + 8) * ncells + c] = mine8;
+    }
+}
+
+template <typename VAL>
 __device__ __forceinline__ void
 conv_cells_block(int bid, int ncells, const int *__restrict__ cellmap,   // [12][ncells]
              const double *__restrict__ glam,               // [6][ncells]
              const double *__restrict__ area,
-             const double *__restrict__ v_inner, TabRef dbctab,
+             const VAL vsrc, TabRef dbctab,
              double *__restrict__ cellvals,                 // [12][ncells]
              const int *__restrict__ sel = nullptr, int nsel = 0) {
     // sel: only the cells sel[0..nsel) (row-partitioned time steppers: the
@@ -54,7 +128,7 @@ conv_cells_block(int bid, int ncells, const int *__restrict__ cellmap,   // [12]
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = cellmap[(size_t)(2 * a + i) * ncells + cc];
-            ul[a][i] = (m >= 0) ? v_inner[m] : dbcvals[-m - 1];
+            ul[a][i] = (m >= 0) ? vsrc.at(m) : dbcvals[-m - 1];
         }
     double gl[3][2];
 #pragma unroll
@@ -107,8 +181,8 @@ k_conv_cells(int ncells, const int *__restrict__ cellmap,
              const double *__restrict__ v_inner, TabRef dbctab,
              double *__restrict__ cellvals, const int *__restrict__ sel,
              int nsel) {
-    conv_cells_block(blockIdx.x, ncells, cellmap, glam, area, v_inner, dbctab,
-                     cellvals, sel, nsel);
+    conv_cells_block(blockIdx.x, ncells, cellmap, glam, area,
+                     ConvFromVec{v_inner}, dbctab, cellvals, sel, nsel);
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -138,6 +212,7 @@ struct dns_conv {
     dns::DevBuf<double> dbc_tab;
     int dbc_rows = 0, dbc_row = 0;
     const int *dbc_ctr = nullptr;
+    uint64_t dbc_gen = 0;     // bumped whenever the values / the table change
     dns::TabRef dbc_ref(int row_shift = 0) const {
         if (dbc_rows <= 0) return {dbcvals.p, nullptr, 0, 1};
         if (dbc_ctr) return {dbc_tab.p, dbc_ctr, std::max(1, ndbc), dbc_rows};

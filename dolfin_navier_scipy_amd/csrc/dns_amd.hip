@@ -1334,19 +1334,34 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     auto kparts = [&](int jj) {
         return (stream_k && jj + 1 <= kStreamDots) ? gridK : gridC;
     };
+    // six-node step: K z_j is kept per column (the tail forms the new
+    // residual r0 - sum y_j K z_j from them)
+    const bool s6 = step6.on && fusedgs && !stream_k && have_resid &&
+                    Wcols.n >= (size_t)c * ld;
+    auto wcol = [&](int jj) -> double * {
+        return s6 ? Wcols.p + (size_t)jj * ld : w.p;
+    };
     for (int j = 0; j < c; ++j) {
         // the preconditioned vectors are kept (Z_j) for the correction behind
         // the cycle
         double *zj = Z.p + (size_t)j * ld;
         double *zp = zj + nv;
-        const double *src = (j == 0) ? r.p : w.p;
+        const double *src = (j == 0) ? r.p : wcol(j - 1);
         const double *spart = (j == 0) ? rr_part : partN.p;
         const int snp = (j == 0) ? rr_np : gridD;
         // full block factorisation: tau = src_p - (J Fh^-1) src_v feeds the
         // Schur block instead of src_p (unguarded: 3 us when already done)
         const double *tin = nullptr;
         const bool mgs = popts.schur == DNS_SCHUR_MG;
-        if (have_jg && !mgs) {
+        if (s6 && j == 0 && step6.kx && have_jg && !mgs) {
+            // six-node step: r = b - kx is formed HERE (extra workgroups),
+            // the Schur rows gather b - kx themselves
+            const int gt = std::max(1, std::min((np + 1) / 2, 4096));
+            hipLaunchKernelGGL(k_tau_first, gt + gridD, kBlock, 0, stream, gt, n,
+                               np, nv, JG.rowptr.p, JG.colidx.p, JG.vals.p, b,
+                               step6.kx, tau.p, r.p, partR.p, partB.p);
+            tin = tau.p;
+        } else if (have_jg && !mgs) {
             const int jt = (fusedgs && j > 0) ? j : 0;
             DNS_LPR_SWITCH(
                 JG.lpr,
@@ -1361,7 +1376,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         }
         if (fusedgs && j > 0 && mgs) {
             hipLaunchKernelGGL(k_arn_head_f<3>, gridA, kBlock, 0, stream, n, nv,
-                               np, j, w.p, partA.p, kparts(j - 1), V.p, ld, Z.p,
+                               np, j, wcol(j - 1), partA.p, kparts(j - 1), V.p, ld, Z.p,
                                (const void *)nullptr, ctl.p, o->maxiter,
                                (const double *)nullptr);
         } else if (!(fusedgs && j > 0) && mgs) {
@@ -1374,19 +1389,19 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         } else if (fusedgs && j > 0) {
             if (dense && fp32_store)
                 hipLaunchKernelGGL(k_arn_head_f<2>, gridA, kBlock, 0, stream, n,
-                                   nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
+                                   nv, np, j, wcol(j - 1), partA.p, kparts(j - 1), V.p,
                                    ld,
                                    Z.p, (const void *)sinv32.p, ctl.p,
                                    o->maxiter, tin, 0, np, sld);
             else if (dense)
                 hipLaunchKernelGGL(k_arn_head_f<1>, gridA, kBlock, 0, stream, n,
-                                   nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
+                                   nv, np, j, wcol(j - 1), partA.p, kparts(j - 1), V.p,
                                    ld,
                                    Z.p, (const void *)sinv.p, ctl.p,
                                    o->maxiter, tin);
             else
                 hipLaunchKernelGGL(k_arn_head_f<0>, gridA, kBlock, 0, stream, n,
-                                   nv, np, j, w.p, partA.p, kparts(j - 1), V.p,
+                                   nv, np, j, wcol(j - 1), partA.p, kparts(j - 1), V.p,
                                    ld,
                                    Z.p, (const void *)sinv.p, ctl.p,
                                    o->maxiter, tin);
@@ -1466,7 +1481,7 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                 K.lpr,
                 hipLaunchKernelGGL(k_spmv_multidot<L>, gridC, kBlock, 0,
                                    stream, n, K.rowptr.p, K.colidx.p,
-                                   K.vals.p, zj, w.p, V.p, ld, j, partA.p,
+                                   K.vals.p, zj, wcol(j), V.p, ld, j, partA.p,
                                    gridC, ctl.p, RowMap{0, n, 0, 0},
                                    fusedgs ? 1 : 0));
             if (fusedgs) continue;       // no Gram-Schmidt kernel
@@ -1499,6 +1514,19 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             hipLaunchKernelGGL(k_orth<0>, gridD, kBlock, 0, stream, n, V.p, ld,
                                w.p, hpart, hnp, j, 0, partN.p, gridD, ctl.p);
         }
+    }
+    if (s6) {
+        // six-node step: out-of-place tail + new residual + convection cells
+        Tail6 t6 = step6.t6;
+        t6.r0 = r.p;
+        t6.W = Wcols.p;
+        t6.nv = nv;
+        hipLaunchKernelGGL(k_arn_tail6, gridD + step6.cells.nblocks, kBlock, 0,
+                           stream, c, n, gridD, partA.p, kparts(c - 1), ctl.p,
+                           histdev.p, (int)hist_cap, o->maxiter, Z.p, ld, t6,
+                           tail_extrap, step6.cells);
+        DNS_HIP(hipGetLastError());
+        return DNS_OK;
     }
     if (fusedgs) {
         // one GPU, fused Gram-Schmidt: tail and correction in ONE launch

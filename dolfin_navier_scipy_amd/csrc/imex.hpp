@@ -47,6 +47,16 @@ struct dns_imex {
     dns::DevBuf<double> kxs[6], rcarry, ckb, ckr;
     bool b_valid = false, carry_ok = false;
     int prime_carry(bool zero_r);
+    // six-node step (step_kernels.hpp): the warm start lives in x0buf[work & 1]
+    // (the tail reads one and writes the other), the residuals of the last two
+    // solves in rc6[.] (same parity), the convection cell values are produced
+    // by the tail of the step before.  `six_ok`: x0buf / cell values / rc6 are
+    // those of the ring as it stands (primed by prime_six or kept by six-node
+    // steps); DNS_STEP6=0 keeps the seven-node step
+    dns::DevBuf<double> x0buf[2], rc6[2], ckx0, ckrc[2], ckcell, kx6;
+    bool six_ok = false, env_six = true;
+    uint64_t six_conv_gen = 0;     // conv->dbc_gen the cell values belong to
+    int prime_six(const dns_imex_coeffs *cf, bool keep_r);
     // coefficients of the polynomial warm start from `nsol_` solutions
     static int extrap_coeffs(int nsol_, int order, double e[5]) {
         e[0] = 1.0;
@@ -143,11 +153,11 @@ struct dns_imex {
         long steps_enqueued;
         bool pre_ok;
         int pre_sig;
-        bool b_valid, carry_ok;
+        bool b_valid, carry_ok, six_ok;
     };
     HostState host_state() const {
         return {cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos,
-                steps_enqueued, pre_ok, pre_sig, b_valid, carry_ok};
+                steps_enqueued, pre_ok, pre_sig, b_valid, carry_ok, six_ok};
     }
     void set_host_state(const HostState &s) {
         cur = s.cur; prev = s.prev; pprev = s.pprev; p3 = s.p3; p4 = s.p4;
@@ -158,6 +168,7 @@ struct dns_imex {
         pre_sig = s.pre_sig;
         b_valid = s.b_valid;
         carry_ok = s.carry_ok;
+        six_ok = s.six_ok;
     }
     std::vector<uint64_t> group_key(const dns_imex_coeffs *cf,
                                     const dns_solve_opts *o, int group) const;

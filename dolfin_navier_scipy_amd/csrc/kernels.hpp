@@ -78,6 +78,24 @@ __device__ __forceinline__ void tail_extrapolate(const TailExtrap &t, int e,
     t.out[e] = v;
 }
 
+// arguments of the six-node resident step (step_kernels.hpp)
+struct TailCells {
+    int ncells, nblocks;                // nblocks == 0: no cell part
+    const int *cellmap;
+    const double *glam, *area;
+    TabRef dbctab;
+    double *cellvals;
+};
+
+struct Tail6 {
+    const double *x0;                   // warm start (not written here)
+    double *xout;                       // new solution
+    const double *r0;                   // residual the cycle started from
+    const double *W;                    // K z_j, column j at W + j ld
+    double *rnew;                       // velocity rows of the new residual
+    int nv;
+};
+
 // Rows a kernel launch works on: local row i of the (possibly sliced) CSR
 // arrays is global row `row0 + i` for i < len1, `row2 + i - len1` beyond -- one
 // GPU: {0, n, 0, 0}; row-partitioned: this rank's velocity rows, then its

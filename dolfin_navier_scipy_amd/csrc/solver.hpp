@@ -407,6 +407,18 @@ struct dns_saddle {
     dns::PairDev Kp;
     bool pair_knob = true;            // DNS_PAIR (read once, at create)
     int build_pair();
+    // six-node resident step (set by dns_imex around a solve): out-of-place
+    // tail with the new residual and the convection cells, K z_j kept per
+    // column in Wcols
+    struct Step6 {
+        bool on = false;
+        dns::Tail6 t6 = {};
+        dns::TailCells cells = {};
+        const double *kx = nullptr;   // K x0 of the step's first kernel: the
+                                      // residual r = b - kx is formed by the
+                                      // first tau kernel (k_tau_first)
+    } step6;
+    dns::DevBuf<double> Wcols;
     dns::TailExtrap tail_extrap = {}; // warm start of the next step, written
                                       // by the tail kernels (set by dns_imex)
     int prologue_nparts = 0;          // > 0: partials of ||r||^2, ||b||^2 the

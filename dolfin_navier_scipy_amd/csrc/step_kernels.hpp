@@ -13,6 +13,7 @@
 // kernel although only the (short) convection gather depends on it.
 #pragma once
 #include "convection.hpp"
+#include "gmres_kernels.hpp"
 #include "kernels.hpp"
 
 namespace dns {
@@ -65,8 +66,8 @@ k_step_front(int nconv_blocks,
     constexpr bool CARRY = MODE == 2;
     if ((int)blockIdx.x < nconv_blocks) {
         if (ncells > 0)
-            conv_cells_block(blockIdx.x, ncells, cellmap, glam, area, x_c,
-                             dbctab, cellvals);
+            conv_cells_block(blockIdx.x, ncells, cellmap, glam, area,
+                             ConvFromVec{x_c}, dbctab, cellvals);
         return;
     }
     const int rb = blockIdx.x - nconv_blocks;
@@ -242,6 +243,476 @@ k_step_back(int n, int nv, double *__restrict__ nfc_c,
     if (threadIdx.x == 0) {
         part_rr[blockIdx.x] = arr;
         part_bb[blockIdx.x] = abb;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The six-node step (round 3): front and back merged, the convection cells
+// moved into the TAIL of the step before.
+//
+//   k_step_one  : per row THREE independent gather chains in one launch --
+//                 kx = K x0 (x0: the warm start the previous tail left),
+//                 rs = R1 (a_c v_c + a_p v_p), nfc_c = scale * gather of the
+//                 cell values (computed by the previous step's tail) -- then
+//                 b = rs + cn_c nfc_c + cn_o nfc_o + g [+ carried residuals],
+//                 r = b - kx, partials of ||r||^2, ||b||^2.
+//   k_arn_tail6 : k_arn_tail_acc (close the last column, y = R^-1 g,
+//                 x_new = x0 + Z y OUT OF PLACE, next warm start) plus
+//                 * the true residual of this solve by linearity,
+//                   r_new = r0 - sum_j y_j W_j  (W_j = K z_j kept per column),
+//                   velocity rows -> the carry-over buffer;
+//                 * in extra workgroups the convection cells of the NEW
+//                   velocity, each value taken from its definition
+//                   x0[m] + sum_j y_j Z_j[m] (the new solution vector is being
+//                   written by other workgroups of this launch: it is never
+//                   read here, x0 and Z are not written).
+//
+// Everything a step needs from the step before is complete when the step's
+// first kernel starts; nothing is recurred (K x0 and the W_j are exact gathers
+// every step), so no rounding error builds up along the run.
+// ---------------------------------------------------------------------------
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_step_one(int n, int nv, const int *__restrict__ k_rowptr,
+           const int *__restrict__ k_colidx, const double *__restrict__ k_vals,
+           const int *__restrict__ r_rowptr, const int *__restrict__ r_colidx,
+           const double *__restrict__ r_vals, const double *__restrict__ x0,
+           const double *__restrict__ x_c, const double *__restrict__ x_p,
+           double a_c, double a_p, double *__restrict__ nfc_c,
+           const double *__restrict__ nfc_o, double cn_c, double cn_o,
+           TabRef gtab, TabRef gptab, const int *__restrict__ gptr,
+           const int *__restrict__ gidx, const double *__restrict__ cellvals,
+           double conv_scale, const double *__restrict__ rc_c,
+           const double *__restrict__ rc_p, double *__restrict__ b,
+           double *__restrict__ r, double *__restrict__ part_rr,
+           double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    const double *__restrict__ g = tab_row(gtab);
+    const double *__restrict__ gp = tab_row(gptab);
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    double arr = 0.0, abb = 0.0;
+    for (int row = sub; row < n; row += nsub) {
+        const bool isv = row < nv;
+        // first pass of the three chains, level by level
+        int kk = k_rowptr[row] + sublane;
+        const int kend = k_rowptr[row + 1];
+        int rk = 0, rend = 0, ck = 0, cend = 0;
+        if (isv) {
+            rk = r_rowptr[row] + sublane;
+            rend = r_rowptr[row + 1];
+            if (gptr) {
+                ck = gptr[row] + sublane;
+                cend = gptr[row + 1];
+            }
+        }
+        const bool k_on = kk < kend, r_on = rk < rend, c_on = ck < cend;
+        int kc = 0, rc = 0, ci = 0;
+        double kval = 0.0, rval = 0.0;
+        if (k_on) {
+            kc = k_colidx[kk];
+            kval = k_vals[kk];
+        }
+        if (r_on) {
+            rc = r_colidx[rk];
+            rval = r_vals[rk];
+        }
+        if (c_on) ci = gidx[ck];
+        // the row's own entries: none depends on the gathers
+        double no_in = 0.0, g_in = 0.0, nc_in = 0.0, car = 0.0;
+        if (sublane == 0) {
+            if (isv) {
+                no_in = nfc_o[row];
+                g_in = g[row];
+                if (!gptr) nc_in = nfc_c[row];
+                if (rc_c) car = a_c * rc_c[row];
+                if (rc_p && a_p != 0.0) car = fma(a_p, rc_p[row], car);
+            } else {
+                g_in = gp[row - nv];
+            }
+        }
+        double ks = k_on ? kval * x0[kc] : 0.0;
+        double rsum = 0.0, cvs = 0.0;
+        if (r_on) {
+            double vv = a_c * x_c[rc];
+            if (a_p != 0.0) vv = fma(a_p, x_p[rc], vv);
+            rsum = rval * vv;
+        }
+        if (c_on) cvs = cellvals[ci];
+        for (kk += LPR; kk < kend; kk += LPR)
+            ks = fma(k_vals[kk], x0[k_colidx[kk]], ks);
+        for (rk += LPR; rk < rend; rk += LPR) {
+            const int c = r_colidx[rk];
+            double vv = a_c * x_c[c];
+            if (a_p != 0.0) vv = fma(a_p, x_p[c], vv);
+            rsum = fma(r_vals[rk], vv, rsum);
+        }
+        for (ck += LPR; ck < cend; ck += LPR) cvs += cellvals[gidx[ck]];
+        ks = subwave_sum<LPR>(ks);
+        rsum = subwave_sum<LPR>(rsum);
+        cvs = subwave_sum<LPR>(cvs);
+        if (sublane == 0) {
+            double bv;
+            if (isv) {
+                const double nc = gptr ? conv_scale * cvs : nc_in;
+                if (gptr) nfc_c[row] = nc;
+                bv = rsum + cn_c * nc + cn_o * no_in + g_in + car;
+            } else {
+                bv = g_in;
+            }
+            const double rv = bv - ks;
+            b[row] = bv;
+            r[row] = rv;
+            arr = fma(rv, rv, arr);
+            abb = fma(bv, bv, abb);
+        }
+    }
+    arr = block_sum(arr, red);
+    abb = block_sum(abb, red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = arr;
+        part_bb[blockIdx.x] = abb;
+    }
+}
+
+// The same cut ALONG the dependencies once more: three gather families that
+// do not need each other run side by side in one launch --
+//   workgroups [0, gk)   : kx = K x0                       (all rows)
+//   workgroups [gk, ...) : b  = R1 (a_c v_c + a_p v_p) + cn_c nfc_c + cn_o nfc_o
+//                               + g [+ carried residuals], nfc_c = gather of
+//                               the cell values            (velocity rows);
+//                          b_p = g_p                       (pressure rows)
+// and what joins them -- r = b - kx with both norms -- is done by extra
+// workgroups of the tau kernel behind (k_tau_first), whose row workgroups
+// gather b - kx themselves.  (One kernel with all three chains per row took
+// 8.9 us; the chains side by side take as long as the longest.)
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_step_one2(int gk, int n, int nv, const int *__restrict__ k_rowptr,
+            const int *__restrict__ k_colidx, const double *__restrict__ k_vals,
+            const int *__restrict__ r_rowptr, const int *__restrict__ r_colidx,
+            const double *__restrict__ r_vals, const double *__restrict__ x0,
+            const double *__restrict__ x_c, const double *__restrict__ x_p,
+            double a_c, double a_p, double *__restrict__ nfc_c,
+            const double *__restrict__ nfc_o, double cn_c, double cn_o,
+            TabRef gtab, TabRef gptab, const int *__restrict__ gptr,
+            const int *__restrict__ gidx, const double *__restrict__ cellvals,
+            double conv_scale, const double *__restrict__ rc_c,
+            const double *__restrict__ rc_p, double *__restrict__ b,
+            double *__restrict__ kx) {
+    const int sublane = threadIdx.x % LPR;
+    if ((int)blockIdx.x < gk) {
+        const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+        const int nsub = gk * (kBlock / LPR);
+        for (int row = sub; row < n; row += nsub) {
+            const double s = csr_row_dot<LPR>(k_rowptr, k_colidx, k_vals, x0,
+                                              row, sublane);
+            if (sublane == 0) kx[row] = s;
+        }
+        return;
+    }
+    const double *__restrict__ g = tab_row(gtab);
+    const double *__restrict__ gp = tab_row(gptab);
+    const int rb = blockIdx.x - gk, nrb = gridDim.x - gk;
+    const int sub = (rb * kBlock + threadIdx.x) / LPR;
+    const int nsub = nrb * (kBlock / LPR);
+    for (int row = sub; row < n; row += nsub) {
+        if (row >= nv) {
+            if (sublane == 0) b[row] = gp[row - nv];
+            continue;
+        }
+        int rk = r_rowptr[row] + sublane;
+        const int rend = r_rowptr[row + 1];
+        int ck = 0, cend = 0;
+        if (gptr) {
+            ck = gptr[row] + sublane;
+            cend = gptr[row + 1];
+        }
+        const bool r_on = rk < rend, c_on = ck < cend;
+        int rc = 0, ci = 0;
+        double rval = 0.0;
+        if (r_on) {
+            rc = r_colidx[rk];
+            rval = r_vals[rk];
+        }
+        if (c_on) ci = gidx[ck];
+        double no_in = 0.0, g_in = 0.0, nc_in = 0.0, car = 0.0;
+        if (sublane == 0) {
+            no_in = nfc_o[row];
+            g_in = g[row];
+            if (!gptr) nc_in = nfc_c[row];
+            if (rc_c) car = a_c * rc_c[row];
+            if (rc_p && a_p != 0.0) car = fma(a_p, rc_p[row], car);
+        }
+        double rsum = 0.0, cvs = 0.0;
+        if (r_on) {
+            double vv = a_c * x_c[rc];
+            if (a_p != 0.0) vv = fma(a_p, x_p[rc], vv);
+            rsum = rval * vv;
+        }
+        if (c_on) cvs = cellvals[ci];
+        for (rk += LPR; rk < rend; rk += LPR) {
+            const int c = r_colidx[rk];
+            double vv = a_c * x_c[c];
+            if (a_p != 0.0) vv = fma(a_p, x_p[c], vv);
+            rsum = fma(r_vals[rk], vv, rsum);
+        }
+        for (ck += LPR; ck < cend; ck += LPR) cvs += cellvals[gidx[ck]];
+        rsum = subwave_sum<LPR>(rsum);
+        cvs = subwave_sum<LPR>(cvs);
+        if (sublane == 0) {
+            const double nc = gptr ? conv_scale * cvs : nc_in;
+            if (gptr) nfc_c[row] = nc;
+            b[row] = rsum + cn_c * nc + cn_o * no_in + g_in + car;
+        }
+    }
+}
+
+// tau(r) for r = b - kx that nobody has formed yet: workgroups [0, gt) take
+// the Schur rows, tau = r_p - (J Fh^-1) r_v with r gathered as b - kx;
+// workgroups [gt, ...) form r itself with the partials of ||r||^2, ||b||^2
+// (one per workgroup, read by the head kernel behind).  Rows of J Fh^-1 are
+// long (~270 entries): 128 lanes per row.
+__global__ void __launch_bounds__(kBlock)
+k_tau_first(int gt, int n, int np, int nv, const int *__restrict__ rowptr,
+            const int *__restrict__ colidx, const double *__restrict__ vals,
+            const double *__restrict__ b, const double *__restrict__ kx,
+            double *__restrict__ tau, double *__restrict__ r,
+            double *__restrict__ part_rr, double *__restrict__ part_bb) {
+    if ((int)blockIdx.x >= gt) {
+        __shared__ double red[4];
+        const int rb = blockIdx.x - gt, nrb = gridDim.x - gt;
+        double arr = 0.0, abb = 0.0;
+        for (int e = rb * kBlock + threadIdx.x; e < n; e += nrb * kBlock) {
+            const double bv = b[e];
+            const double rv = bv - kx[e];
+            r[e] = rv;
+            arr = fma(rv, rv, arr);
+            abb = fma(bv, bv, abb);
+        }
+        arr = block_sum(arr, red);
+        abb = block_sum(abb, red);
+        if (threadIdx.x == 0) {
+            part_rr[rb] = arr;
+            part_bb[rb] = abb;
+        }
+        return;
+    }
+    __shared__ double half[kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pair = threadIdx.x >> 7, l128 = threadIdx.x & 127;
+    for (int base = blockIdx.x * 2; base < np; base += gt * 2) {
+        const int row = base + pair;
+        double s0 = 0.0, s1 = 0.0;
+        if (row < np) {
+            const int k1 = rowptr[row + 1];
+            int k = rowptr[row] + l128;
+            for (; k + 128 < k1; k += 256) {
+                const int c0 = colidx[k], c1 = colidx[k + 128];
+                const double v0 = vals[k], v1 = vals[k + 128];
+                s0 = fma(v0, b[c0] - kx[c0], s0);
+                s1 = fma(v1, b[c1] - kx[c1], s1);
+            }
+            if (k < k1) {
+                const int c0 = colidx[k];
+                s0 = fma(vals[k], b[c0] - kx[c0], s0);
+            }
+        }
+        const double s = wave_sum(s0 + s1);
+        __syncthreads();
+        if (lane == 0) half[wave] = s;
+        __syncthreads();
+        if (l128 == 0 && row < np)
+            tau[row] = (b[nv + row] - kx[nv + row]) -
+                       (half[2 * pair] + half[2 * pair + 1]);
+    }
+}
+
+// (the first `nrow_blocks` workgroups do the rows, the rest the cells; every
+// workgroup repeats the tiny tail computation in its own LDS, workgroup 0
+// alone commits the bookkeeping -- as k_arn_tail_acc)
+__global__ void __launch_bounds__(kBlock)
+k_arn_tail6(int c, int n, int nrow_blocks,
+            const double *__restrict__ norm_part, int nparts, DnsCtl *ctl,
+            double *__restrict__ histbuf, int hist_cap, int maxiter,
+            const double *__restrict__ Z, size_t ld, Tail6 t6, TailExtrap te,
+            TailCells tc) {
+    __shared__ double sc[kMaxRestart + 2];
+    __shared__ double yl[kMaxRestart];
+    __shared__ int jl;
+    const bool open_col = !ctl->done && c > 0;
+    const bool rowblk = (int)blockIdx.x < nrow_blocks;
+    const int ef = blockIdx.x * kBlock + threadIdx.x;
+    double pfx = 0.0, pz0 = 0.0, ph1 = 0.0, ph2 = 0.0, ph3 = 0.0, ph4 = 0.0,
+           pr0 = 0.0, pw0 = 0.0;
+    // cell workgroups: the twelve local values of x0 and of Z_0 are asked for
+    // BEFORE the coefficients y exist (nothing of it depends on them)
+    double u0[6][2], uz[6][2];
+    int cmap[12];
+    int cslot = 0, cq = 0, ccell = 0;
+    bool clive = false;
+    if (!rowblk && tc.nblocks > 0) {
+        const double *__restrict__ dbcvals = tab_row(tc.dbctab);
+        const int t = (blockIdx.x - nrow_blocks) * kBlock + threadIdx.x;
+        cslot = t >> 3;
+        cq = t & 7;
+        clive = cslot < tc.ncells;
+        ccell = clive ? cslot : 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k)
+            cmap[k] = tc.cellmap[(size_t)k * tc.ncells + ccell];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = cmap[2 * a + i];
+                u0[a][i] = (m >= 0) ? t6.x0[m] : dbcvals[-m - 1];
+                uz[a][i] = (m >= 0 && c > 0) ? Z[m] : 0.0;
+            }
+    }
+    if (rowblk && ef < n) {
+        pfx = t6.x0[ef];
+        if (c > 0) pz0 = Z[ef];
+        if (te.out) {
+            if (te.e1 != 0.0) ph1 = te.h1[ef];
+            if (te.e2 != 0.0) ph2 = te.h2[ef];
+            if (te.e3 != 0.0) ph3 = te.h3[ef];
+            if (te.e4 != 0.0) ph4 = te.h4[ef];
+        }
+        if (t6.rnew && ef < t6.nv) {
+            pr0 = t6.r0[ef];
+            if (c > 0) pw0 = t6.W[ef];
+        }
+    }
+    if (open_col) reduce_partials(norm_part, nparts, nparts, c + 1, sc);
+    if (threadIdx.x == 0) {
+        double gl[2] = {0.0, 0.0}, rcol[kMaxRestart + 1];
+        int jcols = ctl->jdone, status = DNS_OK, conv = 0, tot = ctl->total_it;
+        double res = ctl->resnorm;
+        bool closed = false;
+        if (open_col) {
+            const int j = c - 1;
+            const double hn = pythagoras_norm(sc, c);
+            if (hn < 0.0) {
+                status = kGsFallback;
+            } else {
+                for (int i = 0; i <= j; ++i) rcol[i] = sc[i];
+                for (int i = 0; i < j; ++i) {
+                    const double t = ctl->cs[i] * rcol[i] +
+                                     ctl->sn[i] * rcol[i + 1];
+                    rcol[i + 1] = -ctl->sn[i] * rcol[i] +
+                                  ctl->cs[i] * rcol[i + 1];
+                    rcol[i] = t;
+                }
+                const double den = hypot(rcol[j], hn);
+                double cc = 1.0, ss = 0.0;
+                if (den > 0.0) {
+                    cc = rcol[j] / den;
+                    ss = hn / den;
+                } else {
+                    status = DNS_BREAKDOWN;
+                }
+                rcol[j] = den;
+                gl[1] = -ss * ctl->g[j];
+                gl[0] = cc * ctl->g[j];
+                res = fabs(gl[1]);
+                jcols = j + 1;
+                tot += 1;
+                conv = res <= ctl->tol;
+                if (isnan(res)) status = DNS_BREAKDOWN;
+                closed = true;
+            }
+        }
+        for (int i = jcols - 1; i >= 0; --i) {
+            double s = (closed && i == jcols - 1) ? gl[0] : ctl->g[i];
+            for (int k = i + 1; k < jcols; ++k) {
+                const double rik = (closed && k == jcols - 1)
+                                       ? rcol[i]
+                                       : ctl->R[(size_t)k * (kMaxRestart + 1) + i];
+                s -= rik * yl[k];
+            }
+            const double d = (closed && i == jcols - 1)
+                                 ? rcol[i]
+                                 : ctl->R[(size_t)i * (kMaxRestart + 1) + i];
+            yl[i] = (d != 0.0) ? s / d : 0.0;
+        }
+        jl = jcols;
+        if (blockIdx.x == 0) {
+            const int was_conv = ctl->conv;
+            if (closed) {
+                ctl->resnorm = res;
+                ctl->hist[jcols] = res;
+                ctl->total_it = tot;
+                if (status != DNS_OK) ctl->status = status;
+                if (conv) ctl->conv = 1;
+            } else if (status != DNS_OK) {
+                ctl->status = status;
+            }
+            const int nowconv = was_conv || conv;
+            int hl = ctl->hist_len;
+            for (int i = (hl > 0 ? 1 : 0); i <= jcols && hl < hist_cap; ++i)
+                histbuf[hl++] = (closed && i == jcols) ? res : ctl->hist[i];
+            ctl->hist_len = hl;
+            ctl->acc_solves += 1;
+            ctl->acc_iters += tot;
+            if (tot > ctl->acc_maxit) ctl->acc_maxit = tot;
+            if (nowconv && ctl->tol > 0.0) {
+                const double rel = res / ctl->tol;
+                if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
+            }
+            if (!nowconv) ctl->acc_fail += 1;
+        }
+    }
+    __syncthreads();
+    const int jcols = jl;
+    if (!rowblk) {
+        // convection cells of the new velocity x0 + Z y, from the values that
+        // arrived meanwhile (further columns: rare, gathered now)
+        if (tc.nblocks > 0) {
+            const double y0 = jcols > 0 ? yl[0] : 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    double v = fma(y0, uz[a][i], u0[a][i]);
+                    const int m = cmap[2 * a + i];
+                    if (m >= 0)
+                        for (int j = 1; j < jcols; ++j)
+                            v = fma(yl[j], Z[(size_t)j * ld + m], v);
+                    u0[a][i] = v;
+                }
+            conv_cells_compute(u0, tc.ncells, ccell, cslot, cq, clive, tc.glam,
+                               tc.area, tc.cellvals);
+        }
+        return;
+    }
+    const int stride = nrow_blocks * kBlock;
+    for (int e = ef; e < n; e += stride) {
+        const bool first = e == ef;
+        double s = first ? pfx : t6.x0[e];
+        if (jcols > 0) s = fma(yl[0], first ? pz0 : Z[e], s);
+        for (int i = 1; i < jcols; ++i) s = fma(yl[i], Z[(size_t)i * ld + e], s);
+        t6.xout[e] = s;
+        if (te.out) {
+            if (first) {
+                double v = te.e0 * s;
+                v = fma(te.e1, ph1, v);
+                v = fma(te.e2, ph2, v);
+                v = fma(te.e3, ph3, v);
+                v = fma(te.e4, ph4, v);
+                te.out[e] = v;
+            } else {
+                tail_extrapolate(te, e, s);
+            }
+        }
+        if (t6.rnew && e < t6.nv) {
+            double rr = first ? pr0 : t6.r0[e];
+            if (jcols > 0) rr = fma(-yl[0], first ? pw0 : t6.W[e], rr);
+            for (int i = 1; i < jcols; ++i)
+                rr = fma(-yl[i], t6.W[(size_t)i * ld + e], rr);
+            t6.rnew[e] = rr;
+        }
     }
 }
 
