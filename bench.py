@@ -659,13 +659,31 @@ def multi_gpu_main(args, world, rank, local_rank):
                str(level), '--refine', str(refine), '--nts', str(nts),
                '--dense-max', str(args.dense_max), '--partitioned-timeout',
                str(args.partitioned_timeout)] + common
-        dist.barrier()
-        res = run_child(cmd, env, args.partitioned_timeout, rank == 0)
-        # a rank whose child failed makes the run a failure for everybody
-        bad = torch.tensor([1 if (res is not None and 'error' in res) else 0])
-        dist.all_reduce(bad)
-        if int(bad.item()) and rank == 0 and 'error' not in res:
-            res = dict(error='the child of another rank failed', partial=res)
+        def attempt(extra_env):
+            dist.barrier()
+            e2 = dict(env)
+            e2.update(extra_env)
+            res = run_child(cmd, e2, args.partitioned_timeout, rank == 0)
+            # a rank whose child failed makes the run a failure for everybody
+            bad = torch.tensor([1 if (res is not None and 'error' in res)
+                                else 0])
+            dist.all_reduce(bad)
+            if int(bad.item()) and rank == 0 and 'error' not in res:
+                res = dict(error='the child of another rank failed',
+                           partial=res)
+            return res, int(bad.item())
+        res, bad = attempt({})
+        if bad and not args.eager:
+            # once more with plain launches instead of replayed graphs (the
+            # captured RCCL calls are the one part of this path no one-GPU box
+            # can exercise with more than one rank)
+            first = res
+            res, bad = attempt({'DNS_DIST_GRAPH': '0'})
+            if rank == 0 and isinstance(res, dict):
+                res['graph_replay'] = False
+                res['first_attempt_with_graphs'] = first
+        elif rank == 0 and isinstance(res, dict):
+            res['graph_replay'] = not args.eager
         return res
 
     level, refine = weak_ladder(world)
@@ -859,9 +877,12 @@ def main():
                     help='(tests) the child processes of a multi-rank launch '
                     'report canned figures without touching a GPU: exercises '
                     'the launch / rendezvous / JSON plumbing on CPU')
-    ap.add_argument('--force-dist', action='store_true',
-                    help='attach an RCCL communicator even with one rank '
-                    '(self-test of the multi-GPU code path)')
+    ap.add_argument('--no-force-dist', dest='force_dist',
+                    action='store_false',
+                    help='skip the run of the N=1 workload through the '
+                    'row-partitioned code path on one RCCL rank '
+                    '(config.row_partitioned: the code the N > 1 lines time)')
+    ap.set_defaults(force_dist=True)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -981,8 +1002,11 @@ def main():
     # self-test of the multi-GPU code path on one rank (RCCL communicator of
     # size 1): the same partitioned run the N > 1 headline times
     partitioned = None
-    if args.force_dist:
-        partitioned = partitioned_run(args, 1, 0, device, None, False)
+    if args.force_dist and not args.profile_step:
+        try:
+            partitioned = partitioned_run(args, 1, 0, device, None, False)
+        except Exception as exc:          # reported, never fatal
+            partitioned = dict(error=str(exc))
 
     out = None
     if rank == 0:
