@@ -521,6 +521,8 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
         true_relres_last=lst['true_relres'],
         cheb_degree=cheb, fhat=fhat,
         run_record=dict(stp.last_run),
+        graph_replay=bool(not args.eager and not one_gpu and
+                          os.environ.get('DNS_DIST_GRAPH', '1') != '0'),
         collectives_timed_window={k: int(c1[k] - c0[k]) for k in c1},
         matrix_bytes_per_rank_max=int(mb), precond_setup_s=t_setup,
         backend='gloo, host staged (one-GPU rehearsal)' if one_gpu
@@ -680,10 +682,7 @@ def multi_gpu_main(args, world, rank, local_rank):
             first = res
             res, bad = attempt({'DNS_DIST_GRAPH': '0'})
             if rank == 0 and isinstance(res, dict):
-                res['graph_replay'] = False
                 res['first_attempt_with_graphs'] = first
-        elif rank == 0 and isinstance(res, dict):
-            res['graph_replay'] = not args.eager
         return res
 
     level, refine = weak_ladder(world)
