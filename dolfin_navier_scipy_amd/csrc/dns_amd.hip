@@ -261,7 +261,31 @@ int dns_saddle::update_values(const double *fvals) {
 
 // F.vals was re-valued by a device kernel (trapezoidal stepper): bring K and
 // D^-1 along; the host copy is fetched lazily before the next set-up
+int dns_saddle::ensure_F_device() {
+    if (F.nnz > 0 || !dist_sliced) return DNS_OK;
+    // (released when the handle was sliced; the trapezoidal stepper assembles
+    // F = M + dt/2 (A + N) in full on every rank and scatters its rows into
+    // the rank's row block of K)
+    const dns_csr fv = Fh.view();
+    DNS_TRY(F.upload(&fv, stream));
+    return DNS_OK;
+}
+
 int dns_saddle::device_values_changed() {
+    if (dist_sliced) {
+        if (!dd || F.nnz == 0)
+            return fail(DNS_ERR_NOT_READY, "sliced handle without its F block");
+        const int v0 = dist_v0(), v1 = dist_v1();
+        if (v1 > v0)
+            hipLaunchKernelGGL(k_scatter_fvals_rows, grid_for_rows(v1 - v0, 8),
+                               kBlock, 0, stream, v0, v1 - v0, F.rowptr.p,
+                               K.rowptr.p, F.vals.p, K.vals.p);
+        hipLaunchKernelGGL(k_diag_inv, grid_for_elems(nv), kBlock, 0, stream,
+                           nv, F.rowptr.p, F.colidx.p, F.vals.p, dinv.p);
+        DNS_HIP(hipGetLastError());
+        fh_stale = true;
+        return DNS_OK;
+    }
     if (Kp.ready) drop_graphs();
     Kp.release_all();
     hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,

@@ -768,6 +768,23 @@ k_scatter_fvals(int nv, const int *__restrict__ f_rowptr,
     }
 }
 
+// the same for a row block of K: local row i of `k_rowptr` is global row
+// row0 + i of F
+__global__ void __launch_bounds__(kBlock)
+k_scatter_fvals_rows(int row0, int nrows, const int *__restrict__ f_rowptr,
+                     const int *__restrict__ k_rowptr,
+                     const double *__restrict__ fvals,
+                     double *__restrict__ kvals) {
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / 8;
+    const int sl = threadIdx.x % 8;
+    const int nsub = gridDim.x * (kBlock / 8);
+    for (int i = sub; i < nrows; i += nsub) {
+        const int f0 = f_rowptr[row0 + i], f1 = f_rowptr[row0 + i + 1];
+        const int k0 = k_rowptr[i];
+        for (int k = f0 + sl; k < f1; k += 8) kvals[k0 + (k - f0)] = fvals[k];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // dense Schur block:  y = alpha * A x,  A is n x n row-major; one wavefront
 // per row, 16-byte loads where the row start is 16-byte aligned.

@@ -498,6 +498,9 @@ struct dns_saddle {
     bool have_jg = false;
     bool fh_stale = false;            // F.vals changed on the device
     int device_values_changed();
+    int ensure_F_device();            // a sliced handle gets its F block back
+    int dist_v0() const;              // this rank's velocity rows [v0, v1)
+    int dist_v1() const;
     int gs_fallbacks = 0;             // solves in a row whose fused Gram-Schmidt
                                       // fell back (>= 8: not tried any more)
     bool want_history = true;         // copy the residual history back

@@ -68,7 +68,11 @@ class TrapezoidalStepper(object):
     step sizes still converge, with more iterations)"""
 
     def __init__(self, M, A, J, conv, nslots, dt, device=0, precond=None,
-                 JT=None):
+                 JT=None, comm=None):
+        """`comm` (a `comm.Comm`): the saddle solves of the sweeps run
+        row-partitioned over its ranks; the assembly of
+        `N(v_lin)`, `F` and the right-hand side is replicated on every rank,
+        the solution is gathered after every step"""
         self.lib = C.load_library()
         self.conv = conv
         self.M, self.A, self.J = (sps.csr_matrix(M), sps.csr_matrix(A),
@@ -81,8 +85,12 @@ class TrapezoidalStepper(object):
                              self.pattern.indices, self.pattern.indptr),
                             shape=self.pattern.shape)
         self.system = SaddleSystem(F0, self.J, JT=JT, device=device)
+        if comm is not None:
+            self.system.set_comm(comm)
         pkw = dict(cheb_degree=6, schur='auto', fhat='auto', fp32_store=True,
                    drop_tol=3e-3)
+        if comm is not None:
+            pkw['fhat'] = 'explicit'       # (the partitioned solve needs it)
         pkw.update(precond or {})
         if pkw['schur'] == 'auto':
             pkw['schur'] = 'dense' if self.NP <= 6000 else 'jacobi'

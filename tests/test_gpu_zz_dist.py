@@ -462,3 +462,97 @@ def _worker_cfg4(rank, world, port, outdir):
              allreduce=after['allreduce'] - before['allreduce'])
     cm.close()
     dist.destroy_process_group()
+
+
+def _trap_sweeps(comm):
+    """one Picard and two Newton sweeps of the toy problem (snu:1304-1587)
+    through the device stepper, optionally on a row-partitioned handle"""
+    import scenarios
+    import test_gpu_newton_picard as tnp
+    from dolfin_navier_scipy_amd import convection, saddle
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    s = tnp._setup(scenarios.toy_problem())
+    tr = s['trange']
+    cv = convection.ConvectionP2.from_taylor_hood(s['th'], s['inv'],
+                                                  s['dbcinds'], s['dbcvals'])
+    stp = dnp.TrapezoidalStepper(s['M'], s['A'], s['J'], cv, nslots=tr.size,
+                                 dt=tr[1] - tr[0], comm=comm,
+                                 precond=dict(cheb_degree=4,
+                                              factorization='full'))
+    stp.set_rhs(s['fv'], s['fp'])
+    opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True)
+    vd, pd, hist = dnp.newton_picard(stp, tr, s['iniv'], s['lin0'],
+                                     vel_pcrd_stps=1, vel_nwtn_stps=2,
+                                     opts=opts)
+    stp.close()
+    cv.close()
+    tl = tr[-1]
+    return vd[tl], pd[tl], np.array([h[1] for h in hist]), s
+
+
+def _worker_trap(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      GLOO_SOCKET_IFNAME='lo')
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+    import faulthandler
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(200, exit=True)   # never hang a GPU box
+    dist.init_process_group('gloo', rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=120))
+    from dolfin_navier_scipy_amd import comm as dcomm
+    cm = dcomm.Comm.gloo(0)
+    before = cm.stats()
+    v, p, hist, _ = _trap_sweeps(cm)
+    after = cm.stats()
+    np.savez(os.path.join(outdir, 'trap_rank{0}.npz'.format(rank)), v=v, p=p,
+             hist=hist, halo=after['halo_exchange'] - before['halo_exchange'],
+             gathers=after['allgatherv'] - before['allgatherv'])
+    cm.close()
+    dist.destroy_process_group()
+
+
+def test_newton_picard_sweeps_on_a_partitioned_handle(tmp_path):
+    """the trapezoidal Newton/Picard stepper with its saddle solves
+    row-partitioned over two ranks (assembly replicated, solution gathered per
+    step): same sweeps, update norms and iterates as on one GPU and as the
+    oracle's restatement"""
+    from oracle import newton_picard_oracle as npo
+    from spawn_util import spawn_ranks
+    spawn_ranks(_worker_trap, 2, str(tmp_path))
+    r0 = np.load(tmp_path / 'trap_rank0.npz')
+    r1 = np.load(tmp_path / 'trap_rank1.npz')
+    assert np.array_equal(r0['v'], r1['v']) and np.array_equal(r0['p'], r1['p'])
+    v1, p1, hist1, s = _trap_sweeps(None)
+    assert np.linalg.norm(r0['v'] - v1) <= 1e-9*np.linalg.norm(v1)
+    assert np.linalg.norm(r0['p'] - p1) <= 1e-8*np.linalg.norm(p1)
+    assert np.allclose(r0['hist'], hist1, rtol=1e-5, atol=1e-16)
+    tr = s['trange']
+    lin_full = {t: s['appnd'](v) for t, v in s['lin0'].items()}
+    vo, po, _ = npo.newton_picard(
+        tr, s['iniv'], lin_full, vel_pcrd_stps=1, vel_nwtn_stps=2,
+        invinds=s['inv'], M=s['M'], A=s['A'], J=s['J'], fv=s['fv'],
+        fp=s['fp'], conv=s['conv'], appndbcs=s['appnd'])
+    tl = tr[-1]
+    assert np.linalg.norm(r0['v'] - vo[tl]) <= 1e-8*np.linalg.norm(vo[tl])
+    assert np.linalg.norm(r0['p'] - po[tl]) <= 1e-8*np.linalg.norm(po[tl])
+    assert int(r0['halo']) > 0 and int(r0['gathers']) > 0
+
+
+def test_newton_picard_sweeps_on_one_rccl_rank():
+    """the same sweeps with an RCCL communicator of size one: every RCCL call
+    of the partitioned stepper runs (captured into the cycle graphs) and the
+    iterates equal the plain run's"""
+    from dolfin_navier_scipy_amd import comm as dcomm
+    v1, p1, hist1, _ = _trap_sweeps(None)
+    cm = dcomm.Comm.rccl(0, 1, 0, dcomm.rccl_unique_id())
+    v, p, hist, _ = _trap_sweeps(cm)
+    calls = cm.stats()
+    cm.close()
+    assert np.linalg.norm(v - v1) <= 1e-9*np.linalg.norm(v1)
+    assert np.linalg.norm(p - p1) <= 1e-8*np.linalg.norm(p1)
+    assert np.allclose(hist, hist1, rtol=1e-5, atol=1e-16)
+    assert calls['allgatherv'] > 0 and calls['allreduce'] > 0
