@@ -68,11 +68,16 @@ class TrapezoidalStepper(object):
     step sizes still converge, with more iterations)"""
 
     def __init__(self, M, A, J, conv, nslots, dt, device=0, precond=None,
-                 JT=None, comm=None):
+                 JT=None, comm=None, precond_linpoint=None):
         """`comm` (a `comm.Comm`): the saddle solves of the sweeps run
         row-partitioned over its ranks; the assembly of
         `N(v_lin)`, `F` and the right-hand side is replicated on every rank,
-        the solution is gathered after every step"""
+        the solution is gathered after every step.
+        `precond_linpoint` (inner velocity, NV): the preconditioner -- set up
+        ONCE, the system matrix is re-valued every step -- is built for
+        `M + dt/2 (A + N1(v))` at this velocity instead of `M + dt/2 A`: the
+        Oseen term of a representative state is then inside the polynomial
+        and the Schur block (fewer Krylov steps per time step)"""
         self.lib = C.load_library()
         self.conv = conv
         self.M, self.A, self.J = (sps.csr_matrix(M), sps.csr_matrix(A),
@@ -81,8 +86,14 @@ class TrapezoidalStepper(object):
         self.pattern = union_pattern(self.M, self.A, conv.connectivity())
         self.mvals = values_in_pattern(self.M, self.pattern)
         self.avals = values_in_pattern(self.A, self.pattern)
-        F0 = sps.csr_matrix((self.mvals + .5*dt*self.avals,
-                             self.pattern.indices, self.pattern.indptr),
+        conv.bind_pattern(self.pattern)
+        f0 = self.mvals + .5*dt*self.avals
+        if precond_linpoint is not None:
+            Nref, _, _ = conv.assemble(precond_linpoint, newton=False)
+            nd = Nref.data if Nref.data.size == f0.size else \
+                values_in_pattern(Nref, self.pattern)
+            f0 = f0 + .5*dt*nd
+        F0 = sps.csr_matrix((f0, self.pattern.indices, self.pattern.indptr),
                             shape=self.pattern.shape)
         self.system = SaddleSystem(F0, self.J, JT=JT, device=device)
         if comm is not None:

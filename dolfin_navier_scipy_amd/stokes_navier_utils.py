@@ -572,9 +572,18 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
         cvop = _conv_operator(V, dbcnt, list(dbcinds), device=device)
         cvop.set_dbcvals(dbcvals)
     dt = trange[1] - trange[0]
+    # the preconditioner is set up once (the system is re-valued every step):
+    # about the initial state, M + dt/2 (A + N1(iniv)), unless the caller's
+    # `solver['precond_linpoint']` says otherwise (False: M + dt/2 A)
+    plp = (solver or {}).get('precond_linpoint', None)
+    if plp is None and not stokes_flow:
+        plp = iniv
+    elif plp is False:
+        plp = None
     ts = dnp.TrapezoidalStepper(cmmat, camat, cj, cvop,
                                 nslots=trange.size, dt=dt, device=device,
-                                precond=(solver or {}).get('precond'))
+                                precond=(solver or {}).get('precond'),
+                                precond_linpoint=plp)
     try:
         fvtab = None
         if fvtd is not None and tables is None:
