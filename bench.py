@@ -298,7 +298,7 @@ def cpu_baseline_extras(sm, rhsd, v0, nfc0, dt, nsteps_gmres=1,
 
 
 def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64,
-                         precond_at_v0=True):
+                         precond_at_v0=True, use_graph=True):
     """secondary workload (BASELINE config 3): one Picard
     and one Newton trapezoidal sweep over `nsteps` steps, everything on the
     device (convection matrices, F = M + dt/2 (A + N), solve); beside it what
@@ -325,7 +325,8 @@ def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64,
     ts.set_rhs(rhsd['fv'], rhsd['fp'])
     for k in range(nsteps + 1):       # first linearisation: the initial state
         ts.write_linpoint(0, k, v0)
-    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=2)
+    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=use_graph,
+                             reorth=2)
     out = {}
     which = 0
     # untimed pass: graph capture of the solver cycles (trajectory 0 = the

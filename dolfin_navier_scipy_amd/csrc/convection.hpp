@@ -230,6 +230,12 @@ struct dns_conv {
                            const double *avals, double tdt, double *fvals,
                            hipStream_t s);
     int enqueue_bc_gather(double *rhsbc, hipStream_t s);
+    // both in one launch (+ fvn = fv + rhsbc (+ rhscon) if fvn)
+    int enqueue_mat_bc_gather(double *nvals, const double *mvals,
+                              const double *avals, double tdt, double *fvals,
+                              double *rhsbc, const double *fv,
+                              const double *rhscon, double *fvn,
+                              hipStream_t s);
     // element kernel alone (the gather is fused into the step prologue)
     int enqueue_cells(const double *v_dev, hipStream_t s,
                       const int *sel = nullptr, int nsel = 0) {
@@ -399,6 +405,44 @@ k_conv_bc_gather(int nrows, const int *__restrict__ bptr,
     }
 }
 
+// both gathers of an assembly in ONE launch (they read the same local
+// matrices and do not need each other): workgroups [0, gm) the matrix values,
+// the rest the Dirichlet-column right-hand side and -- fvn != nullptr -- the
+// momentum right-hand side of the trapezoidal stepper behind it,
+// fvn = fv + rhsbc (+ rhscon)
+__global__ void __launch_bounds__(kBlock)
+k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
+                     const int *__restrict__ midx, const double *__restrict__ L,
+                     double *__restrict__ nvals,
+                     const double *__restrict__ mvals,
+                     const double *__restrict__ avals, double tdt,
+                     double *__restrict__ fvals, int nrows,
+                     const int *__restrict__ bptr, const int *__restrict__ bidx,
+                     const int *__restrict__ bbc, TabRef dbctab,
+                     double *__restrict__ rhsbc, const double *__restrict__ fv,
+                     const double *__restrict__ rhscon,
+                     double *__restrict__ fvn) {
+    if ((int)blockIdx.x < gm) {
+        for (int z = blockIdx.x * kBlock + threadIdx.x; z < nnz;
+             z += gm * kBlock) {
+            double s = 0.0;
+            for (int k = mptr[z]; k < mptr[z + 1]; ++k) s += L[midx[k]];
+            nvals[z] = s;
+            if (fvals) fvals[z] = mvals[z] + tdt * (avals[z] + s);
+        }
+        return;
+    }
+    const double *__restrict__ dbcvals = tab_row(dbctab);
+    const int rb = blockIdx.x - gm, nrb = gridDim.x - gm;
+    for (int r = rb * kBlock + threadIdx.x; r < nrows; r += nrb * kBlock) {
+        double s = 0.0;
+        for (int k = bptr[r]; k < bptr[r + 1]; ++k)
+            s = fma(L[bidx[k]], dbcvals[bbc[k]], s);
+        rhsbc[r] = -s;
+        if (fvn) fvn[r] = fv[r] - s + (rhscon ? rhscon[r] : 0.0);
+    }
+}
+
 }  // namespace dns
 
 // the matrix side of dns_conv: tables bound to ONE CSR pattern
@@ -428,6 +472,25 @@ inline int dns_conv::enqueue_mat_gather(double *nvals, const double *mvals,
     hipLaunchKernelGGL(dns::k_conv_mat_gather, g, dns::kBlock, 0, s, mat->nnz,
                        mat->mptr.p, mat->midx.p, mat->L.p, nvals, mvals, avals,
                        tdt, fvals);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+inline int dns_conv::enqueue_mat_bc_gather(double *nvals, const double *mvals,
+                                           const double *avals, double tdt,
+                                           double *fvals, double *rhsbc,
+                                           const double *fv,
+                                           const double *rhscon, double *fvn,
+                                           hipStream_t s) {
+    const int gm = std::max(1, std::min((mat->nnz + dns::kBlock - 1) /
+                                            dns::kBlock, 4096));
+    const int gb = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
+                                            dns::kBlock, 2048));
+    hipLaunchKernelGGL(dns::k_conv_mat_bc_gather, gm + gb, dns::kBlock, 0, s,
+                       gm, mat->nnz, mat->mptr.p, mat->midx.p, mat->L.p, nvals,
+                       mvals, avals, tdt, fvals, nv_inner, mat->bptr.p,
+                       mat->bidx.p, mat->bbc.p, dbc_ref(), rhsbc, fv, rhscon,
+                       fvn);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

@@ -497,6 +497,9 @@ struct dns_saddle {
     dns::DevBuf<double> tau;
     bool have_jg = false;
     bool fh_stale = false;            // F.vals changed on the device
+    bool dinv_stale = false;          // ... and 1/diag(F) was not refreshed
+                                      // (explicit Fh^-1: nobody reads it
+                                      // between two set-ups)
     int device_values_changed();
     int ensure_F_device();            // a sliced handle gets its F block back
     int dist_v0() const;              // this rank's velocity rows [v0, v1)
