@@ -179,6 +179,8 @@ SIGNATURES = {
                                   c_double_p]),
     'dns_saddle_set_schur_mg': (ct.c_int, [ct.c_void_p, ct.c_int32,
                                            ct.POINTER(dns_csr), ct.c_int32]),
+    'dns_saddle_set_option': (ct.c_int, [ct.c_void_p, ct.c_char_p,
+                                         ct.c_double]),
     'dns_conv_bind_pattern': (ct.c_int, [ct.c_void_p, ct.POINTER(dns_csr)]),
     'dns_conv_assemble': (ct.c_int, [ct.c_void_p, c_double_p, ct.c_int32,
                                      c_double_p, c_double_p, c_double_p]),

@@ -1984,6 +1984,30 @@ int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
     return dns::guarded([&]() -> int { return dns_saddle_set_schur_mg_impl(h, nprol, prol, smooth_steps); });
 }
 
+static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double value) {
+    if (!h || !name) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    const std::string k(name);
+    if (k == "stream_nnz") h->stream_nnz = (int64_t)value;
+    else if (k == "pair") h->pair_knob = value != 0.0;
+    else if (k == "mg_dense_max") h->mg_dense_max = (int)value;
+    else if (k == "mg_part_min") h->mg_part_min = (int)value;
+    else if (k == "mg_fused") h->mg_fused_knob = value != 0.0;
+    else if (k == "mg_cheb") h->mg_cheb = value != 0.0;
+    else if (k == "mg_cheb_alpha") h->mg_cheb_alpha = std::max(1.5, value);
+    else if (k == "mg_cycles") h->mg_cycles = std::max(1, std::min(2, (int)value));
+    else if (k == "mg_rho") h->mg_rho = std::max(0.01, std::min(0.95, value));
+    else if (k == "dist_graph") h->dist_graph_ok = value != 0.0;
+    else
+        return fail(DNS_ERR_BAD_ARGUMENT, "unknown option '%s'", name);
+    h->precond_ready = false;        // (set up again with the new setting)
+    h->drop_graphs();
+    return DNS_OK;
+}
+
+int dns_saddle_set_option(dns_saddle *h, const char *name, double value) {
+    return dns::guarded([&]() -> int { return dns_saddle_set_option_impl(h, name, value); });
+}
+
 static int dns_saddle_setup_precond_impl(dns_saddle *h, const dns_precond_opts *opts) {
     if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "null handle");
     return h->setup_precond(opts);

@@ -121,6 +121,15 @@ class SaddleSystem(object):
                                                 ct.byref(hi)))
         return lo.value, hi.value
 
+    def set_option(self, name, value):
+        """a tuning knob of this handle (`dns_saddle_set_option`: `stream_nnz`,
+        `pair`, `mg_dense_max`, `mg_part_min`, `mg_fused`, `mg_cheb`,
+        `mg_cheb_alpha`, `mg_cycles`, `mg_rho`, `dist_graph`); before
+        `setup_precond`"""
+        C.check(self.lib.dns_saddle_set_option(self._h, name.encode(),
+                                               float(value)))
+        return self
+
     def precond_info(self):
         """sizes of the resident preconditioner (bench.py's byte counts)"""
         buf = (ct.c_int64*64)()

@@ -416,6 +416,20 @@ int dns_spmv_pair(int device, const dns_csr *k, int32_t nv, const double *x,
  * (Reference counterpart: none -- its direct solver does not need one.) */
 int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
                             int32_t smooth_steps);
+/* Tuning knobs of ONE handle, to be set before dns_saddle_setup_precond (the
+ * environment variables DNS_<NAME> give the defaults when the handle is
+ * created; this call replaces process-global state in tests and drivers):
+ *   "stream_nnz"    matrices with at least this many non-zeros take the
+ *                   LDS-streaming kernels (bandwidth regime)
+ *   "pair"          0/1: pair format of K in the bandwidth regime
+ *   "mg_dense_max"  first multigrid level <= this gets the dense inverse
+ *   "mg_part_min"   levels with at least this many rows are row-partitioned
+ *   "mg_fused"      0/1: fused V(2,2) operators
+ *   "mg_cheb"       0/1: Chebyshev pair of smoothing weights; "mg_cheb_alpha"
+ *   "mg_cycles"     1 or 2 cycles per application; "mg_rho"
+ *   "dist_graph"    0/1: hipGraph replay with captured RCCL calls
+ * Unknown names: DNS_ERR_BAD_ARGUMENT.  (No reference counterpart.) */
+int dns_saddle_set_option(dns_saddle *h, const char *name, double value);
 
 /* ---- linearised convection matrices + Newton/Picard trapezoidal sweeps ------
  * (reference: `get_v_conv_conts` snu:109-133 with `get_convmats` dts:325-376

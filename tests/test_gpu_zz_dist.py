@@ -127,16 +127,9 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
     cyl3 = fhat in ('cyl3', 'cyl3s')
     pr = (_mg3_problem() if three else _mg_problem()) if mgs else (
         _cyl3_problem() if cyl3 else _problem())
-    saved = {k: os.environ.get(k) for k in knobs}
-    os.environ.update(knobs)
-    try:
-        system = sad.SaddleSystem(pr['F'], pr['J'])
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    system = sad.SaddleSystem(pr['F'], pr['J'])
+    for k, v in knobs.items():        # per-handle options, no process state
+        system.set_option(k[len('DNS_'):].lower(), float(v))
     if comm is not None:
         system.set_comm(comm)
     if cyl3:
