@@ -113,7 +113,9 @@ namespace dns {
 // contiguous block partition of `n` rows over `nranks`: starts[r] .. starts[r+1]
 inline std::vector<int> partition_starts(int n, int nranks) {
     std::vector<int> st((size_t)nranks + 1);
-    const int chunk = (n + nranks - 1) / nranks;
+    // (even chunks: the two velocity dofs of a node stay on one rank -- the
+    // pair format of a rank's row block needs that)
+    const int chunk = ((n + nranks - 1) / nranks + 1) & ~1;
     for (int r = 0; r <= nranks; ++r)
         st[r] = (int)std::min<int64_t>((int64_t)n, (int64_t)r * chunk);
     return st;

@@ -276,6 +276,8 @@ int dns_saddle::device_values_changed() {
         if (!dd || F.nnz == 0)
             return fail(DNS_ERR_NOT_READY, "sliced handle without its F block");
         const int v0 = dist_v0(), v1 = dist_v1();
+        if (Kp.ready) drop_graphs();     // (they launch the pair kernel)
+        Kp.release_all();
         if (v1 > v0)
             hipLaunchKernelGGL(k_scatter_fvals_rows, grid_for_rows(v1 - v0, 8),
                                kBlock, 0, stream, v0, v1 - v0, F.rowptr.p,
@@ -890,7 +892,8 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
 int dns_saddle::mg_op(const CsrDev &A, const double *xa, int nsplit,
                       const double *xb, const MgLevel *add, const double *b,
                       double *out, const int *guard) {
-    if (!dist() && streams(A)) {
+    // (called with whole operators only: the levels every rank runs in full)
+    if (streams(A)) {
         StreamEpi ep = stream_epi_plain(1.0, 0.0, nullptr);
         ep.x2 = xb;
         ep.nsplit = nsplit;

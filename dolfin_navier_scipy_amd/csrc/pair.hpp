@@ -49,23 +49,34 @@ struct HostPair {
     std::vector<int> rowblocks;               // rows 0..nvp-1 pair rows, then
                                               // nvp + p pressure rows
     std::vector<int> base;                    // two bases per row block
+    int aoff = 0, poff = 0;                   // row block: first global pair
+                                              // row / pressure row
     int64_t nnz_equiv = 0;
 };
 
-// K: (nv + np) x (nv + np), rows / columns < nv = velocity; nv even
+// K: (nv + np) x (nv + np), rows / columns < nv = velocity; nv even.
+// Row block of a partitioned system (`nvl >= 0`): K holds `nvl` velocity rows
+// that start at the EVEN global row `v0`, then its pressure rows from global
+// pressure row `p0` on; the columns stay global (nv = global velocity count).
 inline bool host_pair_from_k(const HostCsr &K, int nv, HostPair &P,
-                             const char **why = nullptr) {
+                             const char **why = nullptr, int nvl = -1,
+                             int v0 = 0, int p0 = 0) {
     const char *dummy = nullptr;
     if (!why) why = &dummy;
     const int n = K.nrows;
-    if (n <= 0 || nv <= 0 || (nv & 1) || nv > n || K.ncols != n) {
+    const bool block = nvl >= 0;
+    if (!block) nvl = nv;
+    if (n <= 0 || nv <= 0 || (nv & 1) || (nvl & 1) || (v0 & 1) || nvl > n ||
+        K.ncols < nv || (!block && K.ncols != n)) {
         *why = "odd (or no) number of velocity dofs";
         return false;
     }
     P = HostPair();
     P.nv = nv;
-    P.np = n - nv;
-    P.nvp = nv / 2;
+    P.np = n - nvl;
+    P.nvp = nvl / 2;
+    P.aoff = v0 / 2;
+    P.poff = p0;
     P.nnz_equiv = K.nnz();
     const int nvp = P.nvp, np = P.np;
     P.rpA.assign(1, 0);
@@ -111,7 +122,7 @@ inline bool host_pair_from_k(const HostCsr &K, int nv, HostPair &P,
         P.rpA.push_back((int)P.colA.size());
         P.rpB.push_back((int)P.colB.size());
     }
-    for (int r = nv; r < n; ++r) {
+    for (int r = nvl; r < n; ++r) {
         int k = K.rowptr[r];
         const int e = K.rowptr[r + 1];
         while (k < e) {
@@ -206,7 +217,7 @@ inline bool host_pair_from_k(const HostCsr &K, int nv, HostPair &P,
 }
 
 struct PairDev {
-    int nv = 0, np = 0, nvp = 0, nblocks = 0;
+    int nv = 0, np = 0, nvp = 0, nblocks = 0, aoff = 0, poff = 0;
     int64_t nentA = 0;
     DevBuf<int> rpA, rpB, rpC, rowblocks, base;
     DevBuf<unsigned short> cA, cB, cC;
@@ -216,6 +227,8 @@ struct PairDev {
         nv = P.nv;
         np = P.np;
         nvp = P.nvp;
+        aoff = P.aoff;
+        poff = P.poff;
         nblocks = (int)P.rowblocks.size() - 1;
         auto up_i = [&](DevBuf<int> &d, const std::vector<int> &h) -> int {
             DNS_TRY(d.alloc(std::max<size_t>(2, h.size())));
@@ -285,6 +298,8 @@ struct PairArgs {
     const double *vA, *vB, *vC;
     int64_t nentA;
     int nblocks, nvp, nv;
+    int aoff, poff;              // row block of a partitioned system: global
+                                 // pair row / pressure row of its first rows
 };
 
 // y = alpha K x + beta b with the epilogues of k_spmv_stream16x that a K apply
@@ -408,7 +423,7 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
                 s0 = subwave_sum<G>(s0);
                 s1 = subwave_sum<G>(s1);
                 if (g == 0) {
-                    const size_t row = (size_t)2 * (r0 + r);
+                    const size_t row = (size_t)2 * (A.aoff + r0 + r);
                     double o0, o1;
                     if (ep.b) {
                         const dns_double2 bb =
@@ -470,7 +485,7 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
                     s0 += prod0[k];
                 s0 = subwave_sum<G>(s0);
                 if (g == 0) {
-                    const size_t row = (size_t)A.nv + p0 + r;
+                    const size_t row = (size_t)A.nv + A.poff + p0 + r;
                     const double o0 =
                         ep.b ? fma(ep.alpha, s0, ep.beta * ep.b[row])
                              : ep.alpha * s0;
@@ -485,8 +500,8 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
             if ((int)threadIdx.x < nout) {
                 const double out = srow[threadIdx.x];
                 const size_t row =
-                    vrows ? (size_t)2 * r0 + threadIdx.x
-                          : (size_t)A.nv + (r0 - A.nvp) + threadIdx.x;
+                    vrows ? (size_t)2 * (A.aoff + r0) + threadIdx.x
+                          : (size_t)A.nv + A.poff + (r0 - A.nvp) + threadIdx.x;
 #pragma unroll
                 for (int i = 0; i < ND; ++i)
                     if (i < ep.nvec)
@@ -538,6 +553,7 @@ inline int launch_pair16x(const PairDev &A, const double *x, double *y,
     a.vA = A.vA.p; a.vB = A.vB.p; a.vC = A.vC.p;
     a.nblocks = A.nblocks; a.nvp = A.nvp; a.nv = A.nv;
     a.nentA = A.nentA;
+    a.aoff = A.aoff; a.poff = A.poff;
     if (diag)
         hipLaunchKernelGGL((k_spmv_pair16x<4, 1, false>), pair_grid(A, grid_cap),
                            kBlock, 0, s, a, x, y, ep, guard);

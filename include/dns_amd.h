@@ -246,7 +246,9 @@ int dns_halo_lists(const dns_csr *a, int32_t row0, int32_t row1,
 int dns_saddle_device_bytes(dns_saddle *h, int64_t *matrix_bytes);
 /* attach before dns_saddle_setup_precond; NULL detaches */
 int dns_saddle_set_comm(dns_saddle *h, dns_comm *c);
-/* the block partition used for n rows: [start, end) of `rank` */
+/* the block partition used for n rows: [start, end) of `rank` (chunks of
+ * ceil(n / nranks) rows rounded up to an even number: the two velocity dofs of
+ * a node stay on one rank) */
 int dns_partition_range(int32_t n, int32_t nranks, int32_t rank,
                         int32_t *start, int32_t *end);
 /* raw device <-> host copies for the callback backend */

@@ -113,17 +113,18 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
     # level but the dense coarsest one; the knobs are read when the handle is
     # created)
     knobs = {}
-    if fhat in ('mgpart', 'mg3part'):
+    if fhat in ('mgpart', 'mg3part', 'mg3parts'):
         knobs['DNS_MG_PART_MIN'] = '0'
-    if fhat in ('mg3', 'mg3part'):
+    if fhat in ('mg3', 'mg3part', 'mg3parts'):
         knobs['DNS_MG_DENSE_MAX'] = '300'
     if fhat in ('mg', 'mgpart'):
         knobs['DNS_MG_DENSE_MAX'] = '100'      # (two levels at least)
-    if fhat == 'cyl3s':
-        # the row blocks through the streaming kernels (bandwidth regime)
+    if fhat in ('cyl3s', 'mg3parts'):
+        # the row blocks through the streaming kernels (bandwidth regime):
+        # K in the pair format, J Fh^-1 and the level operators as fp32 streams
         knobs['DNS_STREAM_NNZ'] = '1'
-    three = fhat in ('mg3', 'mg3part')
-    mgs = fhat in ('mg', 'mgpart', 'mg3', 'mg3part')
+    three = fhat in ('mg3', 'mg3part', 'mg3parts')
+    mgs = fhat in ('mg', 'mgpart', 'mg3', 'mg3part', 'mg3parts')
     cyl3 = fhat in ('cyl3', 'cyl3s')
     pr = (_mg3_problem() if three else _mg_problem()) if mgs else (
         _cyl3_problem() if cyl3 else _problem())
@@ -294,7 +295,8 @@ def _worker(rank, world, port, outdir):
     out = {}
     for fhat, reorth in (('explicit', False), ('full', False), ('mg', False),
                          ('mgpart', False), ('mg3', False), ('mg3part', False),
-                         ('cyl3', False), ('cyl3s', False)):
+                         ('mg3parts', False), ('cyl3', False),
+                         ('cyl3s', False)):
         info = {}
         before = cm.stats()
         x, st, v, p = _solve_and_step(saddle, cm, fhat, reorth, info=info)
@@ -350,7 +352,8 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
     info3 = {}
     x3, st3, v3, p3 = _solve_and_step(saddle, None, 'mg3', False, info=info3)
     for key, (xr, vr, strf) in (('mgpart', (xm, vm, stm)),
-                                ('mg3part', (x3, v3, st3))):
+                                ('mg3part', (x3, v3, st3)),
+                                ('mg3parts', (x3, v3, st3))):
         assert np.array_equal(r0[key + '_0'], r1[key + '_0'])
         assert float(r0[key + '_4']) <= 5e-12
         assert np.linalg.norm(r0[key + '_0'] - xr) <= 1e-9*np.linalg.norm(xr)
