@@ -13,7 +13,8 @@ import krylov_model as km
 
 
 def starts_for(n, nranks):
-    chunk = (n + nranks - 1)//nranks
+    # (even chunks: the two velocity dofs of a node stay on one rank)
+    chunk = ((n + nranks - 1)//nranks + 1) & ~1
     return [min(n, r*chunk) for r in range(nranks + 1)]
 
 
