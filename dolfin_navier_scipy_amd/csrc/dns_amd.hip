@@ -107,6 +107,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     if (const char *sn = getenv("DNS_MG_FUSED")) mg_fused_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
     if (const char *sn = getenv("DNS_PAIR")) pair_knob = sn[0] != '0';
+    if (const char *sn = getenv("DNS_PART_SETUP")) part_setup = sn[0] != '0';
     if (const char *sn = getenv("DNS_DIST_GRAPH")) dist_graph_ok = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_CHEB")) mg_cheb = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_CYCLES"))
@@ -546,6 +547,8 @@ int dns_saddle::build_explicit(bool dense_schur) {
     }
     HostCsr DF = Fsrc;
     host_scale_rows(dv, DF);
+    tmp_presliced = false;
+    if (comm && part_setup) return build_explicit_part(dense_schur, DF, dv);
     // (with drop_tol == 0 the zero entries of the pattern of F^(k-1) stay)
     HostCsr G = host_cheb_poly(DF, dv, theta, c1, c2, popts.drop_tol);
     lap("polynomial G (row recurrences)");
@@ -1182,7 +1185,9 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     DNS_HIP(hipStreamSynchronize(stream));
     if (comm) {
         // from here on this rank keeps ITS row blocks only
-        DNS_TRY(setup_dist(tmp_Gch, have_jg ? &tmp_JGh : nullptr));
+        DNS_TRY(setup_dist(tmp_Gch, have_jg ? &tmp_JGh : nullptr,
+                           tmp_presliced));
+        tmp_presliced = false;
         tmp_Gch = HostCsr();
         tmp_JGh = HostCsr();
     }
@@ -1992,6 +1997,7 @@ static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double va
     const std::string k(name);
     if (k == "stream_nnz") h->stream_nnz = (int64_t)value;
     else if (k == "pair") h->pair_knob = value != 0.0;
+    else if (k == "part_setup") h->part_setup = value != 0.0;
     else if (k == "mg_dense_max") h->mg_dense_max = (int)value;
     else if (k == "mg_part_min") h->mg_part_min = (int)value;
     else if (k == "mg_fused") h->mg_fused_knob = value != 0.0;

@@ -228,26 +228,31 @@ inline void host_drop_small(HostCsr &A, double tol) {
 // touched list per thread, no matrix temporaries (the matrix form spent 0.4 s
 // of the 0.45 s set-up at N=2 adding matrices with the pattern of F^5).
 // Entries below tol * (row maximum) are dropped at the end; diagonal kept.
+// `rows` (sorted): only these rows are formed, the others stay empty -- a rank
+// of a row-partitioned set-up forms the rows its blocks are made of.
 inline HostCsr host_cheb_poly(const HostCsr &DF, const std::vector<double> &dv,
                               double theta, const std::vector<double> &c1,
-                              const std::vector<double> &c2, double tol) {
+                              const std::vector<double> &c2, double tol,
+                              const std::vector<int> *rows = nullptr) {
     const int n = DF.nrows;
+    const int nr = rows ? (int)rows->size() : n;
     HostCsr G;
     G.nrows = G.ncols = n;
     G.rowptr.assign((size_t)n + 1, 0);
     int nt = (int)std::min<unsigned>(16u, std::max(1u,
                                      std::thread::hardware_concurrency()));
-    nt = std::max(1, std::min(nt, n / 64 + 1));
+    nt = std::max(1, std::min(nt, nr / 64 + 1));
     std::vector<std::vector<int>> rl((size_t)nt), cis((size_t)nt);
     std::vector<std::vector<double>> vas((size_t)nt);
     auto work = [&](int t) {
-        const int r0 = (int)((int64_t)n * t / nt), r1 = (int)((int64_t)n * (t + 1) / nt);
+        const int r0 = (int)((int64_t)nr * t / nt), r1 = (int)((int64_t)nr * (t + 1) / nt);
         std::vector<double> x((size_t)n, 0.0), r((size_t)n, 0.0),
             d((size_t)n, 0.0), w((size_t)n, 0.0);
         std::vector<char> in((size_t)n, 0);
         std::vector<int> touched;
         rl[t].assign((size_t)(r1 - r0), 0);
-        for (int i = r0; i < r1; ++i) {
+        for (int ii = r0; ii < r1; ++ii) {
+            const int i = rows ? (*rows)[ii] : ii;
             touched.clear();
             touched.push_back(i);
             in[i] = 1;
@@ -293,7 +298,7 @@ inline HostCsr host_cheb_poly(const HostCsr &DF, const std::vector<double> &dv,
                 x[j] = r[j] = d[j] = 0.0;
                 in[j] = 0;
             }
-            rl[t][i - r0] = cnt;
+            rl[t][ii - r0] = cnt;
         }
     };
     dns_run_threads(nt, work);
@@ -301,13 +306,17 @@ inline HostCsr host_cheb_poly(const HostCsr &DF, const std::vector<double> &dv,
     for (int t = 0; t < nt; ++t) total += cis[t].size();
     G.colidx.reserve(total);
     G.vals.reserve(total);
+    // row lengths first (rows outside the list: zero), then the prefix sum
     for (int t = 0; t < nt; ++t) {
-        const int r0 = (int)((int64_t)n * t / nt);
-        for (size_t q = 0; q < rl[t].size(); ++q)
-            G.rowptr[r0 + q + 1] = G.rowptr[r0 + q] + rl[t][q];
+        const int r0 = (int)((int64_t)nr * t / nt);
+        for (size_t q = 0; q < rl[t].size(); ++q) {
+            const int i = rows ? (*rows)[(size_t)r0 + q] : r0 + (int)q;
+            G.rowptr[(size_t)i + 1] = rl[t][q];
+        }
         G.colidx.insert(G.colidx.end(), cis[t].begin(), cis[t].end());
         G.vals.insert(G.vals.end(), vas[t].begin(), vas[t].end());
     }
+    for (int i = 0; i < n; ++i) G.rowptr[(size_t)i + 1] += G.rowptr[i];
     return G;
 }
 

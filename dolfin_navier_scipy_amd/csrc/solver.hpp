@@ -377,13 +377,23 @@ struct dns_saddle {
     uint64_t dist_generation = 0;     // bumped whenever the slicing changes
                                       // (attached steppers re-slice their own
                                       // operators then)
-    int setup_dist(const dns::HostCsr &Gch, const dns::HostCsr *JGh);
+    int setup_dist(const dns::HostCsr &Gch, const dns::HostCsr *JGh,
+                   bool presliced = false);
+    // partitioned set-up (every rank forms the rows of its blocks only)
+    int build_explicit_part(bool dense_schur, const dns::HostCsr &DF,
+                            const std::vector<double> &dv);
+    int gather_need_lists(const std::vector<std::vector<int>> &mine,
+                          std::vector<std::vector<std::vector<int>>> &all);
+    int gather_csr_rows(const dns::HostCsr &loc, const std::vector<int> &starts,
+                        int ncols, dns::HostCsr &out);
     int restore_full_device();
     int update_values_dist();
     int enqueue_cycle_dist(const double *b, double *x, int c,
                            const dns_solve_opts *o, int first);
     dns::RowMap dist_rowmap() const;
     dns::HostCsr tmp_Gch, tmp_JGh;    // handed from build_explicit to setup_dist
+    bool tmp_presliced = false;       // ... already this rank's rows only
+    bool part_setup = true;           // DNS_PART_SETUP: partitioned set-up
     std::vector<int> st_v, st_p;      // block partitions of the velocity /
                                       // pressure rows over the ranks
     dns::DevBuf<double> dsum;         // all-reduced scalars

@@ -430,6 +430,9 @@ int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
  *   "mg_cheb"       0/1: Chebyshev pair of smoothing weights; "mg_cheb_alpha"
  *   "mg_cycles"     1 or 2 cycles per application; "mg_rho"
  *   "dist_graph"    0/1: hipGraph replay with captured RCCL calls
+ *   "part_setup"    0/1: with a communicator, every rank forms only the rows
+ *                   of Fh^-1, J Fh^-1 and of the Schur complement its blocks
+ *                   are made of (default 1; 0: every rank forms all rows)
  * Unknown names: DNS_ERR_BAD_ARGUMENT.  (No reference counterpart.) */
 int dns_saddle_set_option(dns_saddle *h, const char *name, double value);
 

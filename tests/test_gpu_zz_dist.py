@@ -113,6 +113,11 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
     # level but the dense coarsest one; the knobs are read when the handle is
     # created)
     knobs = {}
+    if fhat.endswith('_rep'):
+        # the set-up replicated (every rank forms every row) instead of
+        # partitioned (the default with a communicator)
+        knobs['DNS_PART_SETUP'] = '0'
+        fhat = fhat[:-4]
     if fhat in ('mgpart', 'mg3part', 'mg3parts'):
         knobs['DNS_MG_PART_MIN'] = '0'
     if fhat in ('mg3', 'mg3part', 'mg3parts'):
@@ -296,7 +301,8 @@ def _worker(rank, world, port, outdir):
     for fhat, reorth in (('explicit', False), ('full', False), ('mg', False),
                          ('mgpart', False), ('mg3', False), ('mg3part', False),
                          ('mg3parts', False), ('cyl3', False),
-                         ('cyl3s', False)):
+                         ('cyl3s', False), ('full_rep', False),
+                         ('mg3part_rep', False), ('cyl3_rep', False)):
         info = {}
         before = cm.stats()
         x, st, v, p = _solve_and_step(saddle, cm, fhat, reorth, info=info)
@@ -393,6 +399,13 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
     assert np.linalg.norm(r0['cyl3s_1'] - vc) <= 1e-9*np.linalg.norm(vc)
     assert np.linalg.norm(r0['cyl3s_2'] - pc) <= 1e-7*np.linalg.norm(pc)
     assert abs(int(r0['cyl3s_3']) - stc['iters']) <= 3
+    # partitioned set-up (every rank forms its rows of Fh^-1, J Fh^-1 and of
+    # the Schur complement only) == replicated set-up, bit for bit
+    for key in ('full', 'mg3part', 'cyl3'):
+        for i in (0, 1, 2):
+            assert np.array_equal(r0[key + '_%d' % i],
+                                  r0[key + '_rep_%d' % i]), (key, i)
+        assert int(r0[key + '_3']) == int(r0[key + '_rep_3'])
     # per-rank storage: the row blocks, not the matrices
     for rr in (r0, r1):
         assert int(rr['cyl3_5']) < 0.6*info['matrix_bytes'], \
