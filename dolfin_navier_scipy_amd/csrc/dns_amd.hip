@@ -1624,6 +1624,7 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     const int gran = std::max(1, o->check_every);
     int c = (last_iters >= 0) ? last_iters + 1 : std::min(m, 16);
     c = std::min(m, std::max(gran, (c + gran - 1) / gran * gran));
+    if (cycle_first > 0) c = std::min(m, cycle_first);
     if (pipeline_c > 0) c = std::min(m, pipeline_c);
     // dots fused into the K apply while the system is launch-latency bound
     fuse_dots = n <= 400000;
@@ -1659,7 +1660,8 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             bits_of(oo.atol), first ? prologue_key : 0u,
             (uint64_t)popts.cheb_degree, (uint64_t)popts.schur,
             (uint64_t)first + 2u * (uint64_t)reset, (uint64_t)fhat_explicit,
-            (uint64_t)fuse_dots};
+            (uint64_t)fuse_dots, (uint64_t)(uintptr_t)z_plan_override,
+            (uint64_t)dist_x0_exchange + 2u * (uint64_t)dist_lazy1};
         DNS_TRY(run_cached(key, graph, [&]() -> int {
             if (first && prologue) DNS_TRY(prologue());
             if (dist()) return enqueue_cycle_dist(b, x, c, &oo, reset);
@@ -1998,6 +2000,9 @@ static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double va
     if (k == "stream_nnz") h->stream_nnz = (int64_t)value;
     else if (k == "pair") h->pair_knob = value != 0.0;
     else if (k == "part_setup") h->part_setup = value != 0.0;
+    else if (k == "dist_x0_exchange") h->dist_x0_exchange = value != 0.0;
+    else if (k == "dist_lazy1") h->dist_lazy1 = value != 0.0;
+    else if (k == "cycle_first") h->cycle_first = (int)value;
     else if (k == "mg_dense_max") h->mg_dense_max = (int)value;
     else if (k == "mg_part_min") h->mg_part_min = (int)value;
     else if (k == "mg_fused") h->mg_fused_knob = value != 0.0;

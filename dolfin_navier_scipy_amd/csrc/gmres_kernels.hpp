@@ -825,6 +825,128 @@ k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
     }
 }
 
+// ---- one-step cycle of the row-partitioned solve without the all-reduce of
+// the residual norm.  The first basis vector stays UN-normalised (V_0 = r),
+// z = P^-1 r, w = K z, and the four sums <w, r>, <w, w>, <r, r>, <b, b> are
+// all-reduced TOGETHER behind the step: one collective per time step less.
+// In the scaled basis v = r / rho (rho = ||r||) this is the Arnoldi step the
+// other kernels take:  h = <w, r> / rho^2,  hn^2 = <w, w> / rho^2 - h^2,
+// x += (<w, r> / <w, w>) z,  ||r_new|| = rho sqrt(1 - <w, r>^2 / (rr ww)).
+//
+// out[0..1] = sums of the first two scalars of `parta` (nparta partials each),
+// out[2] = sum of partr, out[3] = sum of partb (nparts each): ONE workgroup
+__global__ void __launch_bounds__(kBlock)
+k_sum_lazy4(const double *__restrict__ parta, int nparta,
+            const double *__restrict__ partr, const double *__restrict__ partb,
+            int nparts, double *__restrict__ out) {
+    __shared__ double red[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (int i = threadIdx.x; i < nparta; i += kBlock) {
+        s0 += parta[i];
+        s1 += parta[(size_t)nparta + i];
+    }
+    for (int i = threadIdx.x; i < nparts; i += kBlock) {
+        s2 += partr[i];
+        s3 += partb[i];
+    }
+    s0 = block_sum(s0, red);
+    __syncthreads();
+    s1 = block_sum(s1, red);
+    __syncthreads();
+    s2 = block_sum(s2, red);
+    __syncthreads();
+    s3 = block_sum(s3, red);
+    if (threadIdx.x == 0) {
+        out[0] = s0;
+        out[1] = s1;
+        out[2] = s2;
+        out[3] = s3;
+    }
+}
+
+// Tail of that cycle: every workgroup forms the step length from the four
+// all-reduced sums and updates its share of x; workgroup 0 commits the solve's
+// bookkeeping -- everything k_arn_head (j = 0, first = 1) and k_arn_tail_acc
+// would have left in the control block.  A solve whose start vector is inside
+// the tolerance already takes no step.
+__global__ void __launch_bounds__(kBlock)
+k_arn_tail_lazy1(int n, const double *__restrict__ hs, DnsCtl *ctl,
+                 double *__restrict__ histbuf, int hist_cap, int maxiter,
+                 double rtol, double atol, const double *__restrict__ Z,
+                 double *__restrict__ x, TailExtrap te) {
+    const int ef = blockIdx.x * kBlock + threadIdx.x;
+    double pfx = 0.0, pz0 = 0.0;
+    if (ef < n) {
+        pfx = x[ef];
+        pz0 = Z[ef];
+    }
+    const double wr = hs[0], ww = hs[1], rr = hs[2], bb = hs[3];
+    const double rho = sqrt(rr), bn = sqrt(bb);
+    const double tol = fmax(rtol * bn, atol);
+    int status = DNS_OK, conv = 0, tot = 0;
+    double res = rho, alpha = 0.0;
+    const bool go = (rho > tol) && !isnan(rho) && maxiter > 0;
+    if (isnan(rho) || isnan(tol)) status = DNS_BREAKDOWN;
+    if (go) {
+        const double d = ww * rr - wr * wr;
+        if (!(ww > 0.0) || isnan(ww)) {
+            status = DNS_BREAKDOWN;
+        } else if (!(d > 1e-8 * ww * rr)) {
+            // (the guard of the fused Gram-Schmidt: the norm by Pythagoras has
+            // lost its digits)
+            status = kGsFallback;
+        } else {
+            alpha = wr / ww;
+            res = rho * sqrt(d / (ww * rr));
+            tot = 1;
+            conv = res <= tol;
+            if (isnan(res)) status = DNS_BREAKDOWN;
+        }
+    } else {
+        conv = rho <= tol;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->predone = 0;
+        ctl->jdone = tot;
+        ctl->zero = 0;
+        ctl->done = 1;
+        ctl->status = status;
+        ctl->total_it = tot;
+        ctl->conv = conv;
+        ctl->beta = rho;
+        ctl->tol = tol;
+        ctl->resnorm = res;
+        ctl->bnorm = bn;
+        ctl->g[0] = rho;
+        ctl->hist[0] = rho;
+        ctl->hist[1] = res;
+        ctl->y[0] = rho * alpha;
+        int hl = 0;
+        if (hl < hist_cap) histbuf[hl++] = rho;
+        if (tot > 0 && hl < hist_cap) histbuf[hl++] = res;
+        ctl->hist_len = hl;
+        ctl->acc_solves += 1;
+        ctl->acc_iters += tot;
+        if (tot > ctl->acc_maxit) ctl->acc_maxit = tot;
+        if (conv && tol > 0.0) {
+            const double rel = res / tol;
+            if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
+        }
+        if (!conv) ctl->acc_fail += 1;
+    }
+    if (tot == 0 && !te.out) return;
+    if (ef < n) {
+        const double s = fma(alpha, pz0, pfx);
+        if (tot > 0) x[ef] = s;
+        if (te.out) tail_extrapolate(te, ef, s);
+    }
+    for (int e = ef + gridDim.x * kBlock; e < n; e += gridDim.x * kBlock) {
+        const double s = fma(alpha, Z[e], x[e]);
+        if (tot > 0) x[e] = s;
+        if (te.out) tail_extrapolate(te, e, s);
+    }
+}
+
 // u = sum_{i<jdone} y_i V_i
 __global__ void __launch_bounds__(kBlock)
 k_basis_combine(int n, const double *__restrict__ V, size_t ld,

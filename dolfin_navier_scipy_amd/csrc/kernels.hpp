@@ -729,6 +729,18 @@ k_sum_partials(const double *__restrict__ partials, int nparts,
     if (threadIdx.x == 0) out[0] = s;
 }
 
+// two such sums in ONE launch (workgroup 0: a -> out[0], 1: b -> out[1])
+__global__ void __launch_bounds__(kBlock)
+k_sum_partials2(const double *__restrict__ pa, const double *__restrict__ pb,
+                int nparts, double *__restrict__ out) {
+    __shared__ double red[4];
+    const double *__restrict__ p = blockIdx.x == 0 ? pa : pb;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += kBlock) s += p[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_diag_inv(int nrows, const int *__restrict__ rowptr,
            const int *__restrict__ colidx, const double *__restrict__ vals,

@@ -392,6 +392,16 @@ struct dns_saddle {
                            const dns_solve_opts *o, int first);
     dns::RowMap dist_rowmap() const;
     dns::HostCsr tmp_Gch, tmp_JGh;    // handed from build_explicit to setup_dist
+    // row-partitioned cycle: exchange the start vector's halo (not needed, see
+    // enqueue_cycle_dist); halo plan for the preconditioned vectors when the
+    // caller's is wider than the rows of K need
+    bool dist_x0_exchange = false;
+    // one-step cycles without the all-reduce of the residual norm
+    // (k_arn_tail_lazy1); the constants 1, 0 the head reads as "norms"
+    bool dist_lazy1 = true;
+    int cycle_first = 0;              // > 0: length of a solve's first cycle
+    dns::DevBuf<double> lazy_one;
+    const struct dns_halo_plan *z_plan_override = nullptr;
     bool tmp_presliced = false;       // ... already this rank's rows only
     bool part_setup = true;           // DNS_PART_SETUP: partitioned set-up
     std::vector<int> st_v, st_p;      // block partitions of the velocity /

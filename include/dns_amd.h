@@ -430,6 +430,13 @@ int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
  *   "mg_cheb"       0/1: Chebyshev pair of smoothing weights; "mg_cheb_alpha"
  *   "mg_cycles"     1 or 2 cycles per application; "mg_rho"
  *   "dist_graph"    0/1: hipGraph replay with captured RCCL calls
+ *   "cycle_first"   > 0: Krylov steps in the first cycle of every solve
+ *                   (default: what the previous solve needed, plus one)
+ *   "dist_lazy1"    0/1: one-step cycles of a partitioned solve leave the
+ *                   first basis vector un-normalised; ||r||, ||b|| travel with
+ *                   the step's dots (one all-reduce per time step less)
+ *   "dist_x0_exchange"  0/1: halo exchange of the start vector at the head of
+ *                   every cycle of a partitioned solve (default 0: it is valid)
  *   "part_setup"    0/1: with a communicator, every rank forms only the rows
  *                   of Fh^-1, J Fh^-1 and of the Schur complement its blocks
  *                   are made of (default 1; 0: every rank forms all rows)

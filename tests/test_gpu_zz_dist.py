@@ -113,6 +113,15 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
     # level but the dense coarsest one; the knobs are read when the handle is
     # created)
     knobs = {}
+    if fhat.endswith('_lazy') or fhat.endswith('_nolazy'):
+        # every solve starts with a ONE-step cycle: with 'dist_lazy1' (default)
+        # its first vector stays un-normalised and the norms of r and b are
+        # all-reduced together with the step's dots; later cycles of the solve
+        # are the general ones
+        knobs['DNS_CYCLE_FIRST'] = '1'
+        if fhat.endswith('_nolazy'):
+            knobs['DNS_DIST_LAZY1'] = '0'
+        fhat = fhat[:fhat.rindex('_')]
     if fhat.endswith('_rep'):
         # the set-up replicated (every rank forms every row) instead of
         # partitioned (the default with a communicator)
@@ -282,6 +291,62 @@ def test_rccl_world_size_one_equals_plain_solve():
     cm.close()
 
 
+def test_one_step_cycles_carry_the_norms_with_the_dots():
+    """pipelined CNAB steps of the bench workload on one RCCL rank: once the
+    warm start is good every solve is ONE Krylov step, and with 'dist_lazy1'
+    the norms of r and b are all-reduced together with that step's dots --
+    two all-reduces of scalars per time step become one"""
+    from dolfin_navier_scipy_amd import saddle as sad, comm as dcomm
+    from dolfin_navier_scipy_amd import convection
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=100.)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    dt = 1./512
+    out = {}
+    for lazy in (1, 0):
+        cm = dcomm.Comm.rccl(0, 1, 0, dcomm.rccl_unique_id())
+        system = sad.SaddleSystem((M + .5*dt*A).tocsr(), J)
+        system.set_option('dist_lazy1', lazy)
+        system.set_comm(cm)
+        system.setup_precond(cheb_degree=6, schur='dense', fhat='explicit',
+                             factorization='full', drop_tol=1e-3)
+        cvop = convection.ConvectionP2.from_taylor_hood(
+            femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+        v0 = np.zeros((NV, 1))
+        nfc = cvop.apply(v0, scale=-1.0)
+        stp = sad.ImexStepper(system, (M - .5*dt*A).tocsr())
+        stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+        stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+        stp.set_convection(cvop, scale=-1.0)
+        cf = sad.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                    pscale=-1./dt, extrapolate=4)
+        opts = sad.solve_opts(rtol=1e-10, maxiter=400, reorth=2,
+                              use_graph=True)
+        stp.run(256, cf, opts)               # past the start-up transient
+        c0 = cm.stats()
+        _, its, lst = stp.run(128, cf, opts)
+        c1 = cm.stats()
+        v, p = stp.get_state()
+        out[lazy] = (v, p, its, c1['allreduce'] - c0['allreduce'],
+                     lst['true_relres'], dict(stp.last_run))
+        stp.close()
+        cvop.close()
+        system.set_comm(None)
+        cm.close()
+        system.close()
+    (vl, pl, il, arl, trl, recl), (vn, pn, inn, arn, trn, recn) = out[1], out[0]
+    print('128 steps: Krylov steps', il, '/', inn, 'all-reduces', arl, '/', arn,
+          recl)
+    assert trl <= 1e-9 and trn <= 1e-9
+    assert np.linalg.norm(vl - vn) <= 1e-8*np.linalg.norm(vn)
+    assert np.linalg.norm(pl - pn) <= 1e-6*np.linalg.norm(pn)
+    assert abs(il - inn) <= 8
+    # one rank, dense Schur block by rows: per one-step solve 2 all-reduces
+    # (norms, dots) become 1
+    assert arl <= arn - 64, (arl, arn)
+
+
 def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                       RANK=str(rank), WORLD_SIZE=str(world),
@@ -301,7 +366,9 @@ def _worker(rank, world, port, outdir):
     for fhat, reorth in (('explicit', False), ('full', False), ('mg', False),
                          ('mgpart', False), ('mg3', False), ('mg3part', False),
                          ('mg3parts', False), ('cyl3', False),
-                         ('cyl3s', False), ('full_rep', False),
+                         ('cyl3s', False), ('full_lazy', 2),
+                         ('full_nolazy', 2), ('mg3part_lazy', 2),
+                         ('full_rep', False),
                          ('mg3part_rep', False), ('cyl3_rep', False)):
         info = {}
         before = cm.stats()
@@ -399,6 +466,16 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
     assert np.linalg.norm(r0['cyl3s_1'] - vc) <= 1e-9*np.linalg.norm(vc)
     assert np.linalg.norm(r0['cyl3s_2'] - pc) <= 1e-7*np.linalg.norm(pc)
     assert abs(int(r0['cyl3s_3']) - stc['iters']) <= 3
+    # one-step first cycles with the norms travelling behind the step: the
+    # same answers with fewer all-reduces
+    for key, ref in (('full', 'full'), ('mg3part', 'mg3part')):
+        lz = key + '_lazy'
+        assert np.array_equal(r0[lz + '_0'], r1[lz + '_0'])
+        assert float(r0[lz + '_4']) <= 5e-12
+        for i, tol in ((0, 1e-9), (1, 1e-9), (2, 1e-7)):
+            a, b = r0[lz + '_%d' % i], r0[ref + '_%d' % i]
+            assert np.linalg.norm(a - b) <= tol*np.linalg.norm(b), (lz, i)
+    # (the counts of collectives: test_one_step_cycles_* below)
     # partitioned set-up (every rank forms its rows of Fh^-1, J Fh^-1 and of
     # the Schur complement only) == replicated set-up, bit for bit
     for key in ('full', 'mg3part', 'cyl3'):
