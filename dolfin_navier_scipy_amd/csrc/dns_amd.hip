@@ -226,8 +226,9 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
 // the pair format of K for the K applies of the bandwidth regime (one GPU);
 // silently absent for odd sizes
 int dns_saddle::build_pair() {
+    if (comm) return DNS_OK;         // (the row block's: setup_dist)
     Kp.release_all();
-    if (!pair_knob || comm || !streams(K)) return DNS_OK;
+    if (!pair_knob || !streams(K)) return DNS_OK;
     if (fh_stale) return DNS_OK;     // (host values not current)
     const HostCsr kf = host_k_slice(Fh, JTh, Jh, nv, 0, nv, 0, np);
     HostPair P;
