@@ -1665,7 +1665,9 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             (uint64_t)dist_x0_exchange + 2u * (uint64_t)dist_lazy1};
         DNS_TRY(run_cached(key, graph, [&]() -> int {
             if (first && prologue) DNS_TRY(prologue());
-            if (dist()) return enqueue_cycle_dist(b, x, c, &oo, reset);
+            if (dist())
+                return enqueue_cycle_dist(b, x, c, &oo, reset,
+                                          first && prologue_has_resid);
             return enqueue_cycle(b, x, c, &oo, reset,
                                  first && prologue_has_resid);
         }));

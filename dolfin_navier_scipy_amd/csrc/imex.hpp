@@ -55,6 +55,7 @@ struct dns_imex {
     // steps); DNS_STEP6=0 keeps the seven-node step
     dns::DevBuf<double> x0buf[2], rc6[2], ckx0, ckrc[2], ckcell, kx6;
     bool six_ok = false, env_six = true;
+    bool env_dfront = true;   // DNS_DIST_FRONT: one-launch front of a partitioned step
     uint64_t six_conv_gen = 0;     // conv->dbc_gen the cell values belong to
     int prime_six(const dns_imex_coeffs *cf, bool keep_r);
     // coefficients of the polynomial warm start from `nsol_` solutions

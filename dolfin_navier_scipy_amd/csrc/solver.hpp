@@ -389,7 +389,8 @@ struct dns_saddle {
     int restore_full_device();
     int update_values_dist();
     int enqueue_cycle_dist(const double *b, double *x, int c,
-                           const dns_solve_opts *o, int first);
+                           const dns_solve_opts *o, int first,
+                           bool have_resid = false);
     dns::RowMap dist_rowmap() const;
     dns::HostCsr tmp_Gch, tmp_JGh;    // handed from build_explicit to setup_dist
     // row-partitioned cycle: exchange the start vector's halo (not needed, see

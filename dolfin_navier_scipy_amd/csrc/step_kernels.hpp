@@ -745,4 +745,82 @@ k_batch_begin(CopyList cl, DnsCtl *ctl) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Front of a ROW-PARTITIONED IMEX step in the latency regime: for this rank's
+// rows of K (velocity rows, then pressure rows; RowMap) ONE launch forms
+//   nfc_c = scale * (gathered convection cell values)       (gptr != nullptr)
+//   b_v   = R1 (a_c v_c + a_p v_p) + cn_c nfc_c + cn_o nfc_o + g ,  b_p = gp
+//   r     = b - K x0   and the partials of ||r||^2, ||b||^2
+// (three launches before: convection gather, right-hand side, residual).  R1
+// holds the rank's velocity rows (local row = local velocity row of K).
+// ---------------------------------------------------------------------------
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_dist_front(RowMap rm, int nv_all, const int *__restrict__ krp,
+             const int *__restrict__ kci, const double *__restrict__ kva,
+             const double *__restrict__ x0, const int *__restrict__ rrp,
+             const int *__restrict__ rci, const double *__restrict__ rva,
+             const double *__restrict__ v_c, const double *__restrict__ v_p,
+             double a_c, double a_p, double *__restrict__ nfc_c,
+             const double *__restrict__ nfc_o, double cn_c, double cn_o,
+             TabRef gtab, TabRef gptab, const int *__restrict__ gptr,
+             const int *__restrict__ gidx, const double *__restrict__ cellvals,
+             double conv_scale, double *__restrict__ b, double *__restrict__ r,
+             double *__restrict__ part_rr, double *__restrict__ part_bb) {
+    __shared__ double red[4];
+    const double *__restrict__ g = tab_row(gtab);
+    const double *__restrict__ gp = tab_row(gptab);
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    double arr = 0.0, abb = 0.0;
+    for (int li = sub; li < rm.len1 + rm.len2; li += nsub) {
+        const int row = map_row(rm, li);
+        // K row first: its gathers are the long pole
+        const double sk = csr_row_dot<LPR>(krp, kci, kva, x0, li, sublane);
+        double bv;
+        if (li < rm.len1) {
+            double s = 0.0;
+            const int k1 = rrp[li + 1];
+            if (a_p != 0.0) {
+                for (int k = rrp[li] + sublane; k < k1; k += LPR) {
+                    const int c = rci[k];
+                    s = fma(rva[k], fma(a_c, v_c[c], a_p * v_p[c]), s);
+                }
+            } else {
+                for (int k = rrp[li] + sublane; k < k1; k += LPR)
+                    s = fma(rva[k], a_c * v_c[rci[k]], s);
+            }
+            s = subwave_sum<LPR>(s);
+            double nc;
+            if (gptr) {
+                double sg = 0.0;
+                const int g1 = gptr[row + 1];
+                for (int k = gptr[row] + sublane; k < g1; k += LPR)
+                    sg += cellvals[gidx[k]];
+                nc = conv_scale * subwave_sum<LPR>(sg);
+                if (sublane == 0) nfc_c[row] = nc;
+            } else {
+                nc = nfc_c[row];
+            }
+            bv = s + cn_c * nc + cn_o * nfc_o[row] + g[row];
+        } else {
+            bv = gp[row - nv_all];
+        }
+        if (sublane == 0) {
+            const double v = bv - sk;
+            b[row] = bv;
+            r[row] = v;
+            arr = fma(v, v, arr);
+            abb = fma(bv, bv, abb);
+        }
+    }
+    arr = block_sum(arr, red);
+    abb = block_sum(abb, red);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = arr;
+        part_bb[blockIdx.x] = abb;
+    }
+}
+
 }  // namespace dns
