@@ -1662,7 +1662,8 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
             (uint64_t)popts.cheb_degree, (uint64_t)popts.schur,
             (uint64_t)first + 2u * (uint64_t)reset, (uint64_t)fhat_explicit,
             (uint64_t)fuse_dots, (uint64_t)(uintptr_t)z_plan_override,
-            (uint64_t)dist_x0_exchange + 2u * (uint64_t)dist_lazy1};
+            (uint64_t)dist_x0_exchange + 2u * (uint64_t)dist_lazy1,
+            (uint64_t)(uintptr_t)dist_rnew};
         DNS_TRY(run_cached(key, graph, [&]() -> int {
             if (first && prologue) DNS_TRY(prologue());
             if (dist())

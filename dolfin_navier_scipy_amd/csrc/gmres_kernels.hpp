@@ -873,7 +873,13 @@ __global__ void __launch_bounds__(kBlock)
 k_arn_tail_lazy1(int n, const double *__restrict__ hs, DnsCtl *ctl,
                  double *__restrict__ histbuf, int hist_cap, int maxiter,
                  double rtol, double atol, const double *__restrict__ Z,
-                 double *__restrict__ x, TailExtrap te) {
+                 double *__restrict__ x, TailExtrap te,
+                 const double *__restrict__ r0 = nullptr,
+                 const double *__restrict__ w = nullptr,
+                 double *__restrict__ rnew = nullptr, int nv = 0) {
+    // rnew (residual carry-over): the velocity part of the TRUE residual behind
+    // the step, r0 - alpha w = b - K (x0 + alpha z), wherever r0 and w are
+    // valid (the rank's own rows)
     const int ef = blockIdx.x * kBlock + threadIdx.x;
     double pfx = 0.0, pz0 = 0.0;
     if (ef < n) {
@@ -934,6 +940,9 @@ k_arn_tail_lazy1(int n, const double *__restrict__ hs, DnsCtl *ctl,
         }
         if (!conv) ctl->acc_fail += 1;
     }
+    if (rnew)
+        for (int e = ef; e < nv; e += gridDim.x * kBlock)
+            rnew[e] = fma(-alpha, w[e], r0[e]);
     if (tot == 0 && !te.out) return;
     if (ef < n) {
         const double s = fma(alpha, pz0, pfx);

@@ -403,6 +403,7 @@ struct dns_saddle {
     int cycle_first = 0;              // > 0: length of a solve's first cycle
     dns::DevBuf<double> lazy_one;
     const struct dns_halo_plan *z_plan_override = nullptr;
+    double *dist_rnew = nullptr;      // residual carry-over of the stepper
     bool tmp_presliced = false;       // ... already this rank's rows only
     bool part_setup = true;           // DNS_PART_SETUP: partitioned set-up
     std::vector<int> st_v, st_p;      // block partitions of the velocity /

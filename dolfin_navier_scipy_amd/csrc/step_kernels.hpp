@@ -766,7 +766,11 @@ k_dist_front(RowMap rm, int nv_all, const int *__restrict__ krp,
              TabRef gtab, TabRef gptab, const int *__restrict__ gptr,
              const int *__restrict__ gidx, const double *__restrict__ cellvals,
              double conv_scale, double *__restrict__ b, double *__restrict__ r,
-             double *__restrict__ part_rr, double *__restrict__ part_bb) {
+             double *__restrict__ part_rr, double *__restrict__ part_bb,
+             const double *__restrict__ rcc, const double *__restrict__ rcp) {
+    // rcc / rcp (residual carry-over, dns_imex_coeffs.carry_residual): the true
+    // velocity residuals of the last two solves, added to the right-hand side
+    // with the weights of the solutions they belong to
     __shared__ double red[4];
     const double *__restrict__ g = tab_row(gtab);
     const double *__restrict__ gp = tab_row(gptab);
@@ -804,6 +808,10 @@ k_dist_front(RowMap rm, int nv_all, const int *__restrict__ krp,
                 nc = nfc_c[row];
             }
             bv = s + cn_c * nc + cn_o * nfc_o[row] + g[row];
+            if (rcc) {
+                bv = fma(a_c, rcc[row], bv);
+                if (a_p != 0.0) bv = fma(a_p, rcp[row], bv);
+            }
         } else {
             bv = gp[row - nv_all];
         }

@@ -8,6 +8,15 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
+# PMC passes FIRST: bench.py prints roofline.traffic only from a stamp taken on the sources as they are
+cd /tmp && export TMPDIR=/tmp
+echo "== PMC passes (separate), SpMV alone"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $R/scripts/spmv_roofline.py 4 10 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || echo "pmc fetch failed"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python3 $R/scripts/spmv_roofline.py 4 10 > $OUT/pmc_write.json 2> $OUT/pmc_write.err || echo "pmc write failed"
+cd $R
+python scripts/pmc_summary.py "$OUT/pmc_*/*counter_collection.csv" > $OUT/pmc_summary.json
+python scripts/stamp_traffic.py $OUT/pmc_summary.json > $OUT/traffic_stamp.json
+cd $R
 echo "== bench (default)"; timeout -k 10 500 python bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
 echo "== bench (driver window)"; timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $OUT/bench_driver_window.json 2> $OUT/bench_driver_window.err || echo "driver window failed"
 echo "== refined legs"
@@ -18,6 +27,7 @@ echo "== SBDF2, partitioned path on one RCCL rank"
 timeout -k 10 300 python bench.py --scheme sbdf2 --no-cpu --no-refined --no-picard --roofline-refine 0 > $OUT/bench_sbdf2.json 2> $OUT/bench_sbdf2.err || echo "sbdf2 failed"
 timeout -k 10 300 python bench.py --partitioned-only --gpus 1 --level 2 --steps 400 --warmup 40 --spinup 256 > $OUT/partitioned_one_rank_n10k.json 2> $OUT/partitioned_one_rank_n10k.err || echo "partitioned n10k failed"
 timeout -k 10 300 python bench.py --partitioned-only --gpus 1 --level 2 --refine 2 --nts 2048 --steps 200 --warmup 20 --spinup 256 > $OUT/partitioned_one_rank_n173k.json 2> $OUT/partitioned_one_rank_n173k.err || echo "partitioned n173k failed"
+timeout -k 10 300 python bench.py --partitioned-only --gpus 1 --level 2 --refine 3 --nts 4096 --steps 200 --warmup 20 --spinup 256 > $OUT/partitioned_one_rank_n693k.json 2> $OUT/partitioned_one_rank_n693k.err || echo "partitioned n693k failed"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 kernel stats of the bench command (graph replay)"
 # (graph-mode profiles stay below ~1e4 replayed kernels: profiles/r03_rocprof_graph_crash)
@@ -25,12 +35,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench
 echo "== rocprofv3 kernel stats of the step alone (graph replay / eager)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step_graph -o step -- python3 $R/bench.py --profile-step --steps 300 --warmup 40 --spinup 64 > $OUT/step_graph.json 2> $OUT/step_graph.err || echo "step graph profile failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step_eager -o step -- python3 $R/bench.py --profile-step --eager --steps 400 --warmup 40 > $OUT/step_eager.json 2> $OUT/step_eager.err || echo "step eager profile failed"
-echo "== PMC passes (separate), SpMV alone"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $R/scripts/spmv_roofline.py 4 10 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || echo "pmc fetch failed"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python3 $R/scripts/spmv_roofline.py 4 10 > $OUT/pmc_write.json 2> $OUT/pmc_write.err || echo "pmc write failed"
 cd $R
-python scripts/pmc_summary.py "$OUT/pmc_*/*counter_collection.csv" > $OUT/pmc_summary.json
-python scripts/stamp_traffic.py $OUT/pmc_summary.json > $OUT/traffic_stamp.json
 python - <<PY
 import json, glob, csv
 out='$OUT'
