@@ -118,6 +118,10 @@ struct CsrDev {
     // block whose columns do not fit two 32768-wide windows (read raw)
     DevBuf<unsigned short> c16;
     DevBuf<int> c16base;
+    // per row block of the 2048 tile: r0, nr, k0, nn, blo, bhi, 0, 0 -- what
+    // the 16-bit streaming kernels read INSTEAD of rowblocks / rowptr / c16base
+    // at the head of a tile (passed in the `rowblocks` argument)
+    DevBuf<int> meta16;
     int c16_rawblocks = 0;
 
     int upload(const dns_csr *a, hipStream_t s);
@@ -132,6 +136,7 @@ struct CsrDev {
         }
         c16.release();
         c16base.release();
+        meta16.release();
         nrows = ncols = 0;
         nnz = 0;
     }

@@ -377,10 +377,14 @@ k_spmv_stream16(int nblocks, const int *__restrict__ rowblocks,
     const int cls = blockIdx.x % 8;
     const int vb = cls * gq + (cls < gr ? cls : gr) + blockIdx.x / 8;
     for (int blk = vb; blk < nblocks; blk += gridDim.x) {
-        const int r0 = rowblocks[blk], r1 = rowblocks[blk + 1];
-        const int k0 = rowptr[r0], k1 = rowptr[r1];
-        const int nn = k1 - k0;
-        const int blo = c16base[2 * blk], bhi = c16base[2 * blk + 1];
+        // ONE 32-byte record per row block (r0, nr, k0, nn, blo, bhi): two
+        // scalar loads in front of the stream loads instead of a chain of
+        // three dependent ones (rowblocks -> rowptr -> ...)
+        const int4 m0 = reinterpret_cast<const int4 *>(rowblocks)[2 * blk];
+        const int4 m1 = reinterpret_cast<const int4 *>(rowblocks)[2 * blk + 1];
+        const int r0 = m0.x, r1 = m0.x + m0.y;
+        const int k0 = m0.z, nn = m0.w, k1 = k0 + nn;
+        const int blo = m1.x, bhi = m1.y;
         if (nn > TILE) {
             double s = 0.0;
             for (int k = k0 + threadIdx.x; k < k1; k += kBlock)
@@ -559,10 +563,14 @@ k_spmv_stream16x(int nblocks, const int *__restrict__ rowblocks,
 #pragma unroll
     for (int i = 0; i < (DOTS ? kStreamDots + 1 : 1); ++i) acc[i] = 0.0;
     for (int blk = vb; blk < nblocks; blk += gridDim.x) {
-        const int r0 = rowblocks[blk], r1 = rowblocks[blk + 1];
-        const int k0 = rowptr[r0], k1 = rowptr[r1];
-        const int nn = k1 - k0;
-        const int blo = c16base[2 * blk], bhi = c16base[2 * blk + 1];
+        // ONE 32-byte record per row block (r0, nr, k0, nn, blo, bhi): two
+        // scalar loads in front of the stream loads instead of a chain of
+        // three dependent ones (rowblocks -> rowptr -> ...)
+        const int4 m0 = reinterpret_cast<const int4 *>(rowblocks)[2 * blk];
+        const int4 m1 = reinterpret_cast<const int4 *>(rowblocks)[2 * blk + 1];
+        const int r0 = m0.x, r1 = m0.x + m0.y;
+        const int k0 = m0.z, nn = m0.w, k1 = k0 + nn;
+        const int blo = m1.x, bhi = m1.y;
         __syncthreads();             // previous tile fully consumed
         const int nr = r1 - r0;
         bool single = nn > TILE;     // a single long row

@@ -220,6 +220,7 @@ struct PairDev {
     int nv = 0, np = 0, nvp = 0, nblocks = 0, aoff = 0, poff = 0;
     int64_t nentA = 0;
     DevBuf<int> rpA, rpB, rpC, rowblocks, base;
+    DevBuf<int> meta;        // per row block: r0, nr, k0A, nA, k0B, nB, b0, b1
     DevBuf<unsigned short> cA, cB, cC;
     DevBuf<double> vA, vB, vC;
     bool ready = false;
@@ -251,6 +252,32 @@ struct PairDev {
         DNS_TRY(up_i(rpC, P.rpC));
         DNS_TRY(up_i(rowblocks, P.rowblocks));
         DNS_TRY(up_i(base, P.base));
+        {
+            // everything a workgroup needs to know about its row block in ONE
+            // 32-byte record (two scalar loads instead of a chain of three
+            // dependent ones in front of the stream loads)
+            std::vector<int> mt((size_t)8 * std::max(1, nblocks), 0);
+            for (int b = 0; b < nblocks; ++b) {
+                const int r0 = P.rowblocks[b], r1 = P.rowblocks[b + 1];
+                int *m = &mt[(size_t)8 * b];
+                m[0] = r0;
+                m[1] = r1 - r0;
+                if (r0 < P.nvp) {
+                    m[2] = P.rpA[r0];
+                    m[3] = P.rpA[r1] - P.rpA[r0];
+                    m[4] = P.rpB[r0];
+                    m[5] = P.rpB[r1] - P.rpB[r0];
+                } else {
+                    m[2] = P.rpC[r0 - P.nvp];
+                    m[3] = P.rpC[r1 - P.nvp] - P.rpC[r0 - P.nvp];
+                }
+                m[6] = P.base[2 * b];
+                m[7] = P.base[2 * b + 1];
+            }
+            DNS_TRY(meta.alloc(mt.size()));
+            DNS_TRY(meta.upload(mt.data(), mt.size(), s));
+            DNS_HIP(hipStreamSynchronize(s));     // `mt` dies with this block
+        }
         DNS_TRY(up_s(cA, P.cA));
         DNS_TRY(up_s(cB, P.cB));
         DNS_TRY(up_s(cC, P.cC));
@@ -280,20 +307,22 @@ struct PairDev {
     }
     void release_all() {
         rpA.release(); rpB.release(); rpC.release();
-        rowblocks.release(); base.release();
+        rowblocks.release(); base.release(); meta.release();
         cA.release(); cB.release(); cC.release();
         vA.release(); vB.release(); vC.release();
         ready = false;
         nblocks = 0;
     }
     int64_t bytes() const {
-        return (int64_t)((rpA.n + rpB.n + rpC.n + rowblocks.n + base.n) * 4 +
+        return (int64_t)((rpA.n + rpB.n + rpC.n + rowblocks.n + base.n +
+                          meta.n) * 4 +
                          (cA.n + cB.n + cC.n) * 2 + (vA.n + vB.n + vC.n) * 8);
     }
 };
 
 struct PairArgs {
     const int *rpA, *rpB, *rpC, *rowblocks, *base;
+    const int4 *meta;
     const unsigned short *cA, *cB, *cC;
     const double *vA, *vB, *vC;
     int64_t nentA;
@@ -337,14 +366,14 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
 #pragma unroll
     for (int i = 0; i < (DOTS ? ND + 1 : 1); ++i) acc[i] = 0.0;
     for (int blk = vb; blk < A.nblocks; blk += gridDim.x) {
-        const int r0 = A.rowblocks[blk], r1 = A.rowblocks[blk + 1];
-        const int nr = r1 - r0;
+        const int4 m0 = A.meta[2 * blk], m1 = A.meta[2 * blk + 1];
+        const int r0 = m0.x, nr = m0.y, r1 = r0 + nr;
         const bool vrows = r0 < A.nvp;
-        const int b0 = A.base[2 * blk], b1 = A.base[2 * blk + 1];
+        const int b0 = m1.z, b1 = m1.w;
         __syncthreads();                 // previous tile fully consumed
         if (vrows) {
-            const int ka0 = A.rpA[r0], kb0 = A.rpB[r0];
-            const int na = A.rpA[r1] - ka0, nbt = A.rpB[r1] - kb0;
+            const int ka0 = m0.z, kb0 = m1.x;
+            const int na = m0.w, nbt = m1.y;
             if ((int)threadIdx.x <= nr) {
                 rpsA[threadIdx.x] = A.rpA[r0 + threadIdx.x] - ka0;
                 rpsB[threadIdx.x] = A.rpB[r0 + threadIdx.x] - kb0;
@@ -446,8 +475,8 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
             }
         } else {
             const int p0 = r0 - A.nvp;
-            const int kc0 = A.rpC[p0];
-            const int nc = A.rpC[p0 + nr] - kc0;
+            const int kc0 = m0.z;
+            const int nc = m0.w;
             for (int t = threadIdx.x; t <= nr; t += kBlock)
                 rpsA[t] = A.rpC[p0 + t] - kc0;
             const dns_double2 *__restrict__ vc2 =
@@ -549,6 +578,7 @@ inline int launch_pair16x(const PairDev &A, const double *x, double *y,
     PairArgs a;
     a.rpA = A.rpA.p; a.rpB = A.rpB.p; a.rpC = A.rpC.p;
     a.rowblocks = A.rowblocks.p; a.base = A.base.p;
+    a.meta = reinterpret_cast<const int4 *>(A.meta.p);
     a.cA = A.cA.p; a.cB = A.cB.p; a.cC = A.cC.p;
     a.vA = A.vA.p; a.vB = A.vB.p; a.vC = A.vC.p;
     a.nblocks = A.nblocks; a.nvp = A.nvp; a.nv = A.nv;

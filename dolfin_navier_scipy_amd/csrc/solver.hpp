@@ -113,10 +113,22 @@ inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
                                 : (unsigned short)(0x8000 | (c - hi));
                 }
             }
+            std::vector<int> mt((size_t)8 * std::max(1, nb), 0);
+            for (int b = 0; b < nb; ++b) {
+                int *m = &mt[(size_t)8 * b];
+                m[0] = rb[b];
+                m[1] = rb[b + 1] - rb[b];
+                m[2] = (int)a->rowptr[rb[b]];
+                m[3] = (int)(a->rowptr[rb[b + 1]] - a->rowptr[rb[b]]);
+                m[4] = bases[2 * b];
+                m[5] = bases[2 * b + 1];
+            }
             DNS_TRY(c16.alloc(cc.size()));
             DNS_TRY(c16base.alloc(bases.size()));
+            DNS_TRY(meta16.alloc(mt.size()));
             DNS_TRY(c16.upload(cc.data(), cc.size(), s));
             DNS_TRY(c16base.upload(bases.data(), bases.size(), s));
+            DNS_TRY(meta16.upload(mt.data(), mt.size(), s));
             // `cc`, `bases` die with this block: an asynchronous copy out of a
             // freed (and possibly unmapped) host buffer is a GPU memory fault
             DNS_HIP(hipStreamSynchronize(s));
@@ -168,7 +180,7 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
         // memory-side cost
         const int nb = A.nrowblocks_t[1];
         hipLaunchKernelGGL((k_spmv_stream16<4, 3>), std::min(nb, 65535), kBlock,
-                           0, s, nb, A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p,
+                           0, s, nb, A.meta16.p, A.rowptr.p, A.colidx.p,
                            A.c16.p, A.c16base.p, A.vals.p, x, y, alpha, beta, b);
     } else if ((variant == 3 || variant == 4) && A.c16.p) {
         // diagnostic variants of the 16-bit kernel (see k_spmv_stream16)
@@ -176,12 +188,12 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
         const int grid = std::min(nb, 65535);
         if (variant == 3)
             hipLaunchKernelGGL((k_spmv_stream16<4, 1>), grid, kBlock, 0, s, nb,
-                               A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p,
+                               A.meta16.p, A.rowptr.p, A.colidx.p,
                                A.c16.p, A.c16base.p, A.vals.p, x, y, alpha,
                                beta, b);
         else
             hipLaunchKernelGGL((k_spmv_stream16<4, 2>), grid, kBlock, 0, s, nb,
-                               A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p,
+                               A.meta16.p, A.rowptr.p, A.colidx.p,
                                A.c16.p, A.c16base.p, A.vals.p, x, y, alpha,
                                beta, b);
     } else if (variant == 5 && A.c16.p) {
@@ -190,7 +202,7 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
         const int nb = A.nrowblocks_t[1];
         hipLaunchKernelGGL((k_spmv_stream16<4, 0, double, 0>),
                            std::min(nb, 65535), kBlock, 0, s, nb,
-                           A.rowblocks_t[1].p, A.rowptr.p, A.colidx.p, A.c16.p,
+                           A.meta16.p, A.rowptr.p, A.colidx.p, A.c16.p,
                            A.c16base.p, A.vals.p, x, y, alpha, beta, b, guard);
     } else if (variant == DNS_SPMV_STREAM16 && A.c16.p) {
         // the same with 16-bit column offsets: 10 instead of 12 bytes per
@@ -198,7 +210,7 @@ inline int launch_spmv(const CsrDev &A, const double *x, double *y,
         const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
         const int nb = A.nrowblocks_t[1];
         const int grid = std::min(nb, 65535);
-        const int *rbp = A.rowblocks_t[1].p;
+        const int *rbp = A.meta16.p;
         if (avg <= 6)
             hipLaunchKernelGGL((k_spmv_stream16<1, 0, double, 1>), grid, kBlock,
                                0, s, nb, rbp, A.rowptr.p, A.colidx.p, A.c16.p,
@@ -259,7 +271,7 @@ inline int launch_stream16x(const CsrDev &A, const VT *vals, const double *x,
     const double avg = A.nrows > 0 ? (double)A.nnz / A.nrows : 1.0;
     const int nb = A.nrowblocks_t[1];
     const int grid = std::max(1, std::min(nb, grid_cap));
-    const int *rbp = A.rowblocks_t[1].p;
+    const int *rbp = A.meta16.p;
 #define DNS_STREAM16X(GG)                                                      \
     do {                                                                      \
         if (ep.part)                                                          \
