@@ -2671,16 +2671,19 @@ static int dns_spmv_pair_impl(int device, const dns_csr *k, int32_t nv, const do
     const StreamEpi ep = stream_epi_plain(1.0, 0.0, nullptr);
     // (warmup < 0: the diagnostic variant without the gather of x -- timing
     // only, the result is wrong by design; scripts/spmv_c16.py)
-    const int diag = warmup < 0 ? 1 : 0;
+    int diag = warmup < 0 ? 1 : 0;
+    if (const char *ab = getenv("DNS_PAIR_AB")) diag = atoi(ab);   // A/B record
+    int gcap = 65535;
+    if (const char *gc = getenv("DNS_PAIR_GRID")) gcap = std::max(1, atoi(gc));
     for (int i = 0; i < std::max(1, std::abs((int)warmup)); ++i)
-        DNS_TRY(launch_pair16x(A, dx.p, dy.p, ep, ss.s, nullptr, 65535, diag));
+        DNS_TRY(launch_pair16x(A, dx.p, dy.p, ep, ss.s, nullptr, gcap, diag));
     if (reps > 0 && avg_seconds) {
         hipEvent_t e0, e1;
         DNS_HIP(hipEventCreate(&e0));
         DNS_HIP(hipEventCreate(&e1));
         DNS_HIP(hipEventRecord(e0, ss.s));
         for (int i = 0; i < reps; ++i)
-            DNS_TRY(launch_pair16x(A, dx.p, dy.p, ep, ss.s, nullptr, 65535,
+            DNS_TRY(launch_pair16x(A, dx.p, dy.p, ep, ss.s, nullptr, gcap,
                                    diag));
         DNS_HIP(hipEventRecord(e1, ss.s));
         DNS_HIP(hipEventSynchronize(e1));

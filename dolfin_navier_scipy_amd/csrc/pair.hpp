@@ -337,7 +337,7 @@ struct PairArgs {
 // DOTS: instantiation with the fused-dots epilogue (the plain product keeps
 // its accumulators out of the register file: 6 instead of 4 waves per SIMD)
 template <int G, int DIAG = 0, bool DOTS = true, int ND = kStreamDots>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, (DOTS || DIAG) ? 1 : 7)   // DIAG 2: A/B without the bound
 k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
                double *__restrict__ y, StreamEpi ep,
                const int *__restrict__ guard) {
@@ -419,12 +419,12 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
             double pg[NIB];
 #pragma unroll
             for (int i = 0; i < NIA; ++i) {
-                if (na > 0) xg[i] = xx[DIAG ? (r0 + (i & 3)) : (b0 + ea[i])];
+                if (na > 0) xg[i] = xx[DIAG == 1 ? (r0 + (i & 3)) : (b0 + ea[i])];
                 else xg[i].x = xg[i].y = 0.0;
             }
 #pragma unroll
             for (int i = 0; i < NIB; ++i)
-                pg[i] = nbt > 0 ? xp[DIAG ? (i & 1) : (b1 + eb[i])] : 0.0;
+                pg[i] = nbt > 0 ? xp[DIAG == 1 ? (i & 1) : (b1 + eb[i])] : 0.0;
 #pragma unroll
             for (int i = 0; i < NIA; ++i) {
                 const int slot = threadIdx.x + i * kBlock;
@@ -499,7 +499,7 @@ k_spmv_pair16x(PairArgs A, const double *__restrict__ x,
             dns_double2 xg[NIA];
 #pragma unroll
             for (int i = 0; i < NIA; ++i) {
-                if (nc > 0) xg[i] = xx[DIAG ? (i & 3) : (b0 + ec[i])];
+                if (nc > 0) xg[i] = xx[DIAG == 1 ? (i & 3) : (b0 + ec[i])];
                 else xg[i].x = xg[i].y = 0.0;
             }
 #pragma unroll
@@ -584,7 +584,10 @@ inline int launch_pair16x(const PairDev &A, const double *x, double *y,
     a.nblocks = A.nblocks; a.nvp = A.nvp; a.nv = A.nv;
     a.nentA = A.nentA;
     a.aoff = A.aoff; a.poff = A.poff;
-    if (diag)
+    if (diag == 2)
+        hipLaunchKernelGGL((k_spmv_pair16x<4, 2, false>), pair_grid(A, grid_cap),
+                           kBlock, 0, s, a, x, y, ep, guard);
+    else if (diag)
         hipLaunchKernelGGL((k_spmv_pair16x<4, 1, false>), pair_grid(A, grid_cap),
                            kBlock, 0, s, a, x, y, ep, guard);
     else if (ep.part && ep.nvec <= 3)
