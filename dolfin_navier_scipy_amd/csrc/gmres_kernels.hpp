@@ -839,7 +839,8 @@ __global__ void __launch_bounds__(kBlock)
 k_sum_lazy4(const double *__restrict__ parta, int nparta,
             const double *__restrict__ partr, const double *__restrict__ partb,
             int nparts, double *__restrict__ out) {
-    __shared__ double red[4];
+    // all four sums side by side: independent loads, ONE exchange through LDS
+    __shared__ double red[4][kBlock / 64];
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     for (int i = threadIdx.x; i < nparta; i += kBlock) {
         s0 += parta[i];
@@ -849,18 +850,22 @@ k_sum_lazy4(const double *__restrict__ parta, int nparta,
         s2 += partr[i];
         s3 += partb[i];
     }
-    s0 = block_sum(s0, red);
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    s3 = wave_sum(s3);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[0][wave] = s0;
+        red[1][wave] = s1;
+        red[2][wave] = s2;
+        red[3][wave] = s3;
+    }
     __syncthreads();
-    s1 = block_sum(s1, red);
-    __syncthreads();
-    s2 = block_sum(s2, red);
-    __syncthreads();
-    s3 = block_sum(s3, red);
-    if (threadIdx.x == 0) {
-        out[0] = s0;
-        out[1] = s1;
-        out[2] = s2;
-        out[3] = s3;
+    if (threadIdx.x < 4) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[threadIdx.x][w];
+        out[threadIdx.x] = t;
     }
 }
 
