@@ -248,7 +248,6 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
                 const DnsCtl *ctl, RowMap rm, int with_ww) {
     // with_ww: one more scalar, part[(j+1)*nparts + wg] = <w, w> (the norm of
     // the orthogonalised vector then follows from Pythagoras, k_arn_head_f)
-    if (ctl->done) return;
     (void)nrows;
     constexpr int NQ = (kMaxRestart + 1 + LPR) / LPR;   // dots per lane
     __shared__ double wred[kBlock / 64][NQ * LPR];
@@ -256,6 +255,16 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
     const int nvec = j + 1;
+    // the first row's pointers are asked for BEFORE the guard is looked at
+    // (guard-first the kernel starts with a chain of dependent scalar loads in
+    // front of its first vector load)
+    int kf0 = 0, kf1 = 0;
+    if (sub < rm.len1 + rm.len2) {
+        kf0 = rowptr[sub];
+        kf1 = rowptr[sub + 1];
+    }
+    const int gdone = ctl->done;
+    if (gdone) return;
     double acc[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
@@ -268,7 +277,9 @@ k_spmv_multidot(int nrows, const int *__restrict__ rowptr,
             const int i = q * LPR + sublane;
             vq[q] = (i < nvec) ? V[(size_t)i * ld + row] : 0.0;
         }
-        const double s = csr_row_dot<LPR>(rowptr, colidx, vals, z, li, sublane);
+        const int k0 = (li == sub) ? kf0 : rowptr[li];
+        const int k1 = (li == sub) ? kf1 : rowptr[li + 1];
+        const double s = csr_row_dot_k<LPR>(colidx, vals, z, k0, k1, sublane);
         if (sublane == 0) w[row] = s;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {

@@ -213,6 +213,24 @@ __device__ __forceinline__ void reduce_partials(const double *__restrict__ part,
 // sub-waves take consecutive rows, so a wavefront reads a contiguous run of
 // vals/colidx; shuffle reduction inside the sub-wave.
 // ---------------------------------------------------------------------------
+// the same with the row's pointers already in registers
+template <int LPR>
+__device__ __forceinline__ double csr_row_dot_k(const int *__restrict__ colidx,
+                                                const double *__restrict__ vals,
+                                                const double *__restrict__ x,
+                                                int k0, int k1, int sublane) {
+    int k = k0 + sublane;
+    double s0 = 0.0, s1 = 0.0;
+    for (; k + LPR < k1; k += 2 * LPR) {
+        const int c0 = colidx[k], c1 = colidx[k + LPR];
+        const double v0 = vals[k], v1 = vals[k + LPR];
+        s0 = fma(v0, x[c0], s0);
+        s1 = fma(v1, x[c1], s1);
+    }
+    if (k < k1) s0 = fma(vals[k], x[colidx[k]], s0);
+    return subwave_sum<LPR>(s0 + s1);
+}
+
 template <int LPR>
 __device__ __forceinline__ double csr_row_dot(const int *__restrict__ rowptr,
                                               const int *__restrict__ colidx,
@@ -953,14 +971,26 @@ k_spmv_split(int nv, const int *__restrict__ rowptr,
              const int *__restrict__ jsel, const double *__restrict__ zp,
              double *__restrict__ zv, const int *__restrict__ guard,
              double *__restrict__ xacc, int row0, int row1) {
-    if (*guard) return;
-    const double *rv = rbase + (size_t)(*jsel) * ld;
+    // the first row's pointers are asked for BEFORE the guard is looked at:
+    // written guard-first, the kernel starts with a chain of dependent scalar
+    // loads (kernel arguments -> *guard -> more arguments -> *jsel) in front of
+    // its first vector load -- 1-2 us of a 5 us kernel
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
-    for (int row = row0 + sub; row < row1; row += nsub) {
-        const int k1 = rowptr[row + 1];
-        int k = rowptr[row] + sublane;
+    const int rfirst = row0 + sub;
+    int kf0 = 0, kf1 = 0;
+    if (rfirst < row1) {
+        kf0 = rowptr[rfirst];
+        kf1 = rowptr[rfirst + 1];
+    }
+    const int gdone = *guard;
+    const int jcol = *jsel;
+    if (gdone) return;
+    const double *rv = rbase + (size_t)jcol * ld;
+    for (int row = rfirst; row < row1; row += nsub) {
+        const int k1 = (row == rfirst) ? kf1 : rowptr[row + 1];
+        int k = ((row == rfirst) ? kf0 : rowptr[row]) + sublane;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         for (; k + 3 * LPR < k1; k += 4 * LPR) {
             const int c0 = colidx[k], c1 = colidx[k + LPR];
