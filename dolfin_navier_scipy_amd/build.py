@@ -44,8 +44,13 @@ def needs_build():
 def build_library(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC',
-           '-shared', '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES] \
+    # kernel arguments preloaded into SGPRs by the hardware (gfx950): the
+    # first 16 dwords are there when a wave starts -- latency-bound kernels of
+    # 5 us began with two to five dependent scalar loads of their arguments
+    flags = os.environ.get('DNS_HIPCC_FLAGS',
+                           '-mllvm -amdgpu-kernarg-preload-count=16').split()
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] \
+        + flags + ['-shared', '-o', LIB] + [os.path.join(CSRC, s) for s in SOURCES] \
         + ['-L/opt/rocm/lib', '-lrccl', '-lpthread',
            '-Wl,-rpath,/opt/rocm/lib']
     if verbose:
