@@ -405,6 +405,10 @@ def roofline_pair(saddle, Kmat, nv, reps, label):
     # MEDIAN region is reported, all three are in `regions_avg_us`
     runs = []
     try:
+        # the first launches of a process run at idle clocks (148-152 us
+        # measured first thing, 132-134 us behind half a second of work on the
+        # same box): 0.3 s of the kernel itself untimed, then the regions
+        saddle.spmv_pair(Kmat, nv, x, reps=2000, warmup=5)
         for _ in range(3):
             _, secs, fbytes = saddle.spmv_pair(Kmat, nv, x, reps=reps,
                                                warmup=5)
@@ -418,6 +422,43 @@ def roofline_pair(saddle, Kmat, nv, reps, label):
                 rows=int(Kmat.shape[0]), matrix=label,
                 format_bytes=int(fbytes),
                 regions_avg_us=[1e6*r for r in runs])
+
+
+def hbm_roofline(saddle, args, dt, device):
+    """the roofline kernel on the refined matrix and what plain streaming
+    kernels get out of this HBM -- measured FIRST in the process: after the
+    other legs have allocated and freed a few GB of device memory the same
+    launches run 10-15 % slower (133 us in a fresh process, 147-152 us behind
+    the refined and Newton/Picard legs, `profiles/r03_f_final/`: every timed
+    region inside one process agrees to 1 %, the processes do not), so the
+    order of the legs would otherwise decide the figure"""
+    if args.roofline_refine <= 0:
+        return None, None, None
+    _, smr, _ = build_problem(N=args.level, Re=args.Re,
+                              refine=args.roofline_refine)
+    Kr = saddle_csr((smr['M'] + .5*dt*smr['A']).tocsr(), smr['J'])
+    # only the LDS-streaming kernel (16-bit column offsets) runs on the
+    # refined matrix, so its rocprofv3 average is this measurement and
+    # nothing else
+    label = 'K on the mesh refined {0}x (n={1})'.format(
+        args.roofline_refine, Kr.shape[0])
+    # the solver applies K through the pair format at this size (if K has an
+    # even number of velocity dofs): that is the kernel on record; the CSR
+    # streaming kernel stays next to it
+    roof_pair = roofline_pair(saddle, Kr, smr['M'].shape[0], 30, label)
+    roof_csr = roofline_spmv(saddle, Kr, 30, label, variants=('stream16',))
+    roof_hbm = roof_pair if roof_pair is not None else roof_csr
+    roof_hbm['csr_kernel'] = None if roof_pair is None else dict(
+        roof_csr, traffic=pmc_traffic(Kr, roof_csr['kernel']))
+    traffic = pmc_traffic(Kr, roof_hbm['kernel'])
+    # what plain streaming kernels get out of this HBM (2 GiB, fp64)
+    attain = {k: saddle.hbm_probe(2 << 30, k, reps=20, device=device)
+              for k in ('read', 'read8c', 'read_tiles1', 'copy', 'triad')}
+    # best read pattern: grid-stride 16-byte loads or workgroup-contiguous
+    # 16 KiB tiles (what the CSR stream kernels do)
+    attain['read'] = max(attain['read'], attain.pop('read8c'),
+                         attain.pop('read_tiles1'))
+    return roof_hbm, traffic, attain
 
 
 def roofline_spmv(saddle, Kmat, reps, label, variants=('vector', 'stream')):
@@ -942,6 +983,10 @@ def main():
         raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
 
     dt = 1./args.nts
+    if args.profile_step:
+        args.roofline_refine = 0
+    hbm_roof = hbm_roofline(saddle, args, dt, device) if rank == 0 \
+        else (None, None, None)
     femp, sm, rhsd = build_problem(N=args.level, Re=args.Re,
                                    refine=args.refine)
     M, A, J = sm['M'], sm['A'], sm['J']
@@ -1057,42 +1102,11 @@ def main():
         roof = None if args.profile_step else roofline_spmv(
             saddle, saddle_csr(F, J), 200,
             'K at the benchmark size (cache resident)', variants=('vector',))
-        roof_hbm = None
-        if args.roofline_refine > 0:
-            _, smr, _ = build_problem(N=args.level, Re=args.Re,
-                                      refine=args.roofline_refine)
-            Kr = saddle_csr((smr['M'] + .5*dt*smr['A']).tocsr(), smr['J'])
-            # only the LDS-streaming kernel (16-bit column offsets) runs on the
-            # refined matrix, so its rocprofv3 average is this measurement and
-            # nothing else
-            label = 'K on the mesh refined {0}x (n={1})'.format(
-                args.roofline_refine, Kr.shape[0])
-            roof_csr = roofline_spmv(saddle, Kr, 30, label,
-                                     variants=('stream16',))
-            # the solver applies K through the pair format at this size (if K
-            # has an even number of velocity dofs): that is the kernel on
-            # record; the CSR streaming kernel stays next to it
-            roof_pair = roofline_pair(saddle, Kr, smr['M'].shape[0], 30, label)
-            roof_hbm = roof_pair if roof_pair is not None else roof_csr
-            roof_hbm['csr_kernel'] = None if roof_pair is None else dict(
-                roof_csr, traffic=pmc_traffic(Kr, roof_csr['kernel']))
-            traffic = pmc_traffic(Kr, roof_hbm['kernel'])
-        else:
-            traffic = None
+        roof_hbm, traffic, attain = hbm_roof
         main_roof = roof_hbm if roof_hbm is not None else roof
         if main_roof is None:          # --profile-step: the step's own figure
             main_roof = dict(achieved=step_roof['achieved'],
                              kernel='(whole CNAB step, see roofline.step)')
-        # what plain streaming kernels get out of this HBM (2 GiB, fp64)
-        attain = None
-        if args.roofline_refine > 0:
-            attain = {k: saddle.hbm_probe(2 << 30, k, reps=20, device=device)
-                      for k in ('read', 'read8c', 'read_tiles1', 'copy',
-                                'triad')}
-            # best read pattern: grid-stride 16-byte loads or workgroup-
-            # contiguous 16 KiB tiles (what the CSR stream kernels do)
-            attain['read'] = max(attain['read'], attain.pop('read8c'),
-                                 attain.pop('read_tiles1'))
         roofline = dict(bound='hbm', achieved=main_roof['achieved'],
                         peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=main_roof['achieved']/HBM_PEAK_GBS,
