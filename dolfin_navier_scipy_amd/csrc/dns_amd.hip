@@ -959,7 +959,8 @@ int dns_saddle::mg_cycle_fused(const double *in, double *zp, double *xacc,
         // the second post-sweep; on the finest level it delivers zp = -x''
         double *out = (l == 0) ? zp : lv.x.p;
         const double osc = (l == 0) ? -scale : 1.0;
-        if (!dist() && streams(lv.S)) {
+        // (whole operators: one GPU, or the levels every rank runs in full)
+        if (streams(lv.S)) {
             StreamEpi ep = stream_epi_plain(osc, 0.0, b);
             ep.dinv = lv.dinv.p;
             ep.xin = lv.x2.p;
