@@ -393,6 +393,22 @@ def pmc_traffic(Kmat, kernel='k_spmv_stream16'):
     return rec['hbm_bytes_per_launch']
 
 
+def traffic_source(traffic):
+    """where `roofline.traffic` comes from: never measured by the run that
+    prints it -- replayed from the committed PMC passes while the kernel
+    sources are the ones the passes were taken on"""
+    if traffic is None:
+        return ('none: profiles/spmv_traffic.json is absent, was taken on '
+                'another matrix, or on other kernel sources (withheld)')
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'spmv_traffic.json')))
+    return ('stamped, not measured by this run: replayed from '
+            'profiles/spmv_traffic.json (rocprofv3 --pmc passes of '
+            'scripts/final_profiles.sh, FETCH_SIZE x 2 + WRITE_SIZE per '
+            'launch) taken at commit {0}; printed only while the SHA-256 of '
+            'pair.hpp / kernels.hpp equal the stamped ones'.format(
+                rec.get('commit', '?')))
+
+
 def roofline_pair(saddle, Kmat, nv, reps, label):
     """`y = K x` through the pair format (2x2 node blocks, csrc/pair.hpp) --
     the kernel that applies K inside the solver at this size; same HIP-event
@@ -475,10 +491,27 @@ def roofline_spmv(saddle, Kmat, reps, label, variants=('vector', 'stream')):
     return best
 
 
-def partitioned_run(args, world, rank, device, dist, one_gpu):
+PARITY_TOL = 1e-8           # v (M-norm) and p (l2), relative: north-star
+PARITY_PREFIX_STEPS = 10    # bandwidth ladder: the first steps are compared
+
+
+def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
+                    reference=None):
     """ONE row-partitioned simulation on `world` ranks:
-    start from rest, `--spinup` + `--warmup` untimed steps, then `--steps`
-    timed ones between barriers; the maximum over the ranks counts"""
+    `--spinup` + `--warmup` untimed steps from the start state, then `--steps`
+    timed ones between barriers; the maximum over the ranks counts.
+
+    The line carries its own proof: the final state is gathered
+    (`dns_imex_get_state`, collective) and rank 0 repeats the SAME steps from
+    the SAME state on an un-partitioned handle -- `parity` = the distance of
+    the two final states (v in the M-norm, p in l2, relative); above
+    `PARITY_TOL` the leg is an error.  Meshes of more than
+    `--parity-full-max` unknowns compare the first `PARITY_PREFIX_STEPS` steps
+    instead (the un-partitioned set-up alone takes a minute at n = 5.7M).
+    `start`: `(v0,)` handed over by the caller; else `--start` decides (the
+    steady Stokes state like the N=1 headline, solved un-partitioned on rank
+    0 and broadcast, or rest).  `reference`: `(v, p)` of an un-partitioned run
+    of the same steps the caller has already made (N=1 line)."""
     from dolfin_navier_scipy_amd import saddle, _capi, convection, perfmodel
     from dolfin_navier_scipy_amd import comm as dcomm
     dt = 1./args.nts
@@ -497,40 +530,6 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
         prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
     F = (M + .5*dt*A).tocsr()
     R1 = (M - .5*dt*A).tocsr()
-    system = saddle.SaddleSystem(F, J, device=device)
-    with stdout_to_stderr():
-        if one_gpu:
-            comm_obj = dcomm.Comm.gloo(device)
-        elif dist is not None:
-            comm_obj = dcomm.Comm.rccl_from_torch(device)
-        else:
-            comm_obj = dcomm.Comm.rccl(device, 1, 0, dcomm.rccl_unique_id())
-    system.set_comm(comm_obj)
-    if prols is not None:
-        system.set_schur_mg(prols)
-    t_setup = time.perf_counter()
-    # bandwidth regime: the partitioned solve needs the explicit polynomial
-    # matrix; degree 8 from 1e6 unknowns on (refined_bench.py's setting)
-    fhat = 'explicit' if (args.fhat == 'auto' and NV > 200000) else args.fhat
-    cheb = max(args.cheb, 8) if NV + NP > 1000000 else args.cheb
-    system.setup_precond(cheb_degree=cheb, schur=schur_kind,
-                         fhat=fhat, fp32_store=bool(args.fp32),
-                         drop_tol=args.drop, factorization=args.fact)
-    _capi.device_synchronize(device)
-    t_setup = time.perf_counter() - t_setup
-    cvop = convection.ConvectionP2.from_taylor_hood(
-        th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
-    v0 = np.zeros((NV, 1))
-    nfc = cvop.apply(v0, scale=-1.0)
-    stp = saddle.ImexStepper(system, R1)
-    stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
-    stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
-    stp.set_convection(cvop, scale=-1.0)
-    cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
-                                   pscale=-1./dt, extrapolate=args.extrap)
-    opts = saddle.solve_opts(method='gmres', rtol=args.rtol, maxiter=400,
-                             restart=60, check_every=args.check_every,
-                             use_graph=not args.eager, reorth=args.reorth)
 
     def barrier():
         _capi.device_synchronize(device)
@@ -547,6 +546,92 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
         dist.all_reduce(t, op=op)
         return [float(x) for x in t.cpu()]
 
+    # ---- start state: the same on every rank, bit for bit
+    stokes = None
+    if start is not None:
+        v0, start_kind = np.array(start[0], dtype=np.float64).reshape((NV, 1)), \
+            'handed over by the caller (the N=1 headline\'s Stokes state)'
+    elif args.start == 'stokes':
+        v0 = np.zeros((NV, 1))
+        if rank == 0:
+            v0, _, stokes = initial_state(
+                sm, rhsd, lambda Fm, Jm: saddle.SaddleSystem(Fm, Jm,
+                                                             device=device))
+        if dist is not None:
+            import torch
+            t = torch.from_numpy(np.ascontiguousarray(v0.reshape(-1)))
+            if not one_gpu:
+                t = t.cuda()
+            dist.broadcast(t, 0)
+            v0 = t.cpu().numpy().reshape((NV, 1)).copy()
+        start_kind = ('steady Stokes solution (snu:903-907), solved '
+                      'un-partitioned on rank 0 and broadcast')
+    else:
+        v0, start_kind = np.zeros((NV, 1)), 'rest'
+
+    system = saddle.SaddleSystem(F, J, device=device)
+    with stdout_to_stderr():
+        if one_gpu:
+            comm_obj = dcomm.Comm.gloo(device)
+        elif dist is not None:
+            comm_obj = dcomm.Comm.rccl_from_torch(device)
+        else:
+            comm_obj = dcomm.Comm.rccl(device, 1, 0, dcomm.rccl_unique_id())
+    system.set_comm(comm_obj)
+    if prols is not None:
+        system.set_schur_mg(prols)
+    t_setup = time.perf_counter()
+    # bandwidth regime: the partitioned solve needs the explicit polynomial
+    # matrix; degree 8 from 1e6 unknowns on (refined_bench.py's setting)
+    fhat = 'explicit' if (args.fhat == 'auto' and NV > 200000) else args.fhat
+    cheb = max(args.cheb, 8) if NV + NP > 1000000 else args.cheb
+    pkw = dict(cheb_degree=cheb, schur=schur_kind, fhat=fhat,
+               fp32_store=bool(args.fp32), drop_tol=args.drop,
+               factorization=args.fact)
+    system.setup_precond(**pkw)
+    _capi.device_synchronize(device)
+    t_setup = time.perf_counter() - t_setup
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
+    nfc = cvop.apply(v0, scale=-1.0)
+    cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
+                                   pscale=-1./dt, extrapolate=args.extrap,
+                                   carry_residual=bool(args.carry))
+
+    def options(graph):
+        return saddle.solve_opts(method='gmres', rtol=args.rtol, maxiter=400,
+                                 restart=60, check_every=args.check_every,
+                                 use_graph=graph, reorth=args.reorth)
+    opts = options(not args.eager)
+
+    class new_stepper(object):
+        """a stepper at the start state with a convection operator of its own
+        (a partitioned stepper restricts its operator to the rank's cells)"""
+
+        def __init__(self, sysh):
+            self.cv = convection.ConvectionP2.from_taylor_hood(
+                th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
+            self.st = saddle.ImexStepper(sysh, R1)
+            self.st.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+            self.st.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+            self.st.set_convection(self.cv, scale=-1.0)
+            self.run, self.get_state = self.st.run, self.st.get_state
+
+        last_run = property(lambda self: self.st.last_run)
+
+        def close(self):
+            self.st.close()
+            self.cv.close()
+
+    # ---- what is compared: the whole run, or its first steps
+    full = reference is not None or (NV + NP) <= args.parity_full_max
+    compared = None
+    if not full:
+        stp = new_stepper(system)
+        stp.run(PARITY_PREFIX_STEPS, cf, opts)
+        compared = stp.get_state()            # (collective gather)
+        stp.close()
+    stp = new_stepper(system)
     if args.spinup > 0:
         stp.run(args.spinup, cf, opts)
     stp.run(args.warmup, cf, opts)
@@ -557,6 +642,22 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
     barrier()
     wall = time.perf_counter() - t0
     c1 = comm_obj.stats()
+    run_record = dict(stp.last_run)
+    if full:
+        compared = stp.get_state()
+    # ---- device time per collective: a window of plain launches behind the
+    # timed one (events cannot time calls inside a replayed graph)
+    ntime = max(1, min(args.steps, 20))
+    comm_obj.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    stp.run(ntime, cf, options(False))
+    barrier()
+    wall_eager = time.perf_counter() - t0
+    coll_time = comm_obj.timing()
+    comm_obj.set_timing(False)
+    for rec in coll_time.values():
+        rec['us_per_time_step'] = 1e3*rec['device_ms']/ntime
     MAX = None if dist is None else dist.ReduceOp.MAX
     SUM = None if dist is None else dist.ReduceOp.SUM
     wall = over_ranks([wall], MAX)[0]
@@ -570,7 +671,47 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
         ginfo, int(R1.nnz), int(th.mesh.ncells), its/float(args.steps),
         1e3*wall/args.steps, peak_GBs=world*HBM_PEAK_GBS)
     roof.pop('ops', None)
-    v0r, v1r = dcomm.partition_range(NV, world, rank)
+
+    # ---- the proof: the same steps from the same state, un-partitioned
+    parity = None
+    if rank == 0:
+        nsteps_cmp = (args.spinup + args.warmup + args.steps) if full \
+            else PARITY_PREFIX_STEPS
+        if reference is not None:
+            v_ref, p_ref = reference
+            how = 'the un-partitioned headline run of this process'
+        else:
+            ref_sys = saddle.SaddleSystem(F, J, device=device)
+            if prols is not None:
+                ref_sys.set_schur_mg(prols)
+            ref_sys.setup_precond(**pkw)
+            rst = new_stepper(ref_sys)
+            if full:
+                if args.spinup > 0:
+                    rst.run(args.spinup, cf, opts)
+                rst.run(args.warmup, cf, opts)
+                rst.run(args.steps, cf, opts)
+            else:
+                rst.run(PARITY_PREFIX_STEPS, cf, opts)
+            v_ref, p_ref = rst.get_state()
+            rst.close()
+            ref_sys.close()
+            how = ('an un-partitioned handle on rank 0\'s GPU, same matrices, '
+                   'same preconditioner settings, same calls')
+        mn = lambda x: float(np.sqrt((x.T @ (M @ x)).item()))
+        v_cmp, p_cmp = compared
+        ev = mn(v_cmp - v_ref)/max(mn(v_ref), 1e-300)
+        ep = float(np.linalg.norm(p_cmp - p_ref)
+                   / max(np.linalg.norm(p_ref), 1e-300))
+        parity = dict(v_rel_Mnorm=ev, p_rel_l2=ep, steps=nsteps_cmp,
+                      tol=PARITY_TOL, ok=bool(ev <= PARITY_TOL
+                                              and ep <= PARITY_TOL),
+                      window='whole run (spin-up + warm-up + timed steps)'
+                      if full else 'first {0} steps from the start state '
+                      '(a run of their own before the timed one)'.format(
+                          PARITY_PREFIX_STEPS),
+                      against=how)
+    barrier()
     res = dict(
         steps_per_s=args.steps/wall, ms_per_step=1e3*wall/args.steps,
         steps=args.steps, warmup=args.warmup, spinup=args.spinup,
@@ -580,17 +721,33 @@ def partitioned_run(args, world, rank, device, dist, one_gpu):
         dof_steps_per_s=(NV + NP)*args.steps/wall, schur=schur_kind,
         krylov_iters_per_step=its/float(args.steps),
         true_relres_last=lst['true_relres'],
+        start_state=start_kind, initial_stokes=stokes,
+        parity=parity, carry_residual=bool(args.carry),
         cheb_degree=cheb, fhat=fhat,
-        run_record=dict(stp.last_run),
+        run_record=run_record,
         graph_replay=bool(not args.eager and not one_gpu and
                           os.environ.get('DNS_DIST_GRAPH', '1') != '0'),
         collectives_timed_window={k: int(c1[k] - c0[k]) for k in c1},
+        collectives_device_time=dict(
+            coll_time, steps=ntime, ms_per_step_plain_launches=(
+                1e3*wall_eager/ntime),
+            what='{0} further steps with plain launches instead of graph '
+            'replay (rank 0): HIP events on the launch stream around every '
+            'collective; a call\'s time includes the wait for the slowest '
+            'peer; halo_exchange = the ncclSend/Recv group without its pack '
+            '/ unpack kernels'.format(ntime)),
         matrix_bytes_per_rank_max=int(mb), precond_setup_s=t_setup,
         backend='gloo, host staged (one-GPU rehearsal)' if one_gpu
         else 'RCCL', roofline_step=roof,
         what='one simulation; every rank holds its row blocks of K, Fh^-1, '
              'J Fh^-1 (and of the dense Schur inverse); halo entries by '
              'index lists (Send/Recv), one all-reduce per Arnoldi step')
+    if parity is not None and not parity['ok']:
+        res['error'] = ('parity: the partitioned run is {0:.2e} (v, M-norm) / '
+                        '{1:.2e} (p) away from the un-partitioned run of the '
+                        'same steps (tolerance {2:g})'.format(
+                            parity['v_rel_Mnorm'], parity['p_rel_l2'],
+                            PARITY_TOL))
     stp.close()
     cvop.close()
     system.set_comm(None)
@@ -612,6 +769,9 @@ def partitioned_child(args, world, rank, local_rank):
                    rows_per_rank=3.*args.level/world, level=args.level,
                    refine=args.refine, krylov_iters_per_step=1.0,
                    collectives_timed_window=dict(allreduce=1), dry_run=True,
+                   start_state=args.start,
+                   parity=dict(v_rel_Mnorm=0.0, p_rel_l2=0.0, ok=True,
+                               tol=PARITY_TOL, dry_run=True),
                    roofline_step=dict(achieved=1.0, frac=1e-4))
         if rank == 0:
             print(json.dumps(res))
@@ -707,45 +867,59 @@ def multi_gpu_main(args, world, rank, local_rank):
               str(args.rtol), '--extrap', str(args.extrap), '--fp32',
               str(args.fp32), '--drop', str(args.drop), '--fhat', args.fhat,
               '--fact', args.fact, '--reorth', str(args.reorth),
-              '--check-every', str(args.check_every)]
+              '--check-every', str(args.check_every), '--carry',
+              str(args.carry), '--parity-full-max', str(args.parity_full_max)]
     if args.eager:
         common.append('--eager')
     if args.dry_run:
         common.append('--dry-run')
 
     def fresh_port(fallback):
-        # a port the OS has just handed out on rank 0, told to every rank
-        # through the parents' gloo group (a fixed offset from the launcher's
-        # port can run into one of gloo's own ephemeral sockets: the children
-        # then wait for each other until the time limit)
+        # a port the OS hands out on rank 0, told to every rank through the
+        # parents' gloo group.  The probing socket is bound with SO_REUSEADDR
+        # and stays open for the whole life of the child run: it never
+        # listens, so the child's TCPStore -- which sets SO_REUSEADDR as well
+        # -- binds the same port, while nobody else (gloo's own ephemeral
+        # sockets were the original trouble) is handed it in between; `held`
+        # is closed by the caller when the children are gone
         import socket
         t = torch.zeros(1, dtype=torch.int64)
+        held = None
         if rank == 0:
             try:
-                with socket.socket() as sk:
-                    sk.bind(('127.0.0.1', 0))
-                    t[0] = sk.getsockname()[1]
+                held = socket.socket()
+                held.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                held.bind(('127.0.0.1', 0))
+                t[0] = held.getsockname()[1]
             except OSError:
+                held = None
                 t[0] = fallback
+                sys.stderr.write('bench: no ephemeral port, falling back to '
+                                 '{0}\n'.format(fallback))
         dist.broadcast(t, 0)
-        return int(t.item())
+        return int(t.item()), held
 
-    def partitioned(port_offset, level, refine, nts):
-        env = child_env(MASTER_PORT=fresh_port(base_port + port_offset),
-                        MASTER_ADDR='127.0.0.1')
+    def partitioned(port_offset, level, refine, nts, start, timeout=None):
+        timeout = args.partitioned_timeout if timeout is None else timeout
         cmd = [sys.executable, os.path.abspath(__file__), '--partitioned-only',
                '--gpus', str(world), '--steps', str(args.steps), '--warmup',
                str(args.warmup), '--spinup', str(args.spinup), '--level',
                str(level), '--refine', str(refine), '--nts', str(nts),
                '--dense-max', str(args.dense_max), '--partitioned-timeout',
-               str(args.partitioned_timeout)] + common
+               str(timeout), '--start', start] + common
+        tries = [0]
+
         def attempt(extra_env):
             dist.barrier()
-            e2 = dict(env)
+            port, held = fresh_port(base_port + port_offset + 5*tries[0])
+            tries[0] += 1
+            e2 = child_env(MASTER_PORT=port, MASTER_ADDR='127.0.0.1')
             e2.update(extra_env)
-            if extra_env:     # (second attempt: not the first one's port)
-                e2['MASTER_PORT'] = str(fresh_port(base_port + port_offset + 5))
-            res = run_child(cmd, e2, args.partitioned_timeout, rank == 0)
+            try:
+                res = run_child(cmd, e2, timeout, rank == 0)
+            finally:
+                if held is not None:
+                    held.close()
             # a rank whose child failed makes the run a failure for everybody
             bad = torch.tensor([1 if (res is not None and 'error' in res)
                                 else 0])
@@ -770,16 +944,20 @@ def multi_gpu_main(args, world, rank, local_rank):
     # level-3 mesh (explicit convection: dt=1/512 at Re=100 is past its
     # stability limit there -- the run blows up within 200 steps)
     nts_w = args.nts*2**refine*(2 if level >= 3 else 1)
-    weak = partitioned(17, level, refine, nts_w)
+    # latency-regime legs start from the steady Stokes state like the N=1
+    # headline; the bandwidth ladder starts from rest on every N (its N=1
+    # point, `refined_bench.run`, does too)
+    weak = partitioned(17, level, refine, nts_w, 'stokes')
     # the same loop in the bandwidth regime (>= 7e5 rows per rank)
     bandwidth = None
     if not args.no_bandwidth:
         blevel, brefine = bandwidth_ladder(world)
         nts_b = args.nts*2**brefine*(2 if blevel >= 3 else 1)
-        bandwidth = partitioned(41, blevel, brefine, nts_b)
+        bandwidth = partitioned(41, blevel, brefine, nts_b, 'rest',
+                                timeout=1.5*args.partitioned_timeout)
     strong = None
     if not args.no_strong and (level, refine) != (args.level, 0):
-        strong = partitioned(29, args.level, 0, args.nts)
+        strong = partitioned(29, args.level, 0, args.nts, 'stokes')
     elif not args.no_strong:
         strong = 'identical to the headline run (same mesh)'
 
@@ -798,7 +976,9 @@ def multi_gpu_main(args, world, rank, local_rank):
                '--steps', str(args.steps), '--warmup', str(args.warmup),
                '--spinup', str(args.spinup), '--level', str(args.level),
                '--nts', str(args.nts), '--device',
-               '0' if one_gpu else str(local_rank), '--profile-step'] + common
+               '0' if one_gpu else str(local_rank), '--no-cpu', '--no-refined',
+               '--no-picard', '--roofline-refine', '0', '--no-force-dist',
+               '--no-window-400'] + common
         dist.barrier()
         one = run_child(cmd, env, args.partitioned_timeout, True)
         ms = torch.tensor([one.get('ms_per_step', float('inf'))
@@ -814,8 +994,8 @@ def multi_gpu_main(args, world, rank, local_rank):
                 if 'error' not in one else None),
             error=one.get('error'),
             what='{0} independent simulations of the N=1 workload, one per '
-                 'GPU, no data-path collective (started from rest, unlike '
-                 'the N=1 headline)'.format(world))
+                 'GPU, no data-path collective (Stokes start like the N=1 '
+                 'headline)'.format(world))
     dist.barrier()
 
     out = None
@@ -829,8 +1009,8 @@ def multi_gpu_main(args, world, rank, local_rank):
             workload = ('cylinderwake N={0} refined {1}x Re={2:g} CNAB '
                         'dt=1/{3} Taylor-Hood NV={4} NP={5} (weak-scaling '
                         'ladder: {6:.0f} rows per rank); convection on the '
-                        'device every step; state: rest advanced {7} untimed '
-                        'spin-up steps'.format(
+                        'device every step; state: steady Stokes solution '
+                        'advanced {7} untimed spin-up steps'.format(
                             level, refine, args.Re, nts_w, weak['NV'],
                             weak['NP'], weak['rows_per_rank'], args.spinup))
             rs = weak.get('roofline_step') or {}
@@ -872,7 +1052,10 @@ def multi_gpu_main(args, world, rank, local_rank):
                             weak.get('krylov_iters_per_step') if ok else None),
                         note='no scaling curve is claimed here: the driver '
                         'computes it from the per-N lines'),
-            roofline=roofline, cpu_baseline=None, parity=None)
+            roofline=roofline, cpu_baseline=None,
+            # the partitioned run against an un-partitioned run of the same
+            # steps from the same state on rank 0's GPU (partitioned_run)
+            parity=(weak.get('parity') if isinstance(weak, dict) else None))
         print(json.dumps(out))
         sys.stdout.flush()
     dist.destroy_process_group()
@@ -947,6 +1130,18 @@ def main():
                     'the multigrid Schur block')
     ap.add_argument('--device', type=int, default=0,
                     help='HIP device of a single-GPU run')
+    ap.add_argument('--start', default='stokes', choices=['stokes', 'rest'],
+                    help='(partitioned runs) start state: the steady Stokes '
+                    'solution like the N=1 headline, or rest')
+    ap.add_argument('--parity-full-max', type=int, default=200000,
+                    help='(partitioned runs) up to this many unknowns the '
+                    'WHOLE run is repeated un-partitioned on rank 0 for the '
+                    'parity record; beyond it the first {0} steps'.format(
+                        PARITY_PREFIX_STEPS))
+    ap.add_argument('--no-window-400', dest='window_400',
+                    action='store_false',
+                    help='skip the second, longer timed window '
+                    '(config.window_400)')
     ap.add_argument('--partitioned-only', action='store_true',
                     help='(internal) one row-partitioned simulation on the '
                     'ranks of this launch; prints its figures')
@@ -961,12 +1156,16 @@ def main():
                     help='skip the run of the N=1 workload through the '
                     'row-partitioned code path on one RCCL rank '
                     '(config.row_partitioned: the code the N > 1 lines time)')
-    ap.set_defaults(force_dist=True)
+    ap.set_defaults(force_dist=True, window_400=True)
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # `kill -USR1 <pid>` (or `timeout -s USR1`): the Python stacks on stderr
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)
     if args.partitioned_only:
         return partitioned_child(args, world, rank, local_rank)
     if world > 1:
@@ -1081,13 +1280,26 @@ def main():
         # secondary: the same window right behind the impulsive start (Stokes
         # state, no spin-up): the solves need about two Krylov steps there
         wall_et, _, iters_et, _, _, _ = timed_run(True, spinup=0)
+    # a second, longer window of the same loop (the driver's 20 steps pay one
+    # batch-begin kernel, the first graph launch and one host poll per call)
+    window_400 = None
+    if args.window_400 and not args.profile_step and args.steps != 400:
+        w4, _, i4, l4, _, _ = timed_run(True, nsteps=400, nwarm=40)
+        window_400 = dict(steps=400, warmup=40, steps_per_s=400/w4,
+                          ms_per_step=1e3*w4/400,
+                          krylov_iters_per_step=i4/400.,
+                          true_relres_last=l4['true_relres'],
+                          run_record=l4['run_record'])
 
     # self-test of the multi-GPU code path on one rank (RCCL communicator of
     # size 1): the same partitioned run the N > 1 headline times
     partitioned = None
     if args.force_dist and not args.profile_step:
         try:
-            partitioned = partitioned_run(args, 1, 0, device, None, False)
+            same = args.scheme == 'cnab' and args.refine == 0
+            partitioned = partitioned_run(
+                args, 1, 0, device, None, False, start=(v0,),
+                reference=(v_gpu, p_gpu) if same else None)
         except Exception as exc:          # reported, never fatal
             partitioned = dict(error=str(exc))
 
@@ -1111,6 +1323,7 @@ def main():
                         peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=main_roof['achieved']/HBM_PEAK_GBS,
                         traffic=traffic,
+                        traffic_source=traffic_source(traffic),
                         kernel=main_roof['kernel'], detail=main_roof,
                         attainable_GBs=attain,
                         # like by like: PHYSICAL bytes (PMC traffic) per second
@@ -1179,13 +1392,14 @@ def main():
             warmup=args.warmup, ms_per_step=1e3*wall/args.steps,
             higher_is_better=True, scaling=scaling, vs_baseline=None,
             dtype='f64', data='synthetic',
-            config=dict(workload='cylinderwake N={0} Re={1:g} ' +
-                        args.scheme.upper() + ' dt=1/{2} '
-                        'Taylor-Hood NV={3} NP={4}; convection N(v)v '
-                        'evaluated on the device every step; state: Stokes '
-                        'solution advanced {5} untimed spin-up steps'
-                        .format(args.level, args.Re, args.nts, NV, NP,
-                                args.spinup),
+            config=dict(workload=(
+                            'cylinderwake N={0} Re={1:g} {6} dt=1/{2} '
+                            'Taylor-Hood NV={3} NP={4}; convection N(v)v '
+                            'evaluated on the device every step; state: Stokes '
+                            'solution advanced {5} untimed spin-up steps'
+                            .format(args.level, args.Re, args.nts, NV, NP,
+                                    args.spinup, args.scheme.upper())),
+                        window_400=window_400,
                         spinup_steps=args.spinup,
                         early_transient=dict(
                             steps_per_s=world*args.steps/wall_et,

@@ -209,6 +209,8 @@ SIGNATURES = {
                                  ct.POINTER(ct.c_int32),
                                  ct.POINTER(ct.c_int32),
                                  ct.POINTER(ct.c_int32)]),
+    'dns_trap_checkpoint': (ct.c_int, [_VP]),
+    'dns_trap_restore': (ct.c_int, [_VP, ct.c_int32]),
     'dns_hbm_probe': (ct.c_int, [ct.c_int, ct.c_int64, ct.c_int32, ct.c_int32,
                                  c_double_p]),
     'dns_imex_set_rhs_table': (ct.c_int, [_VP, ct.c_int32, c_double_p,
@@ -228,6 +230,9 @@ SIGNATURES = {
                                     c_double_p, c_double_p, c_double_p]),
     'dns_comm_set_alltoallv_cb': (ct.c_int, [_VP, ALLTOALLV_CB]),
     'dns_comm_stats2': (ct.c_int, [_VP, ct.POINTER(ct.c_int64)]),
+    'dns_comm_set_timing': (ct.c_int, [_VP, ct.c_int]),
+    'dns_comm_timing': (ct.c_int, [_VP, ct.POINTER(ct.c_double),
+                                   ct.POINTER(ct.c_int64)]),
     'dns_halo_lists': (ct.c_int, [ct.POINTER(dns_csr), ct.c_int32, ct.c_int32,
                                   ct.c_int32, ct.c_int32, c_int32_p,
                                   ct.c_int32, c_int32_p, c_int32_p,

@@ -214,6 +214,21 @@ class Comm(object):
         return dict(allreduce=buf[0], allgatherv=buf[1], halo_exchange=buf[2],
                     halo_bytes=buf[3], allgather_bytes=buf[4])
 
+    def set_timing(self, on=True):
+        """event pairs around every collective issued as a plain launch
+        (`dns_comm_set_timing`); switching on resets the sums"""
+        C.check(self.lib.dns_comm_set_timing(self._h, int(bool(on))))
+
+    def timing(self):
+        """device milliseconds and timed calls per kind of collective since
+        `set_timing(True)` (the wait for the slowest peer included)"""
+        ms, calls = (ct.c_double*3)(), (ct.c_int64*3)()
+        C.check(self.lib.dns_comm_timing(self._h, ms, calls))
+        names = ('allreduce', 'allgatherv', 'halo_exchange')
+        return {k: dict(device_ms=ms[i], calls=calls[i],
+                        us_per_call=(1e3*ms[i]/calls[i] if calls[i] else None))
+                for i, k in enumerate(names)}
+
     def close(self):
         if self._h:
             self.lib.dns_comm_destroy(self._h)

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "halo_host.hpp"
 
 struct dns_comm {
     int rank = 0, nranks = 1, device = 0;
@@ -27,12 +28,82 @@ struct dns_comm {
     int64_t n_allreduce = 0, n_allgather = 0, n_alltoall = 0;
     int64_t bytes_alltoall = 0, bytes_allgather = 0;   // sent by this rank
 
+    // Device time per collective (dns_comm_set_timing): an event pair on the
+    // launch stream around every call that is issued as a plain launch (a
+    // call inside a stream capture is left alone: captured events carry no
+    // time).  What lies between the two events is the collective as the
+    // stream sees it -- the wait for the slowest peer included.
+    enum { kAllreduce = 0, kAllgather = 1, kHalo = 2, kKinds = 3 };
+    struct TimedCall {
+        hipEvent_t a, b;
+        int kind;
+    };
+    bool timing = false;
+    std::vector<TimedCall> timed;      // pool, grows up to kMaxTimed pairs
+    size_t timed_used = 0;
+    double timed_ms[kKinds] = {0.0, 0.0, 0.0};
+    int64_t timed_calls[kKinds] = {0, 0, 0};
+    static constexpr size_t kMaxTimed = 4096;
+
+    // sums the recorded pairs into timed_ms / timed_calls (waits for them)
+    int timing_collect() {
+        for (size_t i = 0; i < timed_used; ++i) {
+            float ms = 0.f;
+            DNS_HIP(hipEventSynchronize(timed[i].b));
+            DNS_HIP(hipEventElapsedTime(&ms, timed[i].a, timed[i].b));
+            timed_ms[timed[i].kind] += (double)ms;
+            timed_calls[timed[i].kind]++;
+        }
+        timed_used = 0;
+        return DNS_OK;
+    }
+    // index of the pair whose first event has been recorded, -1: not timed
+    int timing_begin(int kind, hipStream_t s) {
+        if (!timing) return -1;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess ||
+            cs != hipStreamCaptureStatusNone)
+            return -1;
+        if (timed_used == timed.size()) {
+            if (timed.size() >= kMaxTimed) {
+                if (timing_collect() != DNS_OK) return -1;
+            } else {
+                TimedCall t;
+                t.kind = kind;
+                if (hipEventCreate(&t.a) != hipSuccess) return -1;
+                if (hipEventCreate(&t.b) != hipSuccess) {
+                    (void)hipEventDestroy(t.a);
+                    return -1;
+                }
+                timed.push_back(t);
+            }
+        }
+        TimedCall &t = timed[timed_used];
+        t.kind = kind;
+        if (hipEventRecord(t.a, s) != hipSuccess) return -1;
+        return (int)timed_used++;
+    }
+    void timing_end(int idx, hipStream_t s) {
+        if (idx >= 0) (void)hipEventRecord(timed[(size_t)idx].b, s);
+    }
+    // (a pair whose call failed still gets its second event: collect() must
+    // not wait for an event that was never recorded)
+    struct Timed {
+        dns_comm *c;
+        int idx;
+        hipStream_t s;
+        Timed(dns_comm *c_, int kind, hipStream_t s_)
+            : c(c_), idx(c_->timing_begin(kind, s_)), s(s_) {}
+        ~Timed() { c->timing_end(idx, s); }
+    };
+
     // sendbuf/recvbuf: device; counts/displs in doubles, one entry per rank
     int alltoallv(const double *sendbuf, const std::vector<int> &scounts,
                   const std::vector<int> &sdispls, double *recvbuf,
                   const std::vector<int> &rcounts,
                   const std::vector<int> &rdispls, hipStream_t s) {
         n_alltoall++;
+        Timed timed_call(this, kHalo, s);
         for (int q = 0; q < nranks; ++q)
             if (q != rank) bytes_alltoall += 8 * (int64_t)scounts[q];
         if (nccl) {
@@ -62,11 +133,16 @@ struct dns_comm {
     }
 
     ~dns_comm() {
+        for (TimedCall &t : timed) {
+            (void)hipEventDestroy(t.a);
+            (void)hipEventDestroy(t.b);
+        }
         if (nccl) (void)ncclCommDestroy(nccl);
     }
 
     int allreduce(double *dev, int count, hipStream_t s) {
         n_allreduce++;
+        Timed timed_call(this, kAllreduce, s);
         if (nccl) {
             ncclResult_t r = ncclAllReduce(dev, dev, (size_t)count, ncclDouble,
                                            ncclSum, nccl, s);
@@ -85,6 +161,7 @@ struct dns_comm {
     int allgatherv(double *dev, const std::vector<int> &starts, hipStream_t s) {
         n_allgather++;
         bytes_allgather += 8 * (int64_t)(starts[rank + 1] - starts[rank]);
+        Timed timed_call(this, kAllgather, s);
         if (nccl) {
             ncclResult_t r = ncclGroupStart();
             for (int q = 0; q < nranks && r == ncclSuccess; ++q) {
@@ -108,17 +185,3 @@ struct dns_comm {
     }
 };
 
-namespace dns {
-
-// contiguous block partition of `n` rows over `nranks`: starts[r] .. starts[r+1]
-inline std::vector<int> partition_starts(int n, int nranks) {
-    std::vector<int> st((size_t)nranks + 1);
-    // (even chunks: the two velocity dofs of a node stay on one rank -- the
-    // pair format of a rank's row block needs that)
-    const int chunk = ((n + nranks - 1) / nranks + 1) & ~1;
-    for (int r = 0; r <= nranks; ++r)
-        st[r] = (int)std::min<int64_t>((int64_t)n, (int64_t)r * chunk);
-    return st;
-}
-
-}  // namespace dns

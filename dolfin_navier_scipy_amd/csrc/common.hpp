@@ -80,7 +80,21 @@ struct DevBuf {
         n = count;
         return DNS_OK;
     }
+    // Host -> device, SAFE BY CONSTRUCTION: when the call returns the copy
+    // has left `host`, whose lifetime is therefore nobody's concern (a local
+    // std::vector, a caller's borrowed array).  An asynchronous copy out of
+    // pageable memory that is freed -- and possibly unmapped -- before the
+    // DMA engine gets to it is a GPU memory fault (round 3: intermittent
+    // aborts of the test session).  Ordered on `s` like any other work.
     int upload(const T *host, size_t count, hipStream_t s) {
+        DNS_TRY(upload_async(host, count, s));
+        if (count > 0) DNS_HIP(hipStreamSynchronize(s));
+        return DNS_OK;
+    }
+    // ... and the variant that only enqueues: the CALLER guarantees that
+    // `host` stays valid and unmodified until it has synchronised `s` on
+    // EVERY path out of its scope (error returns included -- `SyncOnExit`)
+    int upload_async(const T *host, size_t count, hipStream_t s) {
         if (count > n) return fail(DNS_ERR_BAD_ARGUMENT, "upload overflow");
         if (count == 0) return DNS_OK;
         DNS_HIP(hipMemcpyAsync(p, host, count * sizeof(T),
@@ -98,6 +112,27 @@ struct DevBuf {
         DNS_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
         return DNS_OK;
     }
+};
+
+// host -> device into the middle of a buffer, with the guarantee of
+// DevBuf::upload: the copy has left `host` when the call returns
+template <typename T>
+inline int upload_to(T *dev, const T *host, size_t count, hipStream_t s) {
+    if (count == 0) return DNS_OK;
+    DNS_HIP(hipMemcpyAsync(dev, host, count * sizeof(T), hipMemcpyHostToDevice,
+                           s));
+    DNS_HIP(hipStreamSynchronize(s));
+    return DNS_OK;
+}
+
+// synchronises the stream when the scope is left, whichever way: what makes a
+// group of `upload_async` calls from buffers of that scope safe
+struct SyncOnExit {
+    hipStream_t s;
+    explicit SyncOnExit(hipStream_t s_) : s(s_) {}
+    SyncOnExit(const SyncOnExit &) = delete;
+    SyncOnExit &operator=(const SyncOnExit &) = delete;
+    ~SyncOnExit() { (void)hipStreamSynchronize(s); }
 };
 
 // CSR matrix resident in HBM

@@ -1289,7 +1289,26 @@ int dns_saddle::run_cached(const std::vector<uint64_t> &key, bool use_graph,
     DNS_HIP(hipStreamBeginCapture(stream, dist() ? hipStreamCaptureModeRelaxed
                                                  : hipStreamCaptureModeThreadLocal));
     capturing = true;
-    const int rc = body();
+    int rc;
+    try {
+        rc = body();
+    } catch (...) {
+        // a host-side exception (std::bad_alloc in a builder, ...) must not
+        // leave the stream capturing: every later body() would then be
+        // recorded into a graph nobody launches
+        capturing = false;
+        hipGraph_t partial = nullptr;
+        (void)hipStreamEndCapture(stream, &partial);
+        if (partial) (void)hipGraphDestroy(partial);
+        if (comm) {
+            comm->n_allreduce = c0[0];
+            comm->n_allgather = c0[1];
+            comm->n_alltoall = c0[2];
+            comm->bytes_alltoall = c0[3];
+            comm->bytes_allgather = c0[4];
+        }
+        throw;                     // the C-ABI barrier reports DNS_ERR_HOST
+    }
     capturing = false;
     hipError_t e = hipStreamEndCapture(stream, &ge.graph);
     if (comm) {
@@ -2052,9 +2071,8 @@ static int dns_saddle_solve_impl(dns_saddle *h, const double *rhs_v, const doubl
     DNS_HIP(hipSetDevice(h->device));
     DNS_TRY(h->bdev.upload(rhs_v, (size_t)h->nv, h->stream));
     if (rhs_p) {
-        DNS_HIP(hipMemcpyAsync(h->bdev.p + h->nv, rhs_p,
-                               (size_t)h->np * sizeof(double),
-                               hipMemcpyHostToDevice, h->stream));
+        DNS_TRY(upload_to(h->bdev.p + h->nv, rhs_p, (size_t)h->np,
+                          h->stream));
     } else {
         DNS_HIP(hipMemsetAsync(h->bdev.p + h->nv, 0,
                                (size_t)h->np * sizeof(double), h->stream));

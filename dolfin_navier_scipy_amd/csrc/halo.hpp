@@ -2,11 +2,13 @@
 // partitioned right-hand side of the resident time steppers, imex_capi.inc).
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <iterator>
 #include <vector>
 
 #include "comm.hpp"
 #include "common.hpp"
+#include "halo_host.hpp"
 #include "hostcsr.hpp"
 #include "kernels.hpp"
 
@@ -26,25 +28,6 @@ k_halo_unpack(int count, const int *__restrict__ idx,
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < count;
          i += gridDim.x * kBlock)
         vec[idx[i]] = buf[i];
-}
-
-// sorted distinct columns < ncols_part that the rows [row0, row1) of `a`
-// reference in every rank's column range (need[q]); own range left empty
-inline void halo_need(const dns_csr *a, int row0, int row1, int nranks,
-                      int rank, const int *col_starts, int ncols_part,
-                      std::vector<std::vector<int>> &need) {
-    need.assign((size_t)nranks, std::vector<int>());
-    std::vector<unsigned char> mark((size_t)std::max(1, ncols_part), 0);
-    for (int r = row0; r < row1; ++r)
-        for (int k = a->rowptr[r]; k < a->rowptr[r + 1]; ++k) {
-            const int c = a->colidx[k];
-            if (c < ncols_part) mark[c] = 1;
-        }
-    for (int q = 0; q < nranks; ++q) {
-        if (q == rank) continue;
-        for (int c = col_starts[q]; c < col_starts[q + 1]; ++c)
-            if (mark[c]) need[q].push_back(c);
-    }
 }
 
 }  // namespace dns
@@ -81,6 +64,16 @@ struct dns_halo_plan {
         }
         nsend = (int)si.size();
         nrecv = (int)ri.size();
+        // TEST HOOK (tests/test_gpu_zz_dist.py, bench.py's parity leg): a send
+        // list whose first entry is wrong -- the peer then reads a neighbour's
+        // value where it expects its halo entry.  A partitioned run has to
+        // notice (parity against the un-partitioned run), not merely converge.
+        if (const char *bad = getenv("DNS_TEST_CORRUPT_HALO"))
+            if (bad[0] != '0' && nsend >= 2) {
+                si[0] = si[1];
+                fprintf(stderr, "[dns] TEST HOOK: halo send list of rank %d "
+                        "corrupted on purpose\n", rank);
+            }
         DNS_TRY(sidx.alloc((size_t)std::max(1, nsend)));
         DNS_TRY(ridx.alloc((size_t)std::max(1, nrecv)));
         DNS_TRY(sbuf.alloc((size_t)std::max(1, nsend)));
@@ -106,16 +99,4 @@ struct dns_halo_plan {
     }
 };
 
-// rows [r0, r1) of a host CSR matrix as a CSR of its own (rebased row pointers)
-inline dns::HostCsr host_row_slice(const dns::HostCsr &A, int r0, int r1) {
-    dns::HostCsr S;
-    S.nrows = r1 - r0;
-    S.ncols = A.ncols;
-    S.rowptr.resize((size_t)S.nrows + 1);
-    const int k0 = A.rowptr[r0];
-    for (int i = 0; i <= S.nrows; ++i) S.rowptr[i] = A.rowptr[r0 + i] - k0;
-    S.colidx.assign(A.colidx.begin() + k0, A.colidx.begin() + A.rowptr[r1]);
-    S.vals.assign(A.vals.begin() + k0, A.vals.begin() + A.rowptr[r1]);
-    return S;
-}
 

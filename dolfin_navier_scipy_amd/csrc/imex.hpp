@@ -106,6 +106,9 @@ struct dns_imex {
     bool tab_v = false, tab_p = false;
     int tab_pos = 0;               // host copy of the counter
     bool preparing = false;        // prepare_graphs is capturing (no launch)
+    // the last prepare_graphs call went past its "already prepared" exit, i.e.
+    // it captured (or tried to): the same on every rank of a partitioned run
+    bool prepare_attempted = false;
     // a step counter is needed as soon as anything is tabulated
     bool tables() const {
         return tab_rows > 0 || (conv && conv->dbc_rows > 0);

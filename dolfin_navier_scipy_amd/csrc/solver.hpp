@@ -52,9 +52,13 @@ inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
     DNS_TRY(vals.alloc((size_t)nnz + 2));
     DNS_HIP(hipMemsetAsync(colidx.p + nnz, 0, 2 * sizeof(int), s));
     DNS_HIP(hipMemsetAsync(vals.p + nnz, 0, 2 * sizeof(double), s));
-    DNS_TRY(rowptr.upload(a->rowptr, (size_t)nrows + 1, s));
-    DNS_TRY(colidx.upload(a->colidx, (size_t)nnz, s));
-    DNS_TRY(vals.upload(a->vals, (size_t)nnz, s));
+    {
+        // the caller's arrays outlive this call: one wait for the three
+        SyncOnExit arrived(s);
+        DNS_TRY(rowptr.upload_async(a->rowptr, (size_t)nrows + 1, s));
+        DNS_TRY(colidx.upload_async(a->colidx, (size_t)nnz, s));
+        DNS_TRY(vals.upload_async(a->vals, (size_t)nnz, s));
+    }
     // row blocks of the LDS-streaming kernel: consecutive rows with at most
     // TILE non-zeros and at most kBlock rows; a longer row stands alone
     // (tables for the three tile sizes the tuning variants use)
@@ -129,11 +133,7 @@ inline int CsrDev::upload(const dns_csr *a, hipStream_t s) {
             DNS_TRY(c16.upload(cc.data(), cc.size(), s));
             DNS_TRY(c16base.upload(bases.data(), bases.size(), s));
             DNS_TRY(meta16.upload(mt.data(), mt.size(), s));
-            // `cc`, `bases` die with this block: an asynchronous copy out of a
-            // freed (and possibly unmapped) host buffer is a GPU memory fault
-            DNS_HIP(hipStreamSynchronize(s));
         }
-        DNS_HIP(hipStreamSynchronize(s));       // `rb` is a loop temporary
     }
     return DNS_OK;
 }
@@ -429,6 +429,9 @@ struct dns_saddle {
     // goes false when a capture with collectives failed once (DNS_DIST_GRAPH=0
     // starts that way): plain launches from then on.
     bool dist_graph_ok = true;
+    // logical OR of a flag over the ranks of the communicator (one all-reduce
+    // of one scalar, synchronises the stream; never inside a capture)
+    int all_ranks_any(bool mine, bool *any);
     bool graph_capable() const {
         return !dist() || (comm->nccl != nullptr && dist_graph_ok);
     }

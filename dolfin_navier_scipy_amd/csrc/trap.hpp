@@ -129,4 +129,13 @@ struct dns_trap {
                   dns_solve_stats *stats, const Feedback *fb);
     // N_c, f_c at the current velocity
     int assemble_current(int newton);
+    // checkpoint of the ring (a pipelined batch that did not converge within
+    // its cycle length is repeated from here): the three solutions behind
+    // `cur`, the host's bookkeeping; N_c / f_c are re-assembled on restore
+    dns::DevBuf<double> ck[3];
+    struct {
+        bool valid = false;
+        int nsol = 0, cur_slot = 0;
+        double last_dt = 0.0, updnorm = 0.0;
+    } ckh;
 };

@@ -27,17 +27,71 @@ from .saddle import SaddleSystem, solve_opts
 __all__ = ['solve_sadpnt_smw', 'app_prj_via_sadpnt', 'apply_massinv',
            'SpslaKrylovCounter', 'clear_cache', 'DEFAULTS']
 
-DEFAULTS = dict(direct_tol=1e-13, maxiter=3000, restart=60, cheb_degree=6,
+# `direct_tol`: relative residual (w.r.t. ||rhs||) that stands in for the
+# reference's direct solve.  1e-12 in general; `direct_tol_penalised` (1e-13)
+# for systems with penalised rows -- a Robin penalty of 1/alpha = 1e5 on the
+# boundary rows (BASELINE config 5) inflates ||rhs||, and the un-penalised part
+# of the solution then needs the extra digit (p: 1.0e-8 -> 1.7e-10 against the
+# direct solve, tests/test_gpu_config5.py).  Kept apart because 1e-13 is within
+# ~1e3 eps: on worse conditioned systems the true residual stagnates above it
+# and every solve would run to `maxiter`.
+DEFAULTS = dict(direct_tol=1e-12, direct_tol_penalised=1e-13,
+                penalty_ratio=1e3, maxiter=3000, restart=60, cheb_degree=6,
                 factorization='full', schur='auto', schur_dense_max=6000,
-                refresh_tol=0.1, device=0, cache_size=4)
+                refresh_tol=0.1, refresh_iter_factor=2.0, refresh_iter_slack=4,
+                device=0, cache_size=4)
 
 _cache = {}          # pattern key -> _Entry
 _cache_order = []
 
 
 class _Entry(object):
-    def __init__(self, system, diag, pkw):
-        self.system, self.diag, self.pkw = system, diag, pkw
+    """a resident system, the values of `amat` its preconditioner was set up
+    for, and the Krylov steps of the solves since (`base`: the first solve
+    behind the set-up, `last`: the latest one)"""
+
+    def __init__(self, system, data, pkw):
+        self.system, self.data, self.pkw = system, data, pkw
+        self.base = self.last = None
+
+    def note(self, iters):
+        if self.base is None:
+            self.base = iters
+        self.last = iters
+
+    def stale(self, data, pkw):
+        """REFRESH POLICY of the boundary (the reference factorises whatever
+        it is handed, every call): set up again when (i) the settings changed,
+        (ii) any VALUE of the velocity block moved by more than `refresh_tol`
+        of the largest one (the diagonal alone misses a convection term that
+        turns), or (iii) the last solve needed more than `refresh_iter_factor`
+        x the Krylov steps of the first solve behind the set-up (+ slack)"""
+        if pkw != self.pkw:
+            return True
+        moved = np.abs(data - self.data).max()/max(np.abs(self.data).max(),
+                                                   1e-300)
+        if moved > DEFAULTS['refresh_tol']:
+            return True
+        return (self.base is not None and self.last >
+                DEFAULTS['refresh_iter_factor']*self.base
+                + DEFAULTS['refresh_iter_slack'])
+
+
+_warned_keywords = set()
+
+
+def warn_ignored(func, kw):
+    """keywords of the reference this path has no use for (file-name prefixes,
+    paraview output, ...) are accepted -- a caller written for the reference
+    must not break -- but never silently: one `UserWarning` per keyword"""
+    import warnings
+    for name in sorted(kw):
+        if (func, name) in _warned_keywords:
+            continue
+        _warned_keywords.add((func, name))
+        warnings.warn('{0}: keyword `{1}` has no effect on the MI355X path '
+                      '(accepted for compatibility with the reference)'.format(
+                          func, name), UserWarning, stacklevel=3)
 
 
 def clear_cache():
@@ -94,22 +148,22 @@ def _precond_kwargs(NP, krplsprms, NV=0):
 def _get_system(amat, jmat, jmatT, krplsprms):
     """the HBM-resident system for this sparsity pattern; same pattern with new
     values (Newton/Picard re-linearisation, snu:1484-1491) only re-uploads the
-    values and keeps the preconditioner unless the diagonal moved by more
-    than `refresh_tol`"""
+    values and keeps the preconditioner until `_Entry.stale` says otherwise"""
     amat, jmat = _canonical(amat), _canonical(jmat)
     prols = (krplsprms or {}).get('prolongations')
     key = _pattern_key(amat, jmat, jmatT, prols)
     pkw = _precond_kwargs(jmat.shape[0], krplsprms, NV=jmat.shape[1])
     if prols is not None:           # nested pressure spaces: multigrid Schur
         pkw['schur'] = 'mg'
-    diag = amat.diagonal()
+    data = np.array(amat.data, dtype=np.float64, copy=True)
     ent = _cache.get(key)
     if ent is None:
         system = SaddleSystem(amat, jmat, JT=jmatT, device=DEFAULTS['device'])
         if prols is not None:
             system.set_schur_mg(prols)
         system.setup_precond(**pkw)
-        ent = _Entry(system, diag, pkw)
+        ent = _Entry(system, data, pkw)
+        system._lau_entry = ent
         _cache[key] = ent
         _cache_order.append(key)
         while len(_cache_order) > DEFAULTS['cache_size']:
@@ -117,18 +171,29 @@ def _get_system(amat, jmat, jmatT, krplsprms):
             _cache.pop(old).system.close()
     else:
         ent.system.update_values(amat.data)
-        moved = np.abs(diag - ent.diag).max() / max(np.abs(ent.diag).max(),
-                                                    1e-300)
-        if moved > DEFAULTS['refresh_tol'] or pkw != ent.pkw:
+        if ent.stale(data, pkw):
             ent.system.setup_precond(**pkw)
-            ent.diag, ent.pkw = diag, pkw
+            ent.data, ent.pkw = data, pkw
+            ent.base = ent.last = None
     return ent.system
 
 
-def _solver_opts(krylov, krpslvprms):
+def default_rtol(amat):
+    """the tolerance that stands in for a direct solve of a system with the
+    velocity block `amat`: `direct_tol`, or `direct_tol_penalised` when some
+    diagonal entries tower over the typical one (penalised boundary rows)"""
+    diag = np.abs(sps.csr_matrix(amat).diagonal())
+    diag = diag[diag > 0]
+    if diag.size and diag.max() > DEFAULTS['penalty_ratio']*np.median(diag):
+        return DEFAULTS['direct_tol_penalised']
+    return DEFAULTS['direct_tol']
+
+
+def _solver_opts(krylov, krpslvprms, amat=None):
     prm = krpslvprms if isinstance(krpslvprms, dict) else {}
     if krylov is None:
-        method, tol = 'gmres', DEFAULTS['direct_tol']
+        method = 'gmres'
+        tol = DEFAULTS['direct_tol'] if amat is None else default_rtol(amat)
     else:
         kname = str(krylov).lower()
         if kname in ('gmres', 'bicgstab'):
@@ -173,6 +238,7 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
     """
     if jmat is None or rhsv is None:
         raise ValueError('`jmat` and `rhsv` are required')
+    warn_ignored('solve_sadpnt_smw', kw)
     if amat is None:
         if not (decouplevp and callable(solve_A)):
             raise ValueError('without `amat` the decoupled variant needs '
@@ -184,7 +250,7 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
     rhsp = np.zeros((NP, ncols)) if rhsp is None else \
         np.asarray(rhsp, dtype=np.float64).reshape((NP, -1))
     system = _get_system(amat, jmat, jmatT, krplsprms)
-    opts = _solver_opts(krylov, krpslvprms)
+    opts = _solver_opts(krylov, krpslvprms, amat)
     prm = krpslvprms if isinstance(krpslvprms, dict) else {}
     x0 = prm.get('x0', None)
 
@@ -195,6 +261,7 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
         for k in range(rv.shape[1]):
             xk = None if x0c is None else x0c[:, min(k, x0c.shape[1]-1)]
             out[:, k] = system.solve(rv[:, k], rp[:, k], x0=xk, opts=opts)
+            system._lau_entry.note(system.last_stats['iters'])
             if 'convstatsl' in prm:
                 prm['convstatsl'].append(system.residual_history().tolist())
         return out
@@ -275,6 +342,7 @@ def app_prj_via_sadpnt(amat=None, jmat=None, rhsv=None, jmatT=None,
                        umat=None, vmat=None, transposedprj=False, **kw):
     """apply `Pi = I - A^-1 J^T S^-1 J` (or `Pi^T`) through a saddle solve
     (reference `residual_checks.py:21-35`, `time_int_utils.py:422-425`)"""
+    warn_ignored('app_prj_via_sadpnt', kw)
     NP, NV = jmat.shape
     rhsv = np.asarray(rhsv, dtype=np.float64).reshape((NV, -1))
     jT = sps.csr_matrix(jmat.T) if jmatT is None else jmatT

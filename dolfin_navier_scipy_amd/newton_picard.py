@@ -68,7 +68,8 @@ class TrapezoidalStepper(object):
     step sizes still converge, with more iterations)"""
 
     def __init__(self, M, A, J, conv, nslots, dt, device=0, precond=None,
-                 JT=None, comm=None, precond_linpoint=None):
+                 JT=None, comm=None, precond_linpoint=None, refresh_iters=3.0,
+                 batch=64):
         """`comm` (a `comm.Comm`): the saddle solves of the sweeps run
         row-partitioned over its ranks; the assembly of
         `N(v_lin)`, `F` and the right-hand side is replicated on every rank,
@@ -77,8 +78,15 @@ class TrapezoidalStepper(object):
         ONCE, the system matrix is re-valued every step -- is built for
         `M + dt/2 (A + N1(v))` at this velocity instead of `M + dt/2 A`: the
         Oseen term of a representative state is then inside the polynomial
-        and the Schur block (fewer Krylov steps per time step)"""
+        and the Schur block (fewer Krylov steps per time step).
+        `refresh_iters`: bound on the Krylov steps per time step of a batch of
+        `batch` steps beyond which `sweep` rebuilds the preconditioner about
+        the current operator (`None` / 0: never, the set-up of the start is
+        kept)"""
         self.lib = C.load_library()
+        self.refresh_iters = refresh_iters
+        self.batch = int(batch)
+        self.refreshes = 0
         self.conv = conv
         self.M, self.A, self.J = (sps.csr_matrix(M), sps.csr_matrix(A),
                                   sps.csr_matrix(J))
@@ -105,6 +113,7 @@ class TrapezoidalStepper(object):
         pkw.update(precond or {})
         if pkw['schur'] == 'auto':
             pkw['schur'] = 'dense' if self.NP <= 6000 else 'jacobi'
+        self._pkw = dict(pkw)
         self.system.setup_precond(**pkw)
         conv.bind_pattern(self.pattern)
         self.nslots = int(nslots)
@@ -253,12 +262,38 @@ class TrapezoidalStepper(object):
         C.check(self.lib.dns_trap_update_norm(self._h, ct.byref(out)))
         return out.value
 
+    def checkpoint(self):
+        C.check(self.lib.dns_trap_checkpoint(self._h))
+
+    def restore(self, newton):
+        C.check(self.lib.dns_trap_restore(self._h, int(bool(newton))))
+
+    def refresh_precond(self):
+        """set the preconditioner up again for the system matrix as it stands
+        on the device -- `M + dt/2 (A + N(v_lin))` of the step that ran last.
+        The reference factorises the current operator in every step
+        (snu:1484-1512) and therefore never solves with a stale one; here the
+        polynomial and the Schur block are rebuilt when the policy of `sweep`
+        asks for it (0.07 s at N=2, the price of a few hundred time steps)"""
+        self.system.setup_precond(**self._pkw)
+        self.refreshes += 1
+
     def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=2,
-              record=True, pipeline=True):
+              record=True, pipeline=True, batch=None):
         """one sweep over `trange` linearised about trajectory `lin_which`
         (slot k <-> trange[k]); the new velocities go to the other trajectory.
         Returns `(vdict, pdict, norm_nwtnupd, stats)` (dicts empty unless
-        `record`)"""
+        `record`).
+
+        Uniform time grids run PIPELINED in batches of `batch` steps
+        (`self.batch`, 64): nobody waits for a step, the device counts Krylov
+        steps and failures, the host looks once per batch.  A batch in which a
+        step did not converge within the agreed cycle length is repeated from
+        its checkpoint with synchronous steps.  REFRESH POLICY
+        (`refresh_iters`, constructor): when the Krylov steps per time step of
+        a batch exceed the bound, the preconditioner is rebuilt about the
+        current operator before the next batch -- the system matrix follows
+        the flow every step, the preconditioner follows it when it pays."""
         trange = np.asarray(trange, dtype=np.float64)
         if trange.size > self.nslots:
             raise ValueError('trajectory buffers hold {0} slots'.format(
@@ -267,35 +302,69 @@ class TrapezoidalStepper(object):
         steps = np.diff(trange)
         uniform = steps.size > 3 and \
             np.abs(steps - steps[0]).max() <= 1e-12*abs(steps[0])
-        for attempt in ('pipelined', 'synchronous'):
-            self.start(iniv, newton)
-            self.write_linpoint(1 - lin_which, 0, iniv)
-            vdict, pdict = {}, {}
+        batch = self.batch if batch is None else int(batch)
+        nt = trange.size
+        self.start(iniv, newton)
+        self.write_linpoint(1 - lin_which, 0, iniv)
+        vdict, pdict = {}, {}
+        if record:
+            vdict[trange[0]] = np.asarray(iniv, dtype=float).reshape((-1, 1))
+        tot = dict(iters=0, device_seconds=0., refreshes=0, replayed_batches=0,
+                   batches=[])
+
+        def one(k):
+            st = self.step(trange[k] - trange[k-1], lin_which, k, k, newton,
+                           opts=opts, extrapolate=extrapolate)
             if record:
-                vdict[trange[0]] = np.asarray(iniv,
-                                              dtype=float).reshape((-1, 1))
-            iters, secs, ok = 0, 0., True
-            pipelined = pipeline and uniform and attempt == 'pipelined'
-            for k in range(1, trange.size):
-                if pipelined and k == 3:
-                    # cycle length: what the first steps needed + one slack
-                    self.set_pipeline(max(2, self.last_stats['iters'] + 1))
-                st = self.step(trange[k] - trange[k-1], lin_which, k, k,
-                               newton, opts=opts, extrapolate=extrapolate)
-                if not (pipelined and k >= 3):
-                    iters += st['iters']
-                    secs += st['device_seconds']
-                if record:
-                    vdict[trange[k]], pdict[trange[k]] = self.state()
-            if pipelined and trange.size > 3:
+                vdict[trange[k]], pdict[trange[k]] = self.state()
+            return st
+
+        def sync_steps(k0, k1):
+            its, worst = 0, 0
+            for k in range(k0, k1):
+                st = one(k)
+                its += st['iters']
+                worst = max(worst, st['iters'])
+                tot['device_seconds'] += st['device_seconds']
+            return its, worst
+
+        def policy(per_step, k):
+            bound = self.refresh_iters
+            tot['batches'].append(per_step)
+            if bound and per_step > bound and k < nt:
+                self.refresh_precond()
+                tot['refreshes'] += 1
+
+        pipelined = pipeline and uniform
+        k = min(nt, 3) if pipelined else 1
+        if pipelined:
+            its, worst = sync_steps(1, k)
+            tot['iters'] += its
+            cycle = max(2, worst + 1)
+        while k < nt:
+            kend = min(nt, k + batch)
+            if not pipelined:
+                its, _ = sync_steps(k, kend)
+            else:
+                self.checkpoint()
+                self.set_pipeline(cycle)
+                for kk in range(k, kend):
+                    one(kk)
                 acc = self.poll()
                 self.set_pipeline(0)
-                iters += acc['iters']
-                ok = acc['fails'] == 0
-            if ok:
-                break
-        return vdict, pdict, self.update_norm(), dict(iters=iters,
-                                                      device_seconds=secs)
+                if acc['fails'] == 0:
+                    its, cycle = acc['iters'], max(2, acc['maxit'] + 1)
+                else:
+                    # a step of this batch was not through after `cycle` Krylov
+                    # steps: the batch again, every step run to convergence
+                    self.restore(newton)
+                    its, worst = sync_steps(k, kend)
+                    cycle = max(2, worst + 1)
+                    tot['replayed_batches'] += 1
+            tot['iters'] += its
+            policy(its/float(kend - k), kend)
+            k = kend
+        return vdict, pdict, self.update_norm(), tot
 
 
 def time_sections(trange, nsects=1, addfullsweep=False):

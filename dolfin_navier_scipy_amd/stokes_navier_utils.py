@@ -39,6 +39,9 @@ __all__ = ['solve_nse', 'solve_steadystate_nse', 'get_v_conv_conts',
 _conv_cache = {}
 
 
+_warn_ignored = lau.warn_ignored
+
+
 def clear_cache():
     for cv in _conv_cache.values():
         cv.close()
@@ -67,36 +70,42 @@ def _unroll(bcinds, bcvals):
 
 
 def _localizecdbinds(cdbinds, V, invinds):
-    """positions of (full-space) indices in the vector of inner indices
-    (snu:146-161)"""
+    """where the full-space dof numbers `cdbinds` sit inside the vector of
+    inner dofs -- the matrices at hand have lost the constant Dirichlet dofs
+    already, the controlled ones are still numbered with respect to `V`
+    (snu:146-161).  `invinds` is ascending, so a position is a binary search;
+    without a space the reference indexes `invinds` by itself, kept as it is."""
+    inner = np.asarray(invinds)
     if V is None:
-        allinds = np.array(invinds)
-    else:
-        allinds = np.arange(V.vdim)
-    redcdallinds = allinds[invinds]
-    return np.searchsorted(redcdallinds, cdbinds, side='left')
+        inner = inner[inner]
+    return np.searchsorted(inner, np.asarray(cdbinds), side='left')
+
+
+def _ask_control(func, time, vel, p, mode, memory):
+    """`(value, new memory)` of one control function; `mode=` is only passed
+    to functions that take it (the reference's protocol, snu:170-177)"""
+    try:
+        return func(time, vel=vel, p=p, mode=mode, memory=memory)
+    except TypeError:
+        return func(time, vel=vel, p=p, memory=memory)
 
 
 def _comp_cntrl_bcvals(diricontbcvals=[], diricontfuncs=[], mode=None,
                        diricontfuncmems=[], time=None, vel=None, p=None, **kw):
-    """current values of the controlled Dirichlet dofs: control function value
-    times shape values (snu:164-183)"""
-    cntrlldbcvals = []
+    """values of the controlled Dirichlet dofs at `time`: per controlled
+    boundary the scalar its control function returns times the boundary's shape
+    values; the functions' memories are updated in place (snu:164-183).  Lists
+    left at `None` mean "no controls": like the reference, a `TypeError` ends
+    the walk and what has been collected so far is returned."""
+    out = []
     try:
-        for k, cdbbcv in enumerate(diricontbcvals):
-            ccntrlfunc = diricontfuncs[k]
-            try:
-                cntrlval, diricontfuncmems[k] = \
-                    ccntrlfunc(time, vel=vel, p=p, mode=mode,
-                               memory=diricontfuncmems[k])
-            except TypeError:
-                cntrlval, diricontfuncmems[k] = \
-                    ccntrlfunc(time, vel=vel, p=p,
-                               memory=diricontfuncmems[k])
-            cntrlldbcvals.extend([cntrlval*bcvl for bcvl in cdbbcv])
+        for k, shape in enumerate(diricontbcvals):
+            gain, diricontfuncmems[k] = _ask_control(
+                diricontfuncs[k], time, vel, p, mode, diricontfuncmems[k])
+            out.extend(gain*sv for sv in shape)
     except TypeError:
-        pass  # no controls applied
-    return cntrlldbcvals
+        pass
+    return out
 
 
 def _cntrl_stffnss_rhs(loccntbcinds=None, cntrlldbcvals=None, A=None, J=None,
@@ -239,6 +248,7 @@ def solve_steadystate_nse(A=None, J=None, JT=None, M=None, fv=None, fp=None,
     """steady Navier-Stokes by Picard + Newton iterations (snu:240-546); every
     linear system `[[A + N(v_k), J^T],[J, 0]]` is solved on the GPU through
     `lin_alg_utils.solve_sadpnt_smw` (snu:401,458,497)"""
+    _warn_ignored('solve_steadystate_nse', kw)
     dbcinds, dbcvals = _unroll(dbcinds, dbcvals)
     rs = _restrict(A, M, J, JT, fv, fp, V, invinds, dbcinds, dbcvals,
                    diricontbcinds)
@@ -361,6 +371,7 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
     if closed_loop or dynamic_feedback or static_feedback:
         raise NotImplementedError('feedback loops / observers are outside the '
                                   'MI355X path (SURVEY.md section 2)')
+    _warn_ignored('solve_nse', kw)
     if trange is None:
         trange = np.linspace(t0, tE, Nts+1)
     trange = np.asarray(trange, dtype=np.float64)

@@ -26,11 +26,12 @@ from .saddle import SaddleSystem, ImexStepper, solve_opts
 
 __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 
-# solver settings of the time loops; `rtol` is relative to ||rhs||
-# (1e-13: BASELINE config 5 adds a Robin penalty of 1/alpha = 1e5 to A, which
-# inflates ||rhs||; its pressure meets 1e-8 against the direct solve at 1e-13
-# (1.7e-10), not at 1e-12 (1e-8) -- tests/test_gpu_config5.py)
-SOLVER = dict(method='gmres', rtol=1e-13, maxiter=400, restart=60,
+# solver settings of the time loops; `rtol` is relative to ||rhs||.  `None`:
+# `lin_alg_utils.default_rtol` of the system at hand -- 1e-12, and 1e-13 where
+# penalised rows inflate ||rhs|| (BASELINE config 5: Robin penalty 1/alpha =
+# 1e5; its pressure meets 1e-8 against the direct solve at 1e-13 (1.7e-10), not
+# at 1e-12 (1e-8) -- tests/test_gpu_config5.py)
+SOLVER = dict(method='gmres', rtol=None, maxiter=400, restart=60,
               cheb_degree=6, drop_tol=1e-3, factorization='full', reorth=2,
               schur='auto', extrapolate=4, device=0, check_every=2,
               use_graph=True, carry_residual=True)
@@ -99,7 +100,8 @@ def _device_system(fmat, J, prm):
         fact = 'triangular'
     system.setup_precond(cheb_degree=prm['cheb_degree'], schur=schur,
                          drop_tol=prm['drop_tol'], factorization=fact)
-    opts = solve_opts(method=prm['method'], rtol=prm['rtol'],
+    rtol = prm['rtol'] if prm['rtol'] is not None else lau.default_rtol(fmat)
+    opts = solve_opts(method=prm['method'], rtol=rtol,
                       maxiter=prm['maxiter'], restart=prm['restart'],
                       check_every=prm['check_every'],
                       use_graph=prm['use_graph'], reorth=prm['reorth'])

@@ -231,6 +231,15 @@ int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather);
 /* calls and bytes this rank sent: out[0..4] = all-reduce calls, all-gather-v
  * calls, halo exchanges, halo bytes, all-gather bytes */
 int dns_comm_stats2(dns_comm *c, int64_t *out5);
+/* Device time per collective.  While switched on, every collective that is
+ * issued as a plain launch (not inside a captured graph) is bracketed by an
+ * event pair on the launch stream; `dns_comm_timing` waits for the pairs and
+ * returns the summed milliseconds and the number of timed calls since the
+ * switch, in the order all-reduce, all-gather-v, halo exchange (the
+ * ncclSend/Recv group alone, without its pack / unpack kernels).  The time
+ * between the events includes the wait for the slowest peer. */
+int dns_comm_set_timing(dns_comm *c, int on);
+int dns_comm_timing(dns_comm *c, double *ms3, int64_t *calls3);
 /* The halo plan of a row partition, host only (no GPU needed): for the CSR
  * pattern `a` (n rows, columns < ncols_part partitioned by `col_starts`
  * [nranks+1]; columns >= ncols_part are ignored) and the rows [row0, row1) of
@@ -534,6 +543,13 @@ int dns_trap_step_fb(dns_trap *t, double dt, int32_t lin_which,
 int dns_trap_set_pipeline(dns_trap *t, int32_t cycle_len);
 int dns_trap_poll(dns_trap *t, int32_t *solves, int32_t *fails, int32_t *iters,
                   int32_t *maxit);
+/* checkpoint / restore of the stepper's state between pipelined batches: a
+ * batch in which a step did not converge within the agreed cycle length is
+ * repeated from the checkpoint (call `dns_trap_checkpoint` behind a
+ * `dns_trap_poll`; `dns_trap_restore` leaves the pipeline switched off and
+ * re-assembles N_c / f_c at the restored velocity) */
+int dns_trap_checkpoint(dns_trap *t);
+int dns_trap_restore(dns_trap *t, int32_t newton);
 
 /* ---- resident helpers of the caller side of the path -----------------------
  * A CSR matrix kept in HBM for repeated products with host vectors: what the

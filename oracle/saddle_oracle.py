@@ -30,7 +30,7 @@ import scipy.sparse as sps
 import scipy.sparse.linalg as spsla
 
 __all__ = ['saddle_matrix', 'solve_sadpnt_smw', 'app_prj_via_sadpnt',
-           'apply_massinv', 'SaddleLU']
+           'apply_massinv', 'SaddleLU', 'RefinedSolve']
 
 
 def saddle_matrix(amat, jmat, jmatT=None):
@@ -53,6 +53,64 @@ class SaddleLU(object):
         if rhs.ndim == 1:
             return self.lu.solve(rhs)
         return self.lu.solve(rhs).reshape(rhs.shape)
+
+
+class RefinedSolve(object):
+    """`solve_sadpnt_smw` for a long SEQUENCE of nearby systems (the re-valued
+    matrices of a Newton/Picard sweep over thousands of steps, where a fresh
+    sparse LU per step -- what the direct path amounts to -- takes minutes):
+    the LU of one system of the sequence serves the following ones through
+    iterative refinement, `x += K_ref^-1 (b - K x)`, carried on until the
+    residual is at the rounding floor (`rtol`) or stops shrinking; a system
+    that needs more than `max_inner` corrections gets a factorisation of its
+    own (so the fallback IS the direct solve).  Same answer as the direct
+    solve up to rounding -- `tests/test_newton_picard.py` holds the two side
+    by side."""
+
+    def __init__(self, rtol=2e-16, max_inner=10, floor=1e-13):
+        self.rtol, self.max_inner, self.floor = rtol, max_inner, floor
+        self.lu = None
+        self.factorisations = 0
+        self.corrections = 0
+        self.calls = 0
+
+    def _factor(self, K):
+        self.lu = spsla.splu(K.tocsc())
+        self.factorisations += 1
+
+    def __call__(self, amat=None, jmat=None, jmatT=None, rhsv=None, rhsp=None,
+                 **kw):
+        NP, NV = jmat.shape
+        rhsv = np.asarray(rhsv, dtype=np.float64).reshape((NV, 1))
+        rhsp = np.zeros((NP, 1)) if rhsp is None else \
+            np.asarray(rhsp, dtype=np.float64).reshape((NP, 1))
+        K = saddle_matrix(amat, jmat, jmatT).tocsr()
+        b = np.vstack([rhsv, rhsp])[:, 0]
+        bn = np.linalg.norm(b)
+        self.calls += 1
+        for attempt in (0, 1):
+            if self.lu is None:
+                self._factor(K)
+            x = self.lu.solve(b)
+            r = b - K @ x
+            rn, it = np.linalg.norm(r), 0
+            while rn > self.rtol*bn and it < self.max_inner:
+                xn = x + self.lu.solve(r)
+                r2 = b - K @ xn
+                r2n = np.linalg.norm(r2)
+                it += 1
+                if r2n >= rn:              # no further: the rounding floor
+                    break
+                stalled = r2n > 0.5*rn and r2n <= self.floor*bn
+                x, r, rn = xn, r2, r2n
+                if stalled:
+                    break
+            self.corrections += it
+            if rn <= self.floor*bn:
+                return x.reshape((-1, 1))
+            self.lu = None                 # this system gets its own LU
+        raise RuntimeError('refined solve failed (relative residual {0:.2e})'
+                           .format(rn/bn))
 
 
 def solve_sadpnt_smw(amat=None, jmat=None, jmatT=None, rhsv=None, rhsp=None,

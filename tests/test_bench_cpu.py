@@ -133,3 +133,9 @@ def test_multi_rank_launch_plumbing_on_cpu(tmp_path):
     assert cfg['collectives'] == {'allreduce': 1}
     assert cfg['ensemble']['error'] is None
     assert 'FALLBACK' not in cfg['parallelism']
+    # the N > 1 line carries the parity record of its headline leg, and the
+    # latency-regime legs start where the N = 1 headline starts
+    assert rec['parity']['ok'] is True and rec['parity']['tol'] == 1e-8
+    assert cfg['weak_scaling']['start_state'] == 'stokes'
+    assert cfg['strong_scaling']['start_state'] == 'stokes'
+    assert cfg['weak_scaling_bandwidth']['start_state'] == 'rest'

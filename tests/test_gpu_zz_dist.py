@@ -642,3 +642,60 @@ def test_newton_picard_sweeps_on_one_rccl_rank():
     assert np.linalg.norm(p - p1) <= 1e-8*np.linalg.norm(p1)
     assert np.allclose(hist, hist1, rtol=1e-5, atol=1e-16)
     assert calls['allgatherv'] > 0 and calls['allreduce'] > 0
+
+
+def _bench_two_ranks_one_gpu(extra_env, timeout=900):
+    """`bench.py --gpus 2` as the driver launches it, both ranks on this
+    box's one GPU through the gloo-staged communicator"""
+    import json
+    import subprocess
+    from spawn_util import free_port
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'),
+           '--gpus', '2', '--steps', '20', '--warmup', '5', '--spinup', '24',
+           '--no-bandwidth', '--no-strong', '--no-ensemble',
+           '--partitioned-timeout', '400']
+    env = dict(os.environ, DNS_BENCH_REHEARSE_ONE_GPU='1',
+               GLOO_SOCKET_IFNAME='lo', **extra_env)
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=timeout)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [ln for ln in out.stdout.decode().splitlines()
+             if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    return json.loads(lines[0]), out.stderr.decode()
+
+
+def test_bench_n2_line_carries_its_parity_and_a_wrong_halo_turns_it_red():
+    """the N > 1 bench line proves itself: the gathered final state of the
+    row-partitioned run against an un-partitioned run of the same steps from
+    the same (Stokes) state on rank 0, asserted at 1e-8 -- and a halo list
+    with ONE wrong entry (`DNS_TEST_CORRUPT_HALO`) fails the leg instead of
+    producing a rate (a solver that merely converges would not notice: the
+    partitioned code computes its own `true_relres`)"""
+    rec, _ = _bench_two_ranks_one_gpu({})
+    weak = rec['config']['weak_scaling']
+    assert 'error' not in weak, weak.get('error')
+    par = rec['parity']
+    assert par == weak['parity'] and par['ok'] is True
+    assert par['v_rel_Mnorm'] <= 1e-8 and par['p_rel_l2'] <= 1e-8, par
+    assert par['steps'] == 24 + 5 + 20
+    assert 'Stokes' in weak['start_state']
+    assert 'FALLBACK' not in rec['config']['parallelism']
+    tm = weak['collectives_device_time']
+    for kind in ('allreduce', 'halo_exchange'):
+        assert tm[kind]['calls'] > 0 and tm[kind]['device_ms'] > 0.0, tm
+    print('two ranks, one GPU (gloo staged): parity', par['v_rel_Mnorm'],
+          par['p_rel_l2'], '; device us per call',
+          {k: tm[k]['us_per_call'] for k in ('allreduce', 'halo_exchange')})
+    bad, err = _bench_two_ranks_one_gpu({'DNS_TEST_CORRUPT_HALO': '1'})
+    assert 'TEST HOOK' in err
+    weak = bad['config']['weak_scaling']
+    # (either the corrupted run no longer converges, or it converges to
+    # something else: in both cases the leg is an error and the line says so)
+    assert 'error' in weak, weak
+    assert 'FALLBACK' in bad['config']['parallelism']
+    first = weak.get('first_attempt_with_graphs', weak)
+    assert 'parity' in first['error'] or 'parity' in weak['error'] \
+        or 'child' in weak['error'], weak['error']

@@ -163,3 +163,38 @@ def test_gpu_get_pfromv(setup):
     got = npo.get_pfromv(solve=lau.solve_sadpnt_smw, **args)
     assert np.linalg.norm(got - ref) <= 1e-7*np.linalg.norm(ref)
     lau.clear_cache()
+
+
+def test_refined_solve_is_the_direct_solve(setup):
+    """`saddle_oracle.RefinedSolve` (the LU of one system of a sweep serving the
+    following ones through iterative refinement; used by the long-horizon GPU
+    tests, where a fresh LU per step takes minutes): the same sweep as with
+    the direct solve, to rounding, and with fewer factorisations than steps"""
+    from oracle import saddle_oracle
+    s = setup
+    for picard in (True, False):
+        ref_v, ref_p, ref_upd = npo.trapezoidal_sweep(
+            s['trange'], s['iniv'], linpoints=s['lin0'], picard=picard,
+            **_sweep_kwargs(s))
+        rs = saddle_oracle.RefinedSolve()
+        got_v, got_p, upd = npo.trapezoidal_sweep(
+            s['trange'], s['iniv'], linpoints=s['lin0'], picard=picard,
+            solve=rs, **_sweep_kwargs(s))
+        for t in s['trange'][1:]:
+            assert np.linalg.norm(got_v[t] - ref_v[t]) <= \
+                1e-12*np.linalg.norm(ref_v[t])
+            assert np.linalg.norm(got_p[t] - ref_p[t]) <= \
+                1e-10*np.linalg.norm(ref_p[t])
+        assert abs(upd - ref_upd) <= 1e-10*abs(ref_upd) + 1e-20
+        assert rs.calls == len(s['trange']) - 1
+        assert rs.factorisations < rs.calls
+    # a system far from the factored one falls back to its own LU
+    rs = saddle_oracle.RefinedSolve(max_inner=2)
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((s['NV'], 1))
+    x1 = rs(amat=s['M'] + 0.01*s['A'], jmat=s['J'], rhsv=b)
+    x2 = rs(amat=s['M'] + 50.*s['A'], jmat=s['J'], rhsv=b)
+    ref = saddle_oracle.solve_sadpnt_smw(amat=s['M'] + 50.*s['A'], jmat=s['J'],
+                                         rhsv=b)
+    assert rs.factorisations == 2
+    assert np.linalg.norm(x2 - ref) <= 1e-11*np.linalg.norm(ref)
