@@ -551,6 +551,11 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
     if start is not None:
         v0, start_kind = np.array(start[0], dtype=np.float64).reshape((NV, 1)), \
             'handed over by the caller (the N=1 headline\'s Stokes state)'
+    elif args.start == 'stokes' and NP > args.dense_max:
+        # (the initial Stokes solve of this script runs with the dense Schur
+        # inverse: NP^2 entries)
+        v0, start_kind = np.zeros((NV, 1)), (
+            'rest (no Stokes start beyond --dense-max pressure dofs)')
     elif args.start == 'stokes':
         v0 = np.zeros((NV, 1))
         if rank == 0:
@@ -1364,6 +1369,7 @@ def main():
                 a2.level, a2.refine, a2.nts = lvl, ref, args.nts*2**ref
                 a2.steps, a2.warmup, a2.spinup = 100, 20, 256
                 a2.dense_max = 6000
+                a2.start = 'rest'        # like refined_bench.run beside it
                 try:
                     bw_base['partitioned_one_rank'] = partitioned_run(
                         a2, 1, 0, device, None, False)
