@@ -679,7 +679,7 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
 
     # ---- the proof: the same steps from the same state, un-partitioned
     parity = None
-    if rank == 0:
+    if rank == 0 and not args.no_parity:
         nsteps_cmp = (args.spinup + args.warmup + args.steps) if full \
             else PARITY_PREFIX_STEPS
         if reference is not None:
@@ -1143,6 +1143,10 @@ def main():
                     'WHOLE run is repeated un-partitioned on rank 0 for the '
                     'parity record; beyond it the first {0} steps'.format(
                         PARITY_PREFIX_STEPS))
+    ap.add_argument('--no-parity', action='store_true',
+                    help='(partitioned runs, profiling aid) no un-partitioned '
+                    'reference run: the kernel table of a profiled child is '
+                    'then the table of the partitioned path alone')
     ap.add_argument('--no-window-400', dest='window_400',
                     action='store_false',
                     help='skip the second, longer timed window '

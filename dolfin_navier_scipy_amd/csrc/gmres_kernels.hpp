@@ -880,98 +880,6 @@ k_sum_lazy4(const double *__restrict__ parta, int nparta,
     }
 }
 
-// Tail of that cycle: every workgroup forms the step length from the four
-// all-reduced sums and updates its share of x; workgroup 0 commits the solve's
-// bookkeeping -- everything k_arn_head (j = 0, first = 1) and k_arn_tail_acc
-// would have left in the control block.  A solve whose start vector is inside
-// the tolerance already takes no step.
-__global__ void __launch_bounds__(kBlock)
-k_arn_tail_lazy1(int n, const double *__restrict__ hs, DnsCtl *ctl,
-                 double *__restrict__ histbuf, int hist_cap, int maxiter,
-                 double rtol, double atol, const double *__restrict__ Z,
-                 double *__restrict__ x, TailExtrap te,
-                 const double *__restrict__ r0 = nullptr,
-                 const double *__restrict__ w = nullptr,
-                 double *__restrict__ rnew = nullptr, int nv = 0) {
-    // rnew (residual carry-over): the velocity part of the TRUE residual behind
-    // the step, r0 - alpha w = b - K (x0 + alpha z), wherever r0 and w are
-    // valid (the rank's own rows)
-    const int ef = blockIdx.x * kBlock + threadIdx.x;
-    double pfx = 0.0, pz0 = 0.0;
-    if (ef < n) {
-        pfx = x[ef];
-        pz0 = Z[ef];
-    }
-    const double wr = hs[0], ww = hs[1], rr = hs[2], bb = hs[3];
-    const double rho = sqrt(rr), bn = sqrt(bb);
-    const double tol = fmax(rtol * bn, atol);
-    int status = DNS_OK, conv = 0, tot = 0;
-    double res = rho, alpha = 0.0;
-    const bool go = (rho > tol) && !isnan(rho) && maxiter > 0;
-    if (isnan(rho) || isnan(tol)) status = DNS_BREAKDOWN;
-    if (go) {
-        const double d = ww * rr - wr * wr;
-        if (!(ww > 0.0) || isnan(ww)) {
-            status = DNS_BREAKDOWN;
-        } else if (!(d > 1e-8 * ww * rr)) {
-            // (the guard of the fused Gram-Schmidt: the norm by Pythagoras has
-            // lost its digits)
-            status = kGsFallback;
-        } else {
-            alpha = wr / ww;
-            res = rho * sqrt(d / (ww * rr));
-            tot = 1;
-            conv = res <= tol;
-            if (isnan(res)) status = DNS_BREAKDOWN;
-        }
-    } else {
-        conv = rho <= tol;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctl->predone = 0;
-        ctl->jdone = tot;
-        ctl->zero = 0;
-        ctl->done = 1;
-        ctl->status = status;
-        ctl->total_it = tot;
-        ctl->conv = conv;
-        ctl->beta = rho;
-        ctl->tol = tol;
-        ctl->resnorm = res;
-        ctl->bnorm = bn;
-        ctl->g[0] = rho;
-        ctl->hist[0] = rho;
-        ctl->hist[1] = res;
-        ctl->y[0] = rho * alpha;
-        int hl = 0;
-        if (hl < hist_cap) histbuf[hl++] = rho;
-        if (tot > 0 && hl < hist_cap) histbuf[hl++] = res;
-        ctl->hist_len = hl;
-        ctl->acc_solves += 1;
-        ctl->acc_iters += tot;
-        if (tot > ctl->acc_maxit) ctl->acc_maxit = tot;
-        if (conv && tol > 0.0) {
-            const double rel = res / tol;
-            if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
-        }
-        if (!conv) ctl->acc_fail += 1;
-    }
-    if (rnew)
-        for (int e = ef; e < nv; e += gridDim.x * kBlock)
-            rnew[e] = fma(-alpha, w[e], r0[e]);
-    if (tot == 0 && !te.out) return;
-    if (ef < n) {
-        const double s = fma(alpha, pz0, pfx);
-        if (tot > 0) x[ef] = s;
-        if (te.out) tail_extrapolate(te, ef, s);
-    }
-    for (int e = ef + gridDim.x * kBlock; e < n; e += gridDim.x * kBlock) {
-        const double s = fma(alpha, Z[e], x[e]);
-        if (tot > 0) x[e] = s;
-        if (te.out) tail_extrapolate(te, e, s);
-    }
-}
-
 // u = sum_{i<jdone} y_i V_i
 __global__ void __launch_bounds__(kBlock)
 k_basis_combine(int n, const double *__restrict__ V, size_t ld,

@@ -56,6 +56,16 @@ struct dns_imex {
     dns::DevBuf<double> x0buf[2], rc6[2], ckx0, ckrc[2], ckcell, kx6;
     bool six_ok = false, env_six = true;
     bool env_dfront = true;   // DNS_DIST_FRONT: one-launch front of a partitioned step
+    // row-partitioned step whose one-step cycle ends in k_arn_tail_lazy1: the
+    // tail evaluates the convection cells of the new velocity (DNS_DIST_TAIL,
+    // the step is 7 kernels instead of 8).  `dcells_ok`: the cell values on
+    // the device are those of xs[cur] for the boundary values of generation
+    // `dcells_gen` (left by such a tail or by prime_dcells)
+    bool env_dtail = true, dcells_ok = false;
+    uint64_t dcells_gen = 0;
+    dns::DevBuf<double> x0c;       // the warm start, copied by the front
+    bool dtail_wanted(const dns_solve_opts *o) const;
+    int prime_dcells(const dns_solve_opts *o);
     uint64_t six_conv_gen = 0;     // conv->dbc_gen the cell values belong to
     int prime_six(const dns_imex_coeffs *cf, bool keep_r);
     // coefficients of the polynomial warm start from `nsol_` solutions
@@ -157,11 +167,12 @@ struct dns_imex {
         long steps_enqueued;
         bool pre_ok;
         int pre_sig;
-        bool b_valid, carry_ok, six_ok;
+        bool b_valid, carry_ok, six_ok, dcells_ok;
     };
     HostState host_state() const {
         return {cur, prev, pprev, p3, p4, work, nsol, nc, no, tab_pos,
-                steps_enqueued, pre_ok, pre_sig, b_valid, carry_ok, six_ok};
+                steps_enqueued, pre_ok, pre_sig, b_valid, carry_ok, six_ok,
+                dcells_ok};
     }
     void set_host_state(const HostState &s) {
         cur = s.cur; prev = s.prev; pprev = s.pprev; p3 = s.p3; p4 = s.p4;
@@ -173,6 +184,7 @@ struct dns_imex {
         b_valid = s.b_valid;
         carry_ok = s.carry_ok;
         six_ok = s.six_ok;
+        dcells_ok = s.dcells_ok;
     }
     std::vector<uint64_t> group_key(const dns_imex_coeffs *cf,
                                     const dns_solve_opts *o, int group) const;

@@ -85,6 +85,10 @@ struct TailCells {
     const double *glam, *area;
     TabRef dbctab;
     double *cellvals;
+    // row-partitioned stepper: only the cells sel[0 .. nsel) (those that touch
+    // the rank's rows); nullptr: all of them
+    const int *sel;
+    int nsel;
 };
 
 struct Tail6 {

@@ -455,6 +455,16 @@ struct dns_saddle {
                                       // residual r = b - kx is formed by the
                                       // first tau kernel (k_tau_first)
     } step6;
+    // row-partitioned time stepper (set by dns_imex around a solve): the tail
+    // of a ONE-step cycle (k_arn_tail_lazy1) also evaluates the convection
+    // cells of the new velocity, in extra workgroups, from `x0copy` (the warm
+    // start as the step's front kernel has copied it) and Z_0; `ran` says
+    // whether the cycle that was enqueued did
+    struct DistTail {
+        bool on = false, ran = false;
+        const double *x0copy = nullptr;
+        dns::TailCells cells = {};
+    } dist_tail;
     dns::DevBuf<double> Wcols;
     dns::TailExtrap tail_extrap = {}; // warm start of the next step, written
                                       // by the tail kernels (set by dns_imex)

@@ -767,11 +767,18 @@ k_dist_front(RowMap rm, int nv_all, const int *__restrict__ krp,
              const int *__restrict__ gidx, const double *__restrict__ cellvals,
              double conv_scale, double *__restrict__ b, double *__restrict__ r,
              double *__restrict__ part_rr, double *__restrict__ part_bb,
-             const double *__restrict__ rcc, const double *__restrict__ rcp) {
+             const double *__restrict__ rcc, const double *__restrict__ rcp,
+             double *__restrict__ x0copy = nullptr, int n_all = 0) {
     // rcc / rcp (residual carry-over, dns_imex_coeffs.carry_residual): the true
     // velocity residuals of the last two solves, added to the right-hand side
     // with the weights of the solutions they belong to
+    // x0copy: the warm start as it stands, for the cell workgroups of this
+    // step's tail (k_arn_tail_lazy1 overwrites x0 in place while they run)
     __shared__ double red[4];
+    if (x0copy)
+        for (int e = blockIdx.x * kBlock + threadIdx.x; e < n_all;
+             e += gridDim.x * kBlock)
+            x0copy[e] = x0[e];
     const double *__restrict__ g = tab_row(gtab);
     const double *__restrict__ gp = tab_row(gptab);
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
@@ -828,6 +835,136 @@ k_dist_front(RowMap rm, int nv_all, const int *__restrict__ krp,
     if (threadIdx.x == 0) {
         part_rr[blockIdx.x] = arr;
         part_bb[blockIdx.x] = abb;
+    }
+}
+
+// Tail of that cycle: every workgroup forms the step length from the four
+// all-reduced sums and updates its share of x; workgroup 0 commits the solve's
+// bookkeeping -- everything k_arn_head (j = 0, first = 1) and k_arn_tail_acc
+// would have left in the control block.  A solve whose start vector is inside
+// the tolerance already takes no step.
+__global__ void __launch_bounds__(kBlock)
+k_arn_tail_lazy1(int n, const double *__restrict__ hs, DnsCtl *ctl,
+                 double *__restrict__ histbuf, int hist_cap, int maxiter,
+                 double rtol, double atol, const double *__restrict__ Z,
+                 double *__restrict__ x, TailExtrap te,
+                 const double *__restrict__ r0 = nullptr,
+                 const double *__restrict__ w = nullptr,
+                 double *__restrict__ rnew = nullptr, int nv = 0,
+                 int nrow_blocks = 0, const double *__restrict__ x0copy = nullptr,
+                 TailCells tc = TailCells{}) {
+    // rnew (residual carry-over): the velocity part of the TRUE residual behind
+    // the step, r0 - alpha w = b - K (x0 + alpha z), wherever r0 and w are
+    // valid (the rank's own rows)
+    // tc / x0copy (time stepper with device convection): workgroups beyond
+    // `nrow_blocks` evaluate the convection cells of the NEW velocity from its
+    // definition x0 + alpha z -- x is being overwritten by the row workgroups
+    // of this very launch, so the warm start is read from the copy the front
+    // kernel of the step has made (`x0copy`), never from x
+    if (nrow_blocks <= 0) nrow_blocks = gridDim.x;
+    const bool rowblk = (int)blockIdx.x < nrow_blocks;
+    const int ef = blockIdx.x * kBlock + threadIdx.x;
+    double pfx = 0.0, pz0 = 0.0;
+    double u0[6][2], uz[6][2];
+    int cslot = 0, cq = 0, ccell = 0;
+    bool clive = false;
+    if (!rowblk) {
+        const double *__restrict__ dbcvals = tab_row(tc.dbctab);
+        const int t = (blockIdx.x - nrow_blocks) * kBlock + threadIdx.x;
+        cslot = t >> 3;
+        cq = t & 7;
+        clive = tc.sel ? cslot < tc.nsel : cslot < tc.ncells;
+        ccell = clive ? (tc.sel ? tc.sel[cslot] : cslot) : 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = tc.cellmap[(size_t)(2 * a + i) * tc.ncells + ccell];
+                u0[a][i] = (m >= 0) ? x0copy[m] : dbcvals[-m - 1];
+                uz[a][i] = (m >= 0) ? Z[m] : 0.0;
+            }
+    } else if (ef < n) {
+        pfx = x[ef];
+        pz0 = Z[ef];
+    }
+    const double wr = hs[0], ww = hs[1], rr = hs[2], bb = hs[3];
+    const double rho = sqrt(rr), bn = sqrt(bb);
+    const double tol = fmax(rtol * bn, atol);
+    int status = DNS_OK, conv = 0, tot = 0;
+    double res = rho, alpha = 0.0;
+    const bool go = (rho > tol) && !isnan(rho) && maxiter > 0;
+    if (isnan(rho) || isnan(tol)) status = DNS_BREAKDOWN;
+    if (go) {
+        const double d = ww * rr - wr * wr;
+        if (!(ww > 0.0) || isnan(ww)) {
+            status = DNS_BREAKDOWN;
+        } else if (!(d > 1e-8 * ww * rr)) {
+            // (the guard of the fused Gram-Schmidt: the norm by Pythagoras has
+            // lost its digits)
+            status = kGsFallback;
+        } else {
+            alpha = wr / ww;
+            res = rho * sqrt(d / (ww * rr));
+            tot = 1;
+            conv = res <= tol;
+            if (isnan(res)) status = DNS_BREAKDOWN;
+        }
+    } else {
+        conv = rho <= tol;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->predone = 0;
+        ctl->jdone = tot;
+        ctl->zero = 0;
+        ctl->done = 1;
+        ctl->status = status;
+        ctl->total_it = tot;
+        ctl->conv = conv;
+        ctl->beta = rho;
+        ctl->tol = tol;
+        ctl->resnorm = res;
+        ctl->bnorm = bn;
+        ctl->g[0] = rho;
+        ctl->hist[0] = rho;
+        ctl->hist[1] = res;
+        ctl->y[0] = rho * alpha;
+        int hl = 0;
+        if (hl < hist_cap) histbuf[hl++] = rho;
+        if (tot > 0 && hl < hist_cap) histbuf[hl++] = res;
+        ctl->hist_len = hl;
+        ctl->acc_solves += 1;
+        ctl->acc_iters += tot;
+        if (tot > ctl->acc_maxit) ctl->acc_maxit = tot;
+        if (conv && tol > 0.0) {
+            const double rel = res / tol;
+            if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
+        }
+        if (!conv) ctl->acc_fail += 1;
+    }
+    if (!rowblk) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                u0[a][i] = fma(alpha, uz[a][i], u0[a][i]);
+        conv_cells_compute(u0, tc.ncells, ccell, ccell, cq, clive, tc.glam,
+                           tc.area, tc.cellvals);
+        return;
+    }
+    const int stride = nrow_blocks * kBlock;
+    if (rnew)
+        for (int e = ef; e < nv; e += stride)
+            rnew[e] = fma(-alpha, w[e], r0[e]);
+    if (tot == 0 && !te.out) return;
+    if (ef < n) {
+        const double s = fma(alpha, pz0, pfx);
+        if (tot > 0) x[ef] = s;
+        if (te.out) tail_extrapolate(te, ef, s);
+    }
+    for (int e = ef + stride; e < n; e += stride) {
+        const double s = fma(alpha, Z[e], x[e]);
+        if (tot > 0) x[e] = s;
+        if (te.out) tail_extrapolate(te, e, s);
     }
 }
 

@@ -4,7 +4,7 @@
  mode 'run'    : stepper.run() (graphs = groups of steps)"""
 import sys, os
 import numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench
 from dolfin_navier_scipy_amd import saddle, convection, comm as dcomm
 mode = sys.argv[1]

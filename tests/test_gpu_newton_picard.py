@@ -330,3 +330,209 @@ def test_full_size_picard_and_newton_sweep_against_oracle():
             stp.write_linpoint(which, k, lin[t])
     stp.close()
     cv.close()
+
+
+# ---------------------------------------------------------------------------
+# long horizon: developed vortex shedding, N = 2, Re = 100, dt = 1/512
+# ---------------------------------------------------------------------------
+HORIZON = 2048
+
+
+@pytest.fixture(scope='module')
+def shedding():
+    """cylinder wake N=2, Re=100: the Stokes state advanced 4096 CNAB steps on
+    the device (t = 8: periodic shedding), then the next `HORIZON` CNAB
+    velocities -- the linearisation points of a first Picard sweep
+    (snu:1427-1431)"""
+    from dolfin_navier_scipy_amd import convection, saddle
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    from oracle import saddle_oracle
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, Re=100)
+    th, inv = femp['V'], femp['invinds']
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    dt = 1./512
+    v0 = saddle_oracle.solve_sadpnt_smw(amat=A, jmat=J, rhsv=rhsd['fv'],
+                                        rhsp=rhsd['fp'])[:NV]
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        th, inv, femp['dbcinds'], femp['dbcvals'])
+    system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    system.setup_precond(cheb_degree=6, schur='dense', fp32_store=True,
+                         drop_tol=1e-3, factorization='full')
+    stp = saddle.ImexStepper(system, (M - .5*dt*A).tocsr())
+    nfc = cvop.apply(v0, scale=-1.0)
+    stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+    stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    stp.set_convection(cvop, scale=-1.0)
+    cf = saddle.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                   pscale=-1./dt, extrapolate=4)
+    o = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=2)
+    stp.run(4096, cf, o)
+    vs = [stp.get_state()[0]]
+    for _ in range(HORIZON):
+        stp.run(1, cf, o)
+        vs.append(stp.get_state()[0])
+    stp.close()
+    system.close()
+    cvop.close()
+    # the wake IS shedding: the lift-like cross-stream momentum changes sign
+    return dict(femp=femp, sm=sm, rhsd=rhsd, vs=vs, dt=dt, NV=NV, NP=NP)
+
+
+def _device_conv_callback(cv, NV):
+    """the oracle's `conv(v, picard)` answered by a device operator of its own
+    (verified against the host assembler to 1e-13 above; the host assembler
+    needs 0.3 s per call at this size)"""
+    def conv(v, picard):
+        N, rhsbc, rhscon = cv.assemble(v.reshape(-1)[:NV], newton=not picard)
+        return N, (0.*rhscon if picard else rhscon), rhsbc
+    return conv
+
+
+def test_sweeps_over_2048_steps_of_developed_shedding(shedding):
+    """BASELINE config 3 over a horizon: a Picard sweep, then a Newton sweep,
+    over 2048 steps of developed shedding.  The reference factorises the
+    current operator in every step (snu:1484-1512); here the system matrix is
+    re-valued every step and the preconditioner follows the refresh policy of
+    `TrapezoidalStepper.sweep`.  Asserted: <= 3 Krylov steps per time step in
+    EVERY batch of 64 steps, the Picard sweep within 1e-8 (v in the M-norm, p)
+    of the oracle at every 64th step and at the end, the Newton sweep likewise
+    over its first 512 steps, and the step equation of the Newton sweep
+    satisfied to 1e-9 at steps all along the horizon."""
+    import time
+    from dolfin_navier_scipy_amd import convection, saddle
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    from oracle import saddle_oracle
+    s = shedding
+    femp, sm, rhsd, vs, dt = s['femp'], s['sm'], s['rhsd'], s['vs'], s['dt']
+    th, inv = femp['V'], femp['invinds']
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NV, NP = s['NV'], s['NP']
+    tr = dt*np.arange(HORIZON + 1)
+    cv = convection.ConvectionP2.from_taylor_hood(
+        th, inv, femp['dbcinds'], femp['dbcvals'])
+    stp = dnp.TrapezoidalStepper(
+        M, A, J, cv, nslots=HORIZON + 1, dt=dt,
+        precond=dict(cheb_degree=6, drop_tol=1e-3, factorization='full'),
+        precond_linpoint=vs[0], refresh_iters=3.0)
+    stp.set_rhs(rhsd['fv'], rhsd['fp'])
+    for k in range(HORIZON + 1):
+        stp.write_linpoint(0, k, vs[k])
+    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=2)
+    mnorm = lambda x: np.sqrt((x.T @ (M @ x)).item())
+    # the oracle's operators: a device convection operator of its own
+    cvo = convection.ConvectionP2.from_taylor_hood(
+        th, inv, femp['dbcinds'], femp['dbcvals'])
+    cvo.bind_pattern(stp.pattern)
+    conv = _device_conv_callback(cvo, NV)
+    lin = {t: vs[k] for k, t in enumerate(tr)}
+    marks = list(range(64, HORIZON + 1, 64))
+
+    # ---- Picard, the whole horizon against the oracle
+    t0 = time.perf_counter()
+    got_v, got_p, upd, st = stp.sweep(tr, vs[0], 0, True, opts=opts)
+    t_gpu = time.perf_counter() - t0
+    assert max(st['batches']) <= 3.0, st['batches']
+    t0 = time.perf_counter()
+    rs = saddle_oracle.RefinedSolve()
+    ref_v, ref_p, ref_upd = npo.trapezoidal_sweep(
+        tr, vs[0], M=M, A=A, J=J, fv=rhsd['fv'], fp=rhsd['fp'], conv=conv,
+        appndbcs=lambda v: v, linpoints=lin, picard=True, solve=rs)
+    t_cpu = time.perf_counter() - t0
+    worst = [0., 0.]
+    for k in marks:
+        t = tr[k]
+        worst[0] = max(worst[0], mnorm(got_v[t] - ref_v[t])/mnorm(ref_v[t]))
+        worst[1] = max(worst[1], np.linalg.norm(got_p[t] - ref_p[t])
+                       / np.linalg.norm(ref_p[t]))
+    print('picard, {0} steps: {1:.2f} Krylov steps per time step (worst batch '
+          '{2:.2f}), {3} refreshes; parity v {4:.2e} p {5:.2e}; device {6:.1f} '
+          's (states recorded), oracle {7:.1f} s ({8} LUs)'.format(
+              HORIZON, st['iters']/float(HORIZON), max(st['batches']),
+              st['refreshes'], worst[0], worst[1], t_gpu, t_cpu,
+              rs.factorisations))
+    assert worst[0] <= 1e-8 and worst[1] <= 1e-8, worst
+    assert abs(upd - ref_upd) <= 1e-6*abs(ref_upd)
+
+    # ---- Newton about the Picard trajectory (the device's own: traj[1])
+    got_n, got_pn, updn, stn = stp.sweep(tr, vs[0], 1, False, opts=opts)
+    assert max(stn['batches']) <= 3.0, stn['batches']
+    nref = 512
+    lin_n = {t: got_v[t] for t in tr}
+    ref_n, ref_pn, _ = npo.trapezoidal_sweep(
+        tr[:nref + 1], vs[0], M=M, A=A, J=J, fv=rhsd['fv'], fp=rhsd['fp'],
+        conv=conv, appndbcs=lambda v: v, linpoints=lin_n, picard=False,
+        solve=saddle_oracle.RefinedSolve())
+    wn = [0., 0.]
+    for k in range(64, nref + 1, 64):
+        t = tr[k]
+        wn[0] = max(wn[0], mnorm(got_n[t] - ref_n[t])/mnorm(ref_n[t]))
+        wn[1] = max(wn[1], np.linalg.norm(got_pn[t] - ref_pn[t])
+                    / np.linalg.norm(ref_pn[t]))
+    assert wn[0] <= 1e-8 and wn[1] <= 1e-8, wn
+    # the trapezoidal step equation (snu:1034-1035 + continuity) at steps all
+    # along the horizon, from the device's own iterates
+    import scipy.sparse as sps
+    fv, fp = rhsd['fv'], rhsd['fp']
+    wres = 0.
+    for k in range(128, HORIZON + 1, 128):
+        vc, vn, pn = got_n[tr[k-1]], got_n[tr[k]], got_pn[tr[k]]
+        Nc, rcc, rbc = conv(vc, False)
+        Nn, rcn, rbn = conv(lin_n[tr[k]], False)
+        rhs = M @ vc + .5*dt*((fv + rbn + rcn) + (fv + rbc + rcc)
+                              - (A + Nc) @ vc)
+        res_v = (M + .5*dt*(A + Nn)) @ vn + J.T @ (-dt*pn) - rhs
+        res_p = J @ vn - fp
+        rel = np.sqrt(np.linalg.norm(res_v)**2 + np.linalg.norm(res_p)**2) \
+            / np.sqrt(np.linalg.norm(rhs)**2 + np.linalg.norm(fp)**2)
+        wres = max(wres, rel)
+    print('newton, {0} steps: {1:.2f} Krylov steps per time step (worst batch '
+          '{2:.2f}), {3} refreshes; parity over {4} steps v {5:.2e} p {6:.2e}; '
+          'step residual along the horizon {7:.2e}'.format(
+              HORIZON, stn['iters']/float(HORIZON), max(stn['batches']),
+              stn['refreshes'], nref, wn[0], wn[1], wres))
+    assert wres <= 1e-9, wres
+    stp.close()
+    cv.close()
+    cvo.close()
+
+
+def test_refresh_policy_rebuilds_a_stale_preconditioner(shedding):
+    """the preconditioner set up for `M + dt/2 A` alone (no convection inside)
+    needs ~4 Krylov steps per time step in the developed wake; the policy sees
+    the first batch, rebuilds about the current operator, and the batches
+    behind it need <= 3 -- with the same iterates as a sweep that never
+    refreshes (the preconditioner does not change the answer)"""
+    from dolfin_navier_scipy_amd import convection, saddle
+    from dolfin_navier_scipy_amd import newton_picard as dnp
+    s = shedding
+    femp, sm, rhsd, vs, dt = s['femp'], s['sm'], s['rhsd'], s['vs'], s['dt']
+    M, A, J = sm['M'], sm['A'], sm['J']
+    nst = 320
+    tr = dt*np.arange(nst + 1)
+    opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=True, reorth=2)
+    out = {}
+    for bound in (None, 3.0):
+        cv = convection.ConvectionP2.from_taylor_hood(
+            femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+        stp = dnp.TrapezoidalStepper(
+            M, A, J, cv, nslots=nst + 1, dt=dt,
+            precond=dict(cheb_degree=6, drop_tol=1e-3, factorization='full'),
+            precond_linpoint=None, refresh_iters=bound)
+        stp.set_rhs(rhsd['fv'], rhsd['fp'])
+        for k in range(nst + 1):
+            stp.write_linpoint(0, k, vs[k])
+        v, p, upd, st = stp.sweep(tr, vs[0], 0, True, opts=opts)
+        out[bound] = (v, p, st)
+        stp.close()
+        cv.close()
+    st0, st1 = out[None][2], out[3.0][2]
+    print('stale preconditioner: batches', [round(b, 2) for b in st0['batches']],
+          '-> with the policy', [round(b, 2) for b in st1['batches']],
+          st1['refreshes'], 'refresh(es)')
+    assert st0['refreshes'] == 0 and max(st0['batches']) > 3.0
+    assert 1 <= st1['refreshes'] <= 2
+    assert max(st1['batches'][2:]) <= 3.0
+    assert st1['iters'] < st0['iters']
+    vt, vr = out[3.0][0][tr[-1]], out[None][0][tr[-1]]
+    assert np.linalg.norm(vt - vr) <= 1e-8*np.linalg.norm(vr)
