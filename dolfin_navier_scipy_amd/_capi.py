@@ -109,6 +109,13 @@ SIGNATURES = {
     'dns_saddle_solve': (ct.c_int, [_VP, c_double_p, c_double_p, c_double_p,
                                     c_double_p, ct.POINTER(dns_solve_opts),
                                     ct.POINTER(dns_solve_stats)]),
+    'dns_saddle_solve_multi': (ct.c_int, [_VP, ct.c_int32, c_double_p,
+                                          c_double_p, c_double_p, ct.c_int32,
+                                          c_double_p,
+                                          ct.POINTER(dns_solve_opts),
+                                          ct.POINTER(dns_solve_stats)]),
+    'dns_saddle_residual_history_col': (ct.c_int, [_VP, ct.c_int32, c_double_p,
+                                                   ct.c_int32, c_int32_p]),
     'dns_saddle_residual_history': (ct.c_int, [_VP, c_double_p, ct.c_int32,
                                                c_int32_p]),
     'dns_saddle_apply': (ct.c_int, [_VP, c_double_p, c_double_p]),

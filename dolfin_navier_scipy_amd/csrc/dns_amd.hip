@@ -2093,6 +2093,96 @@ int dns_saddle_solve(dns_saddle *h, const double *rhs_v, const double *rhs_p,
     return dns::guarded([&]() -> int { return dns_saddle_solve_impl(h, rhs_v, rhs_p, x0, out_vp, opts, stats); });
 }
 
+// `ncols` right-hand sides in ONE call: the blocks travel to the device once,
+// the solves run back to back on the resident system (same graphs, same
+// preconditioner), the solutions come back once.  Column c of `rhs_v` is at
+// rhs_v + c NV, of `rhs_p` at rhs_p + c NP (NULL: zero), of `out_vp` at
+// out_vp + c (NV + NP); `x0` holds `x0_cols` start vectors (0: none, 1: the
+// same for every column, else one per column).
+static int dns_saddle_solve_multi_impl(dns_saddle *h, int32_t ncols,
+                                       const double *rhs_v, const double *rhs_p,
+                                       const double *x0, int32_t x0_cols,
+                                       double *out_vp,
+                                       const dns_solve_opts *opts,
+                                       dns_solve_stats *stats) {
+    if (!h || !rhs_v || !out_vp || ncols < 1 || x0_cols < 0 ||
+        (x0_cols > 1 && x0_cols != ncols) || (x0_cols > 0 && !x0))
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    dns_solve_opts o;
+    if (opts)
+        o = *opts;
+    else
+        dns_default_solve_opts(&o);
+    DNS_HIP(hipSetDevice(h->device));
+    const size_t nv = (size_t)h->nv, np = (size_t)h->np, n = (size_t)h->n,
+                 ld = h->ld, k = (size_t)ncols;
+    if (h->mrhs.n < k * ld) DNS_TRY(h->mrhs.alloc(k * ld));
+    if (h->msol.n < k * ld) DNS_TRY(h->msol.alloc(k * ld));
+    DNS_TRY(h->mrhs.zero(h->stream));
+    DNS_TRY(h->msol.zero(h->stream));
+    {
+        // the caller's blocks are borrowed for the whole call: the copies are
+        // only enqueued, ONE wait for all of them (on every way out)
+        SyncOnExit arrived(h->stream);
+        DNS_HIP(hipMemcpy2DAsync(h->mrhs.p, ld * sizeof(double), rhs_v,
+                                 nv * sizeof(double), nv * sizeof(double), k,
+                                 hipMemcpyHostToDevice, h->stream));
+        if (rhs_p && np > 0)
+            DNS_HIP(hipMemcpy2DAsync(h->mrhs.p + nv, ld * sizeof(double), rhs_p,
+                                     np * sizeof(double), np * sizeof(double),
+                                     k, hipMemcpyHostToDevice, h->stream));
+        if (x0_cols > 1)
+            DNS_HIP(hipMemcpy2DAsync(h->msol.p, ld * sizeof(double), x0,
+                                     n * sizeof(double), n * sizeof(double), k,
+                                     hipMemcpyHostToDevice, h->stream));
+        else if (x0_cols == 1)
+            for (size_t c = 0; c < k; ++c)
+                DNS_HIP(hipMemcpyAsync(h->msol.p + c * ld, x0,
+                                       n * sizeof(double),
+                                       hipMemcpyHostToDevice, h->stream));
+    }
+    h->col_history.assign(k, std::vector<double>());
+    int worst = DNS_OK;
+    for (size_t c = 0; c < k; ++c) {
+        dns_solve_stats local;
+        dns_solve_stats *st = stats ? stats + c : &local;
+        memset(st, 0, sizeof(*st));
+        DNS_TRY(h->solve_device(h->mrhs.p + c * ld, h->msol.p + c * ld, &o, st));
+        h->col_history[c] = h->history;
+        if (st->status != DNS_OK && worst == DNS_OK) worst = st->status;
+    }
+    DNS_HIP(hipMemcpy2DAsync(out_vp, n * sizeof(double), h->msol.p,
+                             ld * sizeof(double), n * sizeof(double), k,
+                             hipMemcpyDeviceToHost, h->stream));
+    DNS_HIP(hipStreamSynchronize(h->stream));
+    (void)worst;       // (per-column statuses are in `stats`, like the single solve)
+    return DNS_OK;
+}
+
+int dns_saddle_solve_multi(dns_saddle *h, int32_t ncols, const double *rhs_v,
+                           const double *rhs_p, const double *x0,
+                           int32_t x0_cols, double *out_vp,
+                           const dns_solve_opts *opts, dns_solve_stats *stats) {
+    return dns::guarded([&]() -> int { return dns_saddle_solve_multi_impl(h, ncols, rhs_v, rhs_p, x0, x0_cols, out_vp, opts, stats); });
+}
+
+static int dns_saddle_residual_history_col_impl(dns_saddle *h, int32_t col,
+                                                double *out, int32_t cap,
+                                                int32_t *count) {
+    if (!h || !count || col < 0 || (size_t)col >= h->col_history.size())
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    const std::vector<double> &hist = h->col_history[(size_t)col];
+    *count = (int32_t)hist.size();
+    if (out)
+        for (int32_t i = 0; i < std::min(*count, cap); ++i) out[i] = hist[i];
+    return DNS_OK;
+}
+
+int dns_saddle_residual_history_col(dns_saddle *h, int32_t col, double *out,
+                                    int32_t cap, int32_t *count) {
+    return dns::guarded([&]() -> int { return dns_saddle_residual_history_col_impl(h, col, out, cap, count); });
+}
+
 static int dns_saddle_residual_history_impl(dns_saddle *h, double *out, int32_t cap,
                                 int32_t *count) {
     if (!h || !count) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");

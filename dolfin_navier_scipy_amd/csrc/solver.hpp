@@ -375,6 +375,10 @@ struct dns_saddle {
     dns::DevBuf<double> bi_rhat, bi_p, bi_v, bi_s, bi_t, bi_y, histdev;
     dns::DevBuf<dns::DnsCtl> ctl;
     dns::DevBuf<dns::BicgCtl> bctl;
+    // blocks of right-hand sides / solutions of dns_saddle_solve_multi
+    // (column c at c * ld) and the residual history of every column
+    dns::DevBuf<double> mrhs, msol;
+    std::vector<std::vector<double>> col_history;
     dns::DevBuf<double> scal;        // small scalar scratch
     dns::CtlHeader *hdr_host = nullptr;   // pinned
     double *scal_host = nullptr;          // pinned

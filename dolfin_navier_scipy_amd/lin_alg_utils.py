@@ -219,11 +219,9 @@ class _SaddleSolveFn(object):
         rhs = np.asarray(rhs, dtype=np.float64)
         shape = rhs.shape
         cols = rhs.reshape((self.system.n, -1))
-        out = np.empty_like(cols)
         NV = self.system.NV
-        for k in range(cols.shape[1]):
-            out[:, k] = self.system.solve(cols[:NV, k], cols[NV:, k],
-                                          opts=self.opts)
+        out = self.system.solve_multi(cols[:NV, :], cols[NV:, :],
+                                      opts=self.opts)
         return out.reshape(shape)
 
 
@@ -255,15 +253,20 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
     x0 = prm.get('x0', None)
 
     def _solve_cols(rv, rp, x0=None):
-        out = np.empty((NV+NP, rv.shape[1]))
-        x0c = None if x0 is None else \
-            np.asarray(x0, dtype=np.float64).reshape((NV+NP, -1))
-        for k in range(rv.shape[1]):
-            xk = None if x0c is None else x0c[:, min(k, x0c.shape[1]-1)]
-            out[:, k] = system.solve(rv[:, k], rp[:, k], x0=xk, opts=opts)
-            system._lau_entry.note(system.last_stats['iters'])
+        # all columns in ONE call of the boundary: the blocks cross the PCIe
+        # once, the solves run back to back on the resident system
+        if x0 is not None:
+            x0 = np.asarray(x0, dtype=np.float64).reshape((NV+NP, -1))
+            if 1 < x0.shape[1] < rv.shape[1]:    # the last one for the rest
+                x0 = np.hstack([x0] + [x0[:, -1:]]*(rv.shape[1] - x0.shape[1]))
+            elif x0.shape[1] > rv.shape[1]:
+                x0 = x0[:, :rv.shape[1]]
+        out = system.solve_multi(rv, rp, x0=x0, opts=opts)
+        for k, st in enumerate(system.last_stats_cols):
+            system._lau_entry.note(st['iters'])
             if 'convstatsl' in prm:
-                prm['convstatsl'].append(system.residual_history().tolist())
+                prm['convstatsl'].append(
+                    system.residual_history_col(k).tolist())
         return out
 
     sol = _solve_cols(rhsv, rhsp, x0=x0)

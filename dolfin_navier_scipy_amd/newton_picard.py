@@ -87,6 +87,7 @@ class TrapezoidalStepper(object):
         self.refresh_iters = refresh_iters
         self.batch = int(batch)
         self.refreshes = 0
+        self._level, self._tried = None, False    # (state of the policy)
         self.conv = conv
         self.M, self.A, self.J = (sps.csr_matrix(M), sps.csr_matrix(A),
                                   sps.csr_matrix(J))
@@ -210,7 +211,7 @@ class TrapezoidalStepper(object):
         C.check(self.lib.dns_trap_start(self._h, C.dptr(v), int(bool(newton))))
 
     def step(self, dt, lin_which, lin_slot, out_slot, newton, opts=None,
-             extrapolate=2, raise_on_fail=True, feedback=None):
+             extrapolate=3, raise_on_fail=True, feedback=None):
         """`feedback=(umat (NV, r), vmat_c (r, NV) or None, vmat_n (r, NV))`:
         the low-rank terms of `_get_mats_rhs_ts` (snu:1036-1042) -- system
         `F - dt/2 U V_n` by Sherman-Morrison-Woodbury, rhs `+ dt/2 U V_c v_c`"""
@@ -278,7 +279,7 @@ class TrapezoidalStepper(object):
         self.system.setup_precond(**self._pkw)
         self.refreshes += 1
 
-    def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=2,
+    def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=3,
               record=True, pipeline=True, batch=None):
         """one sweep over `trange` linearised about trajectory `lin_which`
         (slot k <-> trange[k]); the new velocities go to the other trajectory.
@@ -291,9 +292,12 @@ class TrapezoidalStepper(object):
         step did not converge within the agreed cycle length is repeated from
         its checkpoint with synchronous steps.  REFRESH POLICY
         (`refresh_iters`, constructor): when the Krylov steps per time step of
-        a batch exceed the bound, the preconditioner is rebuilt about the
-        current operator before the next batch -- the system matrix follows
-        the flow every step, the preconditioner follows it when it pays."""
+        a batch exceed the bound AND have risen by a fifth over what this
+        preconditioner gave in the first batch behind its set-up, it is rebuilt
+        about the current operator before the next batch (a first batch above
+        the bound gets one rebuild straight away: a set-up made for another
+        state) -- the system matrix follows the flow every step, the
+        preconditioner follows it when it pays."""
         trange = np.asarray(trange, dtype=np.float64)
         if trange.size > self.nslots:
             raise ValueError('trajectory buffers hold {0} slots'.format(
@@ -331,7 +335,25 @@ class TrapezoidalStepper(object):
         def policy(per_step, k):
             bound = self.refresh_iters
             tot['batches'].append(per_step)
-            if bound and per_step > bound and k < nt:
+            if not bound or k >= nt:
+                return
+            if self._level is None:
+                # the first batch behind a set-up: what THIS preconditioner
+                # gives at its best.  Above the bound, one rebuild about the
+                # current operator is tried (a set-up made for another state)
+                self._level = per_step
+                if per_step > bound and not self._tried:
+                    self._tried = True
+                    self._level = None
+                    self.refresh_precond()
+                    tot['refreshes'] += 1
+                return
+            # later: rebuild when the count is above the bound AND has risen by
+            # a fifth over that level -- a bound that no rebuild reaches (tight
+            # tolerance) must not rebuild batch after batch
+            if per_step > bound and per_step > 1.2*self._level:
+                self._level = None
+                self._tried = True
                 self.refresh_precond()
                 tot['refreshes'] += 1
 
@@ -384,7 +406,7 @@ def time_sections(trange, nsects=1, addfullsweep=False):
 
 def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
                   vel_nwtn_stps=2, vel_nwtn_tol=1e-14, opts=None,
-                  extrapolate=2, rhs_table=None, nsects=1,
+                  extrapolate=3, rhs_table=None, nsects=1,
                   loc_nwtn_tol=5e-15, loc_pcrd_stps=True, addfullsweep=False,
                   tables=None):
     """Picard sweeps first, then Newton sweeps, each linearised about the

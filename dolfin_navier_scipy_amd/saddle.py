@@ -181,6 +181,53 @@ class SaddleSystem(object):
                                           ct.byref(out)))
         return out.value
 
+    def solve_multi(self, rhsv, rhsp=None, x0=None, raise_on_fail=True, **kw):
+        """`k` right-hand sides in one call (`dns_saddle_solve_multi`): `rhsv`
+        `(NV, k)`, `rhsp` `(NP, k)` or None, `x0` `(NV+NP, 1 or k)` or None;
+        returns the `(NV+NP, k)` solutions; `last_stats_cols` holds one
+        record per column, `last_stats` the last column's"""
+        o = kw.pop('opts', None)
+        o = solve_opts(**kw) if o is None else o
+        rv = np.asarray(rhsv, dtype=np.float64).reshape((self.NV, -1))
+        k = rv.shape[1]
+        rvf = np.ascontiguousarray(rv.T).reshape(-1)          # column by column
+        rpf = None
+        if rhsp is not None:
+            rpf = np.ascontiguousarray(np.asarray(
+                rhsp, dtype=np.float64).reshape((self.NP, k)).T).reshape(-1)
+        x0f, x0c = None, 0
+        if x0 is not None:
+            xa = np.asarray(x0, dtype=np.float64).reshape((self.n, -1))
+            x0c = xa.shape[1]
+            if x0c not in (1, k):
+                raise ValueError('`x0` must have 1 or {0} columns'.format(k))
+            x0f = np.ascontiguousarray(xa.T).reshape(-1)
+        out = np.empty(k*self.n)
+        sts = (C.dns_solve_stats*k)()
+        C.check(self.lib.dns_saddle_solve_multi(
+            self._h, k, C.dptr(rvf), C.dptr(rpf), C.dptr(x0f), x0c,
+            C.dptr(out), ct.byref(o), sts))
+        self.last_stats_cols = [st.asdict() for st in sts]
+        self.last_stats = self.last_stats_cols[-1]
+        if raise_on_fail:
+            for c, st in enumerate(sts):
+                if st.status != C.DNS_OK:
+                    cls = C.NotConverged if st.status == C.DNS_NOT_CONVERGED \
+                        else C.Breakdown
+                    raise cls(st.status, 'column {0}: Krylov solve stopped '
+                              'after {1} iterations at relative residual '
+                              '{2:.3e}'.format(c, st.iters, st.est_relres))
+        return out.reshape((k, self.n)).T.copy()
+
+    def residual_history_col(self, col):
+        cnt = ct.c_int32(0)
+        C.check(self.lib.dns_saddle_residual_history_col(
+            self._h, int(col), None, 0, ct.byref(cnt)))
+        out = np.zeros(max(cnt.value, 1))
+        C.check(self.lib.dns_saddle_residual_history_col(
+            self._h, int(col), C.dptr(out), cnt.value, ct.byref(cnt)))
+        return out[:cnt.value]
+
     def residual_history(self):
         cnt = ct.c_int32(0)
         C.check(self.lib.dns_saddle_residual_history(self._h, None, 0,

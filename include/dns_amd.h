@@ -160,6 +160,22 @@ int dns_saddle_solve(dns_saddle *h, const double *rhs_v, const double *rhs_p,
                      const double *x0, double *out_vp,
                      const dns_solve_opts *opts, dns_solve_stats *stats);
 
+/* `ncols` right-hand sides in one call -- `lau.solve_sadpnt_smw` takes
+ * `(NV, k)` blocks (`umat` / `vmat` feedback, stokes_navier_utils.py:1036-1042,
+ * 1512; `apply_massinv`, tests/time_dep_nse_bigchannel.py:33): the blocks cross
+ * the PCIe once, the solves run back to back on the resident system.
+ * Column c of `rhs_v` at rhs_v + c NV, of `rhs_p` (may be NULL) at rhs_p + c NP,
+ * of `out_vp` at out_vp + c (NV + NP); `x0`: `x0_cols` start vectors (0 none,
+ * 1 shared, `ncols` one each); `stats` (may be NULL) holds `ncols` records.
+ * A column that does not converge is reported in its record, like the single
+ * solve; the residual histories per column: dns_saddle_residual_history_col */
+int dns_saddle_solve_multi(dns_saddle *h, int32_t ncols, const double *rhs_v,
+                           const double *rhs_p, const double *x0,
+                           int32_t x0_cols, double *out_vp,
+                           const dns_solve_opts *opts, dns_solve_stats *stats);
+int dns_saddle_residual_history_col(dns_saddle *h, int32_t col, double *out,
+                                    int32_t cap, int32_t *count);
+
 /* residual history of the last solve (`krpslvprms['convstatsl']`,
  * tests/time_dep_nse_krylov.py:47); returns the number of entries written */
 int dns_saddle_residual_history(dns_saddle *h, double *out, int32_t cap,

@@ -67,8 +67,11 @@ class RefinedSolve(object):
     solve up to rounding -- `tests/test_newton_picard.py` holds the two side
     by side."""
 
-    def __init__(self, rtol=2e-16, max_inner=10, floor=1e-13):
+    def __init__(self, rtol=2e-16, max_inner=10, floor=1e-13, refactor_at=6):
         self.rtol, self.max_inner, self.floor = rtol, max_inner, floor
+        # a solve that needed this many corrections makes the NEXT system
+        # factor its own matrix (the sequence has drifted away)
+        self.refactor_at = refactor_at
         self.lu = None
         self.factorisations = 0
         self.corrections = 0
@@ -107,6 +110,8 @@ class RefinedSolve(object):
                     break
             self.corrections += it
             if rn <= self.floor*bn:
+                if it >= self.refactor_at:
+                    self.lu = None
                 return x.reshape((-1, 1))
             self.lu = None                 # this system gets its own LU
         raise RuntimeError('refined solve failed (relative residual {0:.2e})'

@@ -71,7 +71,13 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True,
     roof = perfmodel.step_roofline(system.precond_info(), int(R1.nnz),
                                    int(th.mesh.ncells), its/float(nsteps),
                                    1e3*wall/nsteps)
-    out = dict(refine=refine, spinup_steps=max(40, spinup), roofline_step=roof, NV=int(NV), NP=int(NP), n=int(NV + NP), dt=dt,
+    pinfo = system.precond_info()
+    out = dict(refine=refine, spinup_steps=max(40, spinup), roofline_step=roof,
+               NV=int(NV), NP=int(NP), n=int(NV + NP), dt=dt,
+               nnz_K=int(pinfo['nnz_K']), nnz_Gc=int(pinfo['nnz_Gc']),
+               nnz_JG=int(pinfo['nnz_JG']),
+               cheb_degree=int(pinfo['cheb_degree']),
+               drop_tol=float(os.environ.get('MG_DROP', '1e-3')),
                steps=nsteps, gpu_steps_per_s=nsteps/wall,
                gpu_ms_per_step=1e3*wall/nsteps,
                krylov_iters_per_step=its/float(nsteps),

@@ -58,6 +58,7 @@ def main():
     spinup = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     rtol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-10
     bound = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
+    extrap = int(sys.argv[5]) if len(sys.argv) > 5 else 3
     dt = 1./512
     femp, sm, rhsd = bench.build_problem(N=2, Re=100.)
     M, A, J = sm['M'], sm['A'], sm['J']
@@ -67,7 +68,8 @@ def main():
     print('CNAB trajectory: {0} + {1} steps in {2:.1f} s'.format(
         spinup, nsteps, time.perf_counter() - t0), file=sys.stderr)
     trange = dt*np.arange(nsteps + 1)
-    out = dict(nsteps=nsteps, spinup=spinup, rtol=rtol, bound=bound, runs=[])
+    out = dict(nsteps=nsteps, spinup=spinup, rtol=rtol, bound=bound,
+               extrapolate=extrap, runs=[])
     for refresh in (None, bound):
         cvop = convection.ConvectionP2.from_taylor_hood(
             th, inv, femp['dbcinds'], femp['dbcvals'])
@@ -84,7 +86,7 @@ def main():
         for name, picard in (('picard', True), ('newton', False)):
             t0 = time.perf_counter()
             _, _, upd, st = ts.sweep(trange, vs[0], which, picard, opts=opts,
-                                     record=False)
+                                     record=False, extrapolate=extrap)
             wall = time.perf_counter() - t0
             rec = dict(sweep=name, refresh_bound=refresh,
                        steps_per_s=nsteps/wall,

@@ -17,6 +17,11 @@ def sad():
     return saddle
 
 
+def _capi_mod():
+    from dolfin_navier_scipy_amd import _capi
+    return _capi
+
+
 @pytest.fixture(scope='module')
 def small(toy_prob):
     M, A, J = (toy_prob['smc'][k] for k in 'MAJ')
@@ -230,6 +235,49 @@ def test_restart_and_x0(sad, small):
     x2 = system.solve(small['rhsv'], small['rhsp'], x0=x, rtol=1e-10)
     assert system.last_stats['iters'] == 0
     assert np.array_equal(x2, x)
+    system.close()
+
+
+def test_multi_column_solve_is_the_column_by_column_solve(sad, small):
+    """`dns_saddle_solve_multi`: `(NV, k)` blocks in one call of the boundary
+    (`lau.solve_sadpnt_smw` takes them: `umat`/`vmat`, `apply_massinv`) -- the
+    same answers, iteration counts and residual histories as k single calls"""
+    F, J = small['F'], small['J']
+    NP, NV = J.shape
+    rng = np.random.default_rng(21)
+    RV = small['M'] @ rng.standard_normal((NV, 3))
+    RP = 1e-3*rng.standard_normal((NP, 3))
+    system = sad.SaddleSystem(F, J)
+    system.setup_precond(cheb_degree=4, schur='dense')
+    X = system.solve_multi(RV, RP, rtol=1e-11, use_graph=True)
+    assert X.shape == (NV + NP, 3) and len(system.last_stats_cols) == 3
+    for c in range(3):
+        xc = system.solve(RV[:, c], RP[:, c], rtol=1e-11, use_graph=True)
+        st = system.last_stats
+        assert np.array_equal(xc, X[:, c])
+        assert st['iters'] == system.last_stats_cols[c]['iters']
+        hist = system.residual_history()
+        assert np.array_equal(hist, system.residual_history_col(c))
+        ref = saddle_oracle.solve_sadpnt_smw(amat=F, jmat=J, rhsv=RV[:, c],
+                                             rhsp=RP[:, c]).reshape(-1)
+        assert np.linalg.norm(xc - ref) <= 1e-8*np.linalg.norm(ref)
+    # no pressure block handed over = zeros; ONE start vector for all columns,
+    # or one each (the exact solutions: no iteration)
+    X0 = system.solve_multi(RV, None, rtol=1e-11)
+    for c in range(3):
+        assert np.array_equal(X0[:, c], system.solve(RV[:, c], None, rtol=1e-11))
+    Xs = system.solve_multi(RV, RP, x0=X, rtol=1e-9)
+    assert [st['iters'] for st in system.last_stats_cols] == [0, 0, 0]
+    assert np.array_equal(Xs, X)
+    Xo = system.solve_multi(RV, RP, x0=X[:, :1], rtol=1e-9)
+    assert system.last_stats_cols[0]['iters'] == 0
+    assert system.last_stats_cols[1]['iters'] > 0
+    assert np.linalg.norm(Xo - X) <= 1e-7*np.linalg.norm(X)
+    # a column that cannot converge is reported, not swallowed
+    with pytest.raises(_capi_mod().NotConverged):
+        system.solve_multi(RV, RP, rtol=1e-14, maxiter=2)
+    with pytest.raises(ValueError):
+        system.solve_multi(RV, RP, x0=X[:, :2])
     system.close()
 
 

@@ -570,6 +570,23 @@ def _trap_sweeps(comm):
     vd, pd, hist = dnp.newton_picard(stp, tr, s['iniv'], s['lin0'],
                                      vel_pcrd_stps=1, vel_nwtn_stps=2,
                                      opts=opts)
+    # ... and three steps with the low-rank feedback terms of
+    # `_get_mats_rhs_ts` (snu:1036-1042: `F - dt/2 U V_n` by Sherman-Morrison-
+    # Woodbury; every Woodbury column is one more partitioned solve)
+    rng = np.random.default_rng(21)
+    NV = s['NV']
+    umat = 1e-1*(s['M'] @ rng.standard_normal((NV, 2)))
+    vmats = [rng.standard_normal((2, NV))/np.sqrt(NV) for _ in tr]
+    for k, t in enumerate(tr):
+        stp.write_linpoint(0, k, s['lin0'][t])
+    stp.start(s['iniv'], newton=True)
+    osync = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=False,
+                              reorth=1)
+    dt = tr[1] - tr[0]
+    for k in range(1, 4):
+        stp.step(dt, 0, k, k, True, opts=osync,
+                 feedback=(umat, vmats[k-1], vmats[k]))
+    s['fb_state'] = stp.state()
     stp.close()
     cv.close()
     tl = tr[-1]
@@ -592,9 +609,10 @@ def _worker_trap(rank, world, port, outdir):
     from dolfin_navier_scipy_amd import comm as dcomm
     cm = dcomm.Comm.gloo(0)
     before = cm.stats()
-    v, p, hist, _ = _trap_sweeps(cm)
+    v, p, hist, sw = _trap_sweeps(cm)
     after = cm.stats()
     np.savez(os.path.join(outdir, 'trap_rank{0}.npz'.format(rank)), v=v, p=p,
+             fbv=sw['fb_state'][0], fbp=sw['fb_state'][1],
              hist=hist, halo=after['halo_exchange'] - before['halo_exchange'],
              gathers=after['allgatherv'] - before['allgatherv'])
     cm.close()
@@ -616,6 +634,11 @@ def test_newton_picard_sweeps_on_a_partitioned_handle(tmp_path):
     assert np.linalg.norm(r0['v'] - v1) <= 1e-9*np.linalg.norm(v1)
     assert np.linalg.norm(r0['p'] - p1) <= 1e-8*np.linalg.norm(p1)
     assert np.allclose(r0['hist'], hist1, rtol=1e-5, atol=1e-16)
+    # low-rank feedback on the partitioned handle == on one GPU
+    assert np.array_equal(r0['fbv'], r1['fbv'])
+    fv1, fp1 = s['fb_state']
+    assert np.linalg.norm(r0['fbv'] - fv1) <= 1e-9*np.linalg.norm(fv1)
+    assert np.linalg.norm(r0['fbp'] - fp1) <= 1e-8*np.linalg.norm(fp1)
     tr = s['trange']
     lin_full = {t: s['appnd'](v) for t, v in s['lin0'].items()}
     vo, po, _ = npo.newton_picard(
@@ -633,11 +656,13 @@ def test_newton_picard_sweeps_on_one_rccl_rank():
     of the partitioned stepper runs (captured into the cycle graphs) and the
     iterates equal the plain run's"""
     from dolfin_navier_scipy_amd import comm as dcomm
-    v1, p1, hist1, _ = _trap_sweeps(None)
+    v1, p1, hist1, s1 = _trap_sweeps(None)
     cm = dcomm.Comm.rccl(0, 1, 0, dcomm.rccl_unique_id())
-    v, p, hist, _ = _trap_sweeps(cm)
+    v, p, hist, sc = _trap_sweeps(cm)
     calls = cm.stats()
     cm.close()
+    for a, b, tol in zip(sc['fb_state'], s1['fb_state'], (1e-9, 1e-8)):
+        assert np.linalg.norm(a - b) <= tol*np.linalg.norm(b)
     assert np.linalg.norm(v - v1) <= 1e-9*np.linalg.norm(v1)
     assert np.linalg.norm(p - p1) <= 1e-8*np.linalg.norm(p1)
     assert np.allclose(hist, hist1, rtol=1e-5, atol=1e-16)
