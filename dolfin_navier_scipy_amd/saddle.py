@@ -6,7 +6,7 @@ import scipy.sparse as sps
 
 from . import _capi as C
 
-__all__ = ['SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
+__all__ = ['streaming_precond_defaults', 'SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
            'dense_inverse', 'spmv_bench', 'spmv_pair', 'solve_opts', 'precond_opts']
 
 _METHODS = {'gmres': C.DNS_METHOD_GMRES, 'bicgstab': C.DNS_METHOD_BICGSTAB}
@@ -379,6 +379,20 @@ class ImexStepper(object):
         out = ct.c_double(0.)
         C.check(self.lib.dns_imex_vnorm(self._h, ct.byref(out)))
         return out.value
+
+
+def streaming_precond_defaults(n):
+    """degree and drop tolerance of the explicit polynomial `Fh^-1` for a
+    system of `n` unknowns.  Where the step is bandwidth bound the polynomial
+    matrix `Gc` is the largest stream of a Krylov step (3.6 x the non-zeros of
+    `K` at degree 8, drop 1e-3): a HIGHER degree with a LARGER drop tolerance
+    keeps the Krylov-step count and cuts the stream -- measured on the refined
+    wake (profiles/r04_gc_pareto/table.txt): n = 173k 3651 -> 4039 steps/s,
+    n = 693k 1301 -> 1595, n = 2.78M 308 -> 431.  At the reference sizes (cache
+    resident, ONE Krylov step per time step) degree 6 / 1e-3 stays."""
+    if n >= 100000:
+        return dict(cheb_degree=8, drop_tol=7e-3)
+    return dict(cheb_degree=6, drop_tol=1e-3)
 
 
 # ---- standalone kernels ---------------------------------------------------
