@@ -406,7 +406,7 @@ def traffic_source(traffic):
             'scripts/final_profiles.sh, FETCH_SIZE x 2 + WRITE_SIZE per '
             'launch) taken at commit {0}; printed only while the SHA-256 of '
             'pair.hpp / kernels.hpp equal the stamped ones'.format(
-                rec.get('commit', '?')))
+                rec.get('taken_at_commit', '?')))
 
 
 def roofline_pair(saddle, Kmat, nv, reps, label):

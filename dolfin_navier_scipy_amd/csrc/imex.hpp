@@ -153,6 +153,7 @@ struct dns_imex {
     int batch_len = 8;             // steps per batch: 8 -> 16 -> 32 while the
                                    // predictions hold
     uint64_t prepared_sig = 0;     // configuration the graphs were captured for
+    int chi_hi = 0;                // longest cycle length they cover (monotone)
     // record of the last dns_imex_run (dns_imex_run_info)
     int run_unconverged = 0, run_first_bad = -1, run_replayed = 0;
     int run_captures = 0;          // graphs captured inside the last run

@@ -22,7 +22,7 @@ echo "== bench (driver window)"; timeout -k 10 300 python bench.py --steps 20 --
 echo "== refined legs"
 timeout -k 10 300 python refined_bench.py 2 2048 200 0 > $OUT/refine2_bench.json 2> $OUT/refine2.err || echo "refine2 failed"
 timeout -k 10 300 python refined_bench.py 3 4096 100 0 > $OUT/refine3_bench.json 2> $OUT/refine3.err || echo "refine3 failed"
-MG_DEG=8 MG_FHAT=explicit timeout -k 10 400 python refined_bench.py 4 8192 100 0 > $OUT/refine4_bench.json 2> $OUT/refine4.err || echo "refine4 failed"
+timeout -k 10 400 python refined_bench.py 4 8192 100 0 > $OUT/refine4_bench.json 2> $OUT/refine4.err || echo "refine4 failed"
 echo "== SBDF2, partitioned path on one RCCL rank"
 timeout -k 10 300 python bench.py --scheme sbdf2 --no-cpu --no-refined --no-picard --roofline-refine 0 > $OUT/bench_sbdf2.json 2> $OUT/bench_sbdf2.err || echo "sbdf2 failed"
 timeout -k 10 300 python bench.py --partitioned-only --gpus 1 --level 2 --steps 400 --warmup 40 --spinup 256 > $OUT/partitioned_one_rank_n10k.json 2> $OUT/partitioned_one_rank_n10k.err || echo "partitioned n10k failed"
@@ -30,11 +30,14 @@ timeout -k 10 300 python bench.py --partitioned-only --gpus 1 --level 2 --refine
 timeout -k 10 300 python bench.py --partitioned-only --gpus 1 --level 2 --refine 3 --nts 4096 --steps 200 --warmup 20 --spinup 256 > $OUT/partitioned_one_rank_n693k.json 2> $OUT/partitioned_one_rank_n693k.err || echo "partitioned n693k failed"
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprofv3 kernel stats of the bench command (graph replay)"
-# (graph-mode profiles stay below ~1e4 replayed kernels: profiles/r03_rocprof_graph_crash)
+# (a ring of 131072 AQL packets never wraps inside these runs: rocprofv3 7.2
+# dies on a graph launch whose packet batch wraps the ring, profiles/r04_rocprof_wrap)
+export ROC_AQL_QUEUE_SIZE=131072
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python3 $R/bench.py --no-cpu --no-refined --no-picard --steps 200 --warmup 20 --spinup 64 > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err || echo "profiled bench failed"
 echo "== rocprofv3 kernel stats of the step alone (graph replay / eager)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step_graph -o step -- python3 $R/bench.py --profile-step --steps 300 --warmup 40 --spinup 64 > $OUT/step_graph.json 2> $OUT/step_graph.err || echo "step graph profile failed"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step_graph -o step -- python3 $R/bench.py --profile-step --steps 2000 --warmup 40 --spinup 256 > $OUT/step_graph.json 2> $OUT/step_graph.err || echo "step graph profile failed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_step_eager -o step -- python3 $R/bench.py --profile-step --eager --steps 400 --warmup 40 > $OUT/step_eager.json 2> $OUT/step_eager.err || echo "step eager profile failed"
+unset ROC_AQL_QUEUE_SIZE
 cd $R
 python - <<PY
 import json, glob, csv
