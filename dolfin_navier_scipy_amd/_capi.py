@@ -160,6 +160,7 @@ SIGNATURES = {
     'dns_imex_vnorm': (ct.c_int, [_VP, c_double_p]),
     'dns_imex_run_info': (ct.c_int, [_VP, c_int32_p, c_int32_p, c_int32_p,
                                      c_int32_p]),
+    'dns_imex_step_counters': (ct.c_int, [_VP, ct.POINTER(ct.c_int64)]),
     'dns_conv_create_p2': (ct.c_int, [ct.c_int, ct.c_int32, c_int32_p,
                                       c_double_p, c_double_p, ct.c_int32,
                                       ct.c_int32, c_int32_p, ct.c_int32,

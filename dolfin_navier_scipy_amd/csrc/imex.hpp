@@ -64,6 +64,10 @@ struct dns_imex {
     bool env_dtail = true, dcells_ok = false;
     uint64_t dcells_gen = 0;
     dns::DevBuf<double> x0c;       // the warm start, copied by the front
+    // steps BUILT (launched or captured; a replayed graph is not counted), of
+    // them: with the cells in the tail / with the cell kernel left out because
+    // the tail before had run it (dns_imex_step_counters: tests)
+    int64_t n_steps_built = 0, n_steps_tail_cells = 0, n_steps_cells_reused = 0;
     bool dtail_wanted(const dns_solve_opts *o) const;
     int prime_dcells(const dns_solve_opts *o);
     uint64_t six_conv_gen = 0;     // conv->dbc_gen the cell values belong to

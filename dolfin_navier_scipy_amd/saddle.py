@@ -369,6 +369,13 @@ class ImexStepper(object):
             C.check(status)
         return secs.value, its.value, self.last_stats
 
+    def step_counters(self):
+        """`(built, tail_cells, cells_reused)` of the row-partitioned step
+        (`dns_imex_step_counters`)"""
+        buf = (ct.c_int64*3)()
+        C.check(self.lib.dns_imex_step_counters(self._h, buf))
+        return tuple(int(b) for b in buf)
+
     def get_state(self):
         v = np.empty(self.sys.NV)
         p = np.empty(self.sys.NP)

@@ -357,6 +357,12 @@ int dns_imex_run(dns_imex *st, int32_t nsteps, const dns_imex_coeffs *cf,
  * a batch mispredicted its cycle length, graphs captured inside the call */
 int dns_imex_run_info(dns_imex *st, int32_t *unconverged, int32_t *first_bad,
                       int32_t *replayed, int32_t *captures);
+/* diagnostics of the row-partitioned step (tests): out[0] = steps built
+ * (launched or captured; graph replays are not counted), out[1] = of them the
+ * steps whose one-step cycle evaluated the convection cells of the new
+ * velocity in its tail, out[2] = the steps that left the cell kernel out
+ * because the tail before had run it */
+int dns_imex_step_counters(dns_imex *st, int64_t *out3);
 /* v (NV) and p = pscale*p~ (NP) of the current state */
 int dns_imex_get_state(dns_imex *st, double *v, double *p);
 /* ||v||_2 of the current velocity (blow-up guard, tiu:94-103) */

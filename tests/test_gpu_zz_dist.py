@@ -724,3 +724,93 @@ def test_bench_n2_line_carries_its_parity_and_a_wrong_halo_turns_it_red():
     first = weak.get('first_attempt_with_graphs', weak)
     assert 'parity' in first['error'] or 'parity' in weak['error'] \
         or 'child' in weak['error'], weak['error']
+
+
+def _dtail_steps(sad, comm, tail_on, nsteps=40):
+    """config 4's mesh with the convection on the device, every solve starting
+    with a ONE-step cycle, a tolerance such that most steps ARE that one step:
+    the lazy tail then evaluates the convection cells of the new velocity and
+    the next step's front leaves its cell kernel out (`DNS_DIST_TAIL`)"""
+    from dolfin_navier_scipy_amd import convection
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=3, Re=40)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    dt = 0.5/256
+    os.environ['DNS_DIST_TAIL'] = '1' if tail_on else '0'
+    system = sad.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    system.set_option('cycle_first', 1.)
+    if comm is not None:
+        system.set_comm(comm)
+    system.setup_precond(cheb_degree=6, schur='dense', fhat='explicit',
+                         factorization='full', drop_tol=1e-3)
+    cvop = convection.ConvectionP2.from_taylor_hood(
+        femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+    stepper = sad.ImexStepper(system, (M - .5*dt*A).tocsr())
+    v0 = np.zeros((NV, 1))                       # impulsive start from rest
+    nfc = cvop.apply(v0, scale=-1.0)
+    stepper.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+    stepper.set_convection(cvop, scale=-1.0)
+    stepper.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    cf = sad.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                pscale=-1./dt, extrapolate=4)
+    opts = sad.solve_opts(rtol=1e-7, reorth=2, use_graph=True)
+    its = 0
+    for _ in range(nsteps):
+        its += stepper.step(cf, opts=opts)['iters']
+    v, p = stepper.get_state()
+    counters = stepper.step_counters()
+    stepper.close()
+    cvop.close()
+    system.close()
+    os.environ.pop('DNS_DIST_TAIL', None)
+    return v, p, its, counters
+
+
+def _worker_dtail(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      GLOO_SOCKET_IFNAME='lo')
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+    import faulthandler
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(200, exit=True)   # never hang a GPU box
+    dist.init_process_group('gloo', rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=120))
+    from dolfin_navier_scipy_amd import saddle, comm as dcomm
+    cm = dcomm.Comm.gloo(0)
+    on = _dtail_steps(saddle, cm, True)
+    off = _dtail_steps(saddle, cm, False)
+    np.savez(os.path.join(outdir, 'dtail_rank{0}.npz'.format(rank)),
+             v_on=on[0], p_on=on[1], v_off=off[0], p_off=off[1],
+             its=[on[2], off[2]], c_on=on[3], c_off=off[3])
+    cm.close()
+    dist.destroy_process_group()
+
+
+def test_convection_cells_in_the_lazy_tail_over_two_ranks(tmp_path):
+    """the cells of the new velocity evaluated by the tail of a one-step cycle
+    (from the copied warm start and Z_0, own rows AND halo) are the cells the
+    cell kernel computes from the new solution: two ranks, tail on / off --
+    bitwise the same trajectories, both ranks equal, and the single-GPU run's"""
+    from dolfin_navier_scipy_amd import saddle
+    from spawn_util import spawn_ranks
+    spawn_ranks(_worker_dtail, 2, str(tmp_path))
+    r0 = np.load(tmp_path / 'dtail_rank0.npz')
+    r1 = np.load(tmp_path / 'dtail_rank1.npz')
+    built, tail_cells, reused = [int(c) for c in r0['c_on']]
+    print('two ranks, 40 steps: tail evaluated the cells in', tail_cells,
+          'steps, the front left its cell kernel out in', reused, 'of', built,
+          '; Krylov steps', list(r0['its']))
+    assert tail_cells >= 10 and reused >= 10, (built, tail_cells, reused)
+    assert [int(c) for c in r0['c_off']][1:] == [0, 0]
+    for key in ('v_on', 'p_on', 'v_off', 'p_off'):
+        assert np.array_equal(r0[key], r1[key]), key
+    assert np.array_equal(r0['v_on'], r0['v_off'])
+    assert np.array_equal(r0['p_on'], r0['p_off'])
+    v1, p1, _, _ = _dtail_steps(saddle, None, True)
+    assert np.linalg.norm(r0['v_on'] - v1) <= 1e-6*np.linalg.norm(v1)
+    assert np.linalg.norm(r0['p_on'] - p1) <= 1e-5*np.linalg.norm(p1)
