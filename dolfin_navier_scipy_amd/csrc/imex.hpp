@@ -9,6 +9,12 @@ struct dns_imex {
     dns_saddle *sys = nullptr;
     dns::CsrDev R1;                // all rows, or this rank's (partitioned)
     dns::HostCsr R1h;              // host copy (row blocks are cut from it)
+    // pair format of R1 (2x2 node blocks, pair.hpp) for the streamed
+    // right-hand-side product of the bandwidth regime: R1 = M - theta dt A has
+    // the block structure of F (8.5 instead of 10 bytes per non-zero, a third
+    // of the gather addresses); absent when R1 is not streamed or NV is odd
+    dns::PairDev R1p;
+    int build_r1_pair(const dns::HostCsr &rows, int v0);
     // row-partitioned system (dist_solve.inc): the right-hand side is formed
     // for this rank's rows only -- R1 by rows, the convection from the cells
     // that touch them -- and the solution's halo entries are exchanged by
@@ -157,7 +163,7 @@ struct dns_imex {
     int batch_len = 8;             // steps per batch: 8 -> 16 -> 32 while the
                                    // predictions hold
     uint64_t prepared_sig = 0;     // configuration the graphs were captured for
-    int chi_hi = 0;                // longest cycle length they cover (monotone)
+    int chi_hi = 0;                // longest cycle length they cover (with hysteresis)
     // record of the last dns_imex_run (dns_imex_run_info)
     int run_unconverged = 0, run_first_bad = -1, run_replayed = 0;
     int run_captures = 0;          // graphs captured inside the last run
