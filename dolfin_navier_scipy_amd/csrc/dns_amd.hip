@@ -103,6 +103,8 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
         DNS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     }
     if (const char *sn = getenv("DNS_STREAM_NNZ")) stream_nnz = atoll(sn);
+    if (const char *sn = getenv("DNS_STREAM_GRID"))
+        sgrid = std::max(64, std::min(atoi(sn), 16384));
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
     if (const char *sn = getenv("DNS_MG_FUSED")) mg_fused_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
@@ -210,7 +212,7 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     gridD = (int)std::max<int64_t>(1, std::min<int64_t>((n + kBlock - 1) / kBlock,
                                                        1024));
     const size_t pmax =
-        (size_t)std::max(std::max(std::max(gridS, gridD), nred), kStreamGrid);
+        (size_t)std::max(std::max(std::max(gridS, gridD), nred), sgrid);
     DNS_TRY(partA.alloc((size_t)(kMaxRestart + 2) * pmax));
     DNS_TRY(partE.alloc((size_t)(kMaxRestart + 1) * pmax));
     DNS_TRY(partN.alloc(pmax));
@@ -1366,16 +1368,16 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
         ep.part = partR.p;
         ep.nvec = 0;
         ep.with_ww = 1;
-        resid_np = Kp.ready ? pair_grid(Kp, kStreamGrid)
-                            : stream_grid(K, kStreamGrid);
+        resid_np = Kp.ready ? pair_grid(Kp, sgrid)
+                            : stream_grid(K, sgrid);
         ep.nparts = resid_np;
         ep.part_bb = partB.p;
         if (Kp.ready)
             DNS_TRY(launch_pair16x(Kp, x, r.p, ep, stream, nullptr,
-                                   kStreamGrid));
+                                   sgrid));
         else
             DNS_TRY(launch_stream16x<double>(K, K.vals.p, x, r.p, ep, stream,
-                                             nullptr, kStreamGrid));
+                                             nullptr, sgrid));
     } else if (!have_resid) {
         DNS_LPR_SWITCH(
             K.lpr, hipLaunchKernelGGL(k_resid_norm<L>, gridS, kBlock, 0, stream,
@@ -1397,8 +1399,8 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
     // (while they fit its accumulators)
     const bool stream_k = streams(K);
     const bool fusedgs = o->reorth == 2 && (fuse_dots || stream_k);
-    const int gridK = stream_k ? (Kp.ready ? pair_grid(Kp, kStreamGrid)
-                                           : stream_grid(K, kStreamGrid))
+    const int gridK = stream_k ? (Kp.ready ? pair_grid(Kp, sgrid)
+                                           : stream_grid(K, sgrid))
                                : gridC;
     // partials the consumers of step j's dots read: written by the kernel
     // that applied K in step j
@@ -1541,11 +1543,11 @@ int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
             ep.nparts = gridK;
             if (Kp.ready)
                 DNS_TRY(launch_pair16x(Kp, zj, w.p, ep, stream, done_ptr(),
-                                       kStreamGrid));
+                                       sgrid));
             else
                 DNS_TRY(launch_stream16x<double>(K, K.vals.p, zj, w.p, ep,
                                                  stream, done_ptr(),
-                                                 kStreamGrid));
+                                                 sgrid));
             continue;                    // no Gram-Schmidt kernel
         } else if (fuse_dots || fusedgs) {
             DNS_LPR_SWITCH(

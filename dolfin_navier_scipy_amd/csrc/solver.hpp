@@ -366,6 +366,9 @@ struct dns_saddle {
     // matrices with at least this many non-zeros go through the LDS-streaming
     // kernels (bandwidth regime); below, the sub-wave kernels (latency regime)
     int64_t stream_nnz = 1300000;
+    // workgroups (= partials per scalar) of a streaming launch with reductions
+    // (fused dots, residual norms): DNS_STREAM_GRID / option `stream_grid`
+    int sgrid = dns::kStreamGrid;
     bool streams(const dns::CsrDev &A) const {
         return A.nnz >= stream_nnz && A.c16.p != nullptr;
     }
