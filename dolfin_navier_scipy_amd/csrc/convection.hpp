@@ -235,7 +235,8 @@ struct dns_conv {
                               const double *avals, double tdt, double *fvals,
                               double *rhsbc, const double *fv,
                               const double *rhscon, double *fvn,
-                              hipStream_t s);
+                              hipStream_t s, const int *kpos = nullptr,
+                              double *kvals = nullptr);
     // element kernel alone (the gather is fused into the step prologue)
     int enqueue_cells(const double *v_dev, hipStream_t s,
                       const int *sel = nullptr, int nsel = 0) {
@@ -421,14 +422,23 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
                      const int *__restrict__ bbc, TabRef dbctab,
                      double *__restrict__ rhsbc, const double *__restrict__ fv,
                      const double *__restrict__ rhscon,
-                     double *__restrict__ fvn) {
+                     double *__restrict__ fvn,
+                     const int *__restrict__ kpos = nullptr,
+                     double *__restrict__ kvals = nullptr) {
+    // kpos / kvals: the new value of F goes straight into its place in the
+    // assembled K = [[F, JT], [J, 0]] as well (a scatter kernel of its own
+    // before)
     if ((int)blockIdx.x < gm) {
         for (int z = blockIdx.x * kBlock + threadIdx.x; z < nnz;
              z += gm * kBlock) {
             double s = 0.0;
             for (int k = mptr[z]; k < mptr[z + 1]; ++k) s += L[midx[k]];
             nvals[z] = s;
-            if (fvals) fvals[z] = mvals[z] + tdt * (avals[z] + s);
+            if (fvals) {
+                const double f = mvals[z] + tdt * (avals[z] + s);
+                fvals[z] = f;
+                if (kvals) kvals[kpos[z]] = f;
+            }
         }
         return;
     }
@@ -481,7 +491,8 @@ inline int dns_conv::enqueue_mat_bc_gather(double *nvals, const double *mvals,
                                            double *fvals, double *rhsbc,
                                            const double *fv,
                                            const double *rhscon, double *fvn,
-                                           hipStream_t s) {
+                                           hipStream_t s, const int *kpos,
+                                           double *kvals) {
     const int gm = std::max(1, std::min((mat->nnz + dns::kBlock - 1) /
                                             dns::kBlock, 4096));
     const int gb = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
@@ -490,7 +501,7 @@ inline int dns_conv::enqueue_mat_bc_gather(double *nvals, const double *mvals,
                        gm, mat->nnz, mat->mptr.p, mat->midx.p, mat->L.p, nvals,
                        mvals, avals, tdt, fvals, nv_inner, mat->bptr.p,
                        mat->bidx.p, mat->bbc.p, dbc_ref(), rhsbc, fv, rhscon,
-                       fvn);
+                       fvn, kpos, kvals);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

@@ -275,7 +275,7 @@ int dns_saddle::ensure_F_device() {
     return DNS_OK;
 }
 
-int dns_saddle::device_values_changed() {
+int dns_saddle::device_values_changed(bool k_current) {
     if (dist_sliced) {
         if (!dd || F.nnz == 0)
             return fail(DNS_ERR_NOT_READY, "sliced handle without its F block");
@@ -301,8 +301,10 @@ int dns_saddle::device_values_changed() {
     }
     if (Kp.ready) drop_graphs();
     Kp.release_all();
-    hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
-                       stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p, K.vals.p);
+    if (!k_current)
+        hipLaunchKernelGGL(k_scatter_fvals, grid_for_rows(nv, 8), kBlock, 0,
+                           stream, nv, F.rowptr.p, K.rowptr.p, F.vals.p,
+                           K.vals.p);
     if (fhat_explicit && precond_ready)
         dinv_stale = true;
     else

@@ -554,7 +554,8 @@ struct dns_saddle {
     bool dinv_stale = false;          // ... and 1/diag(F) was not refreshed
                                       // (explicit Fh^-1: nobody reads it
                                       // between two set-ups)
-    int device_values_changed();
+    // (k_current: the caller's kernel has written the new values into K too)
+    int device_values_changed(bool k_current = false);
     int ensure_F_device();            // a sliced handle gets its F block back
     int dist_v0() const;              // this rank's velocity rows [v0, v1)
     int dist_v1() const;

@@ -65,6 +65,55 @@ k_trap_acc(const double *__restrict__ partials, int nparts, double scale,
     if (threadIdx.x == 0) acc[0] += scale * s;
 }
 
+// Partial sums of d^T M d, d = x - y -- the M-norm of the Newton update,
+// dt ||v_n - v_lin||_M^2 (snu:1557-1560) -- one partial per workgroup: d is
+// formed in the gather, the row is walked once (four kernels before: d, M d,
+// dot partials, accumulate).  copy_out: x is stored there on the way (the new
+// velocity into its trajectory slot, snu:1012-1014).
+template <int LPR>
+__global__ void __launch_bounds__(kBlock)
+k_trap_updnorm(int nv, const int *__restrict__ rowptr,
+               const int *__restrict__ colidx, const double *__restrict__ mvals,
+               const double *__restrict__ x, const double *__restrict__ y,
+               double *__restrict__ part, double *__restrict__ copy_out) {
+    __shared__ double red[4];
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = gridDim.x * (kBlock / LPR);
+    double acc = 0.0;
+    for (int row = sub; row < nv; row += nsub) {
+        double s = 0.0;
+        const int k1 = rowptr[row + 1];
+        for (int k = rowptr[row] + sublane; k < k1; k += LPR) {
+            const int c = colidx[k];
+            s = fma(mvals[k], x[c] - y[c], s);
+        }
+        s = subwave_sum<LPR>(s);
+        if (sublane == 0) {
+            const double xr = x[row];
+            acc = fma(xr - y[row], s, acc);
+            if (copy_out) copy_out[row] = xr;
+        }
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// kpos[z] = where the z-th non-zero of F sits in the assembled K (velocity
+// rows of K start with the row of F)
+__global__ void __launch_bounds__(kBlock)
+k_trap_kpos(int nv, const int *__restrict__ f_rowptr,
+            const int *__restrict__ k_rowptr, int *__restrict__ kpos) {
+    const int sub = (blockIdx.x * kBlock + threadIdx.x) / 8;
+    const int sl = threadIdx.x % 8;
+    const int nsub = gridDim.x * (kBlock / 8);
+    for (int row = sub; row < nv; row += nsub) {
+        const int f0 = f_rowptr[row], f1 = f_rowptr[row + 1];
+        const int k0 = k_rowptr[row];
+        for (int k = f0 + sl; k < f1; k += 8) kpos[k] = k0 + (k - f0);
+    }
+}
+
 // d = x - y
 __global__ void __launch_bounds__(kBlock)
 k_trap_diff(int n, const double *__restrict__ x, const double *__restrict__ y,
@@ -108,6 +157,15 @@ struct dns_trap {
     dns::DevBuf<double> fv_tab, fp_tab, mbc_tab;
     bool have_fv_tab = false, have_fp_tab = false, have_mbc_tab = false;
     int cur_slot = 0;                          // time instance of xs[cur]
+    // the work buffer holds this step's warm start already: the tail kernel of
+    // the step before wrote it (dns::TailExtrap) for `pre_sig` = 8 nsol + order
+    // and the step size `pre_dt`
+    bool pre_ok = false;
+    int pre_sig = -1;
+    double pre_dt = 0.0;
+    // position of every non-zero of F in the assembled K (un-partitioned
+    // handle): the assembly kernel writes both
+    dns::DevBuf<int> kpos;
     const double *fv_at(int slot) const {
         return have_fv_tab ? fv_tab.p + (size_t)slot * sys->nv : fv.p;
     }
