@@ -40,11 +40,19 @@ k_trap_rhs(int nv, int np, const int *__restrict__ rowptr,
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
+    // ncvals == nullptr: the convection part of C_c v_c has gone into fvn_c
+    // as the convection VECTOR (dns_trap::assemble_current)
     for (int row = sub; row < nv; row += nsub) {
         double s = 0.0;
         const int k1 = rowptr[row + 1];
-        for (int k = rowptr[row] + sublane; k < k1; k += LPR)
-            s = fma(mvals[k] - hdt * (avals[k] + ncvals[k]), v_c[colidx[k]], s);
+        if (ncvals) {
+            for (int k = rowptr[row] + sublane; k < k1; k += LPR)
+                s = fma(mvals[k] - hdt * (avals[k] + ncvals[k]),
+                        v_c[colidx[k]], s);
+        } else {
+            for (int k = rowptr[row] + sublane; k < k1; k += LPR)
+                s = fma(mvals[k] - hdt * avals[k], v_c[colidx[k]], s);
+        }
         s = subwave_sum<LPR>(s);
         if (sublane == 0) b[row] = s + hdt * (fvn_n[row] + fvn_c[row]);
     }
@@ -99,6 +107,20 @@ k_trap_updnorm(int nv, const int *__restrict__ rowptr,
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 
+// f_c - N_c v_c without the matrix: fvn_c = fv - N(v_c) v_c, the gather of the
+// convection cell values along the rows (inverted index of dns_conv)
+__global__ void __launch_bounds__(kBlock)
+k_trap_fc(int nv, const int *__restrict__ gptr, const int *__restrict__ gidx,
+          const double *__restrict__ cellvals, const double *__restrict__ fv,
+          double *__restrict__ fvn_c) {
+    for (int r = blockIdx.x * kBlock + threadIdx.x; r < nv;
+         r += gridDim.x * kBlock) {
+        double s = 0.0;
+        for (int k = gptr[r]; k < gptr[r + 1]; ++k) s += cellvals[gidx[k]];
+        fvn_c[r] = fv[r] - s;
+    }
+}
+
 // kpos[z] = where the z-th non-zero of F sits in the assembled K (velocity
 // rows of K start with the row of F)
 __global__ void __launch_bounds__(kBlock)
@@ -129,7 +151,7 @@ struct dns_trap {
     dns_saddle *sys = nullptr;
     dns_conv *conv = nullptr;
     int nslots = 0;
-    dns::DevBuf<double> mvals, avals, nc_vals, nn_vals;
+    dns::DevBuf<double> mvals, avals, nn_vals;
     dns::DevBuf<double> xs[5];                 // ring of [v; p~] solutions
     int cur = 0, prev = 1, pprev = 2, p3 = 3, work = 4;
     int nsol = 0;
