@@ -152,8 +152,8 @@ struct dns_trap {
     dns_conv *conv = nullptr;
     int nslots = 0;
     dns::DevBuf<double> mvals, avals, nn_vals;
-    dns::DevBuf<double> xs[5];                 // ring of [v; p~] solutions
-    int cur = 0, prev = 1, pprev = 2, p3 = 3, work = 4;
+    dns::DevBuf<double> xs[6];                 // ring of [v; p~] solutions
+    int cur = 0, prev = 1, pprev = 2, p3 = 3, p4 = 4, work = 5;
     int nsol = 0;
     dns::DevBuf<double> fv, fp, fvn_c, fvn_n, rhsbc, rhscon, b, dtmp, mtmp;
     dns::DevBuf<double> traj[2];
@@ -212,7 +212,7 @@ struct dns_trap {
     // checkpoint of the ring (a pipelined batch that did not converge within
     // its cycle length is repeated from here): the three solutions behind
     // `cur`, the host's bookkeeping; N_c / f_c are re-assembled on restore
-    dns::DevBuf<double> ck[4];
+    dns::DevBuf<double> ck[5];
     struct {
         bool valid = false;
         int nsol = 0, cur_slot = 0;

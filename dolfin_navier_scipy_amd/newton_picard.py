@@ -211,7 +211,7 @@ class TrapezoidalStepper(object):
         C.check(self.lib.dns_trap_start(self._h, C.dptr(v), int(bool(newton))))
 
     def step(self, dt, lin_which, lin_slot, out_slot, newton, opts=None,
-             extrapolate=3, raise_on_fail=True, feedback=None):
+             extrapolate=4, raise_on_fail=True, feedback=None):
         """`feedback=(umat (NV, r), vmat_c (r, NV) or None, vmat_n (r, NV))`:
         the low-rank terms of `_get_mats_rhs_ts` (snu:1036-1042) -- system
         `F - dt/2 U V_n` by Sherman-Morrison-Woodbury, rhs `+ dt/2 U V_c v_c`"""
@@ -279,7 +279,7 @@ class TrapezoidalStepper(object):
         self.system.setup_precond(**self._pkw)
         self.refreshes += 1
 
-    def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=3,
+    def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=4,
               record=True, pipeline=True, batch=None):
         """one sweep over `trange` linearised about trajectory `lin_which`
         (slot k <-> trange[k]); the new velocities go to the other trajectory.
@@ -406,7 +406,7 @@ def time_sections(trange, nsects=1, addfullsweep=False):
 
 def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
                   vel_nwtn_stps=2, vel_nwtn_tol=1e-14, opts=None,
-                  extrapolate=3, rhs_table=None, nsects=1,
+                  extrapolate=4, rhs_table=None, nsects=1,
                   loc_nwtn_tol=5e-15, loc_pcrd_stps=True, addfullsweep=False,
                   tables=None):
     """Picard sweeps first, then Newton sweeps, each linearised about the

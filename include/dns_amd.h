@@ -505,11 +505,17 @@ int dns_conv_assemble2(dns_conv *cv, const double *u_inner,
  * block (to which `conv` must be bound); two trajectory buffers of `nslots`
  * velocities each hold the linearisation points of the running sweep
  * (`which`) and the velocities it produces (`1 - which`).
- *   start : v_c = iniv, N_c and f_c assembled there, update norm reset
+ *   start : v_c = iniv, f_c - N_c v_c evaluated there, update norm reset
  *   step  : one step of size dt linearised about traj[lin_which][lin_slot];
  *           F = M + dt/2 (A + N_n) is formed on the device inside `sys`
  *           (same pattern, preconditioner kept); result -> traj[1-lin_which]
- *           [out_slot] (out_slot < 0: not stored)
+ *           [out_slot] (out_slot < 0: not stored).  `extrapolate_x0` = order
+ *           of the warm start from the last solutions, 0 .. 4 as in
+ *           dns_imex_coeffs (the reference's `krylovini='upd'` is order 1,
+ *           snu:1493-1503).  The part of the right-hand side that depends on
+ *           the current velocity through the convection, f_c - N_c v_c, is
+ *           evaluated as fv - N(v_c)v_c (N1(u)u = N2(u)u = N(u)u): no second
+ *           matrix assembly per step
  *   get_state: v_c and p = -p~/dt (snu:1542)
  *   update_norm: sum of dt ||v_n - v_lin||_M^2 since `start` (snu:1557-1560)
  */

@@ -28,7 +28,7 @@ from dolfin_navier_scipy_amd import newton_picard as dnp  # noqa: E402
 def main():
     nsteps = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     rtol = float(sys.argv[2]) if len(sys.argv) > 2 else tnp.SWEEP_RTOL
-    extrap = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    extrap = int(sys.argv[3]) if len(sys.argv) > 3 else 4
     s = tnp.shedding_setup(nsteps)
     femp, sm, rhsd, vs, dt = s['femp'], s['sm'], s['rhsd'], s['vs'], s['dt']
     th, inv = femp['V'], femp['invinds']

@@ -58,7 +58,7 @@ def main():
     spinup = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
     rtol = float(sys.argv[3]) if len(sys.argv) > 3 else 1e-10
     bound = float(sys.argv[4]) if len(sys.argv) > 4 else 3.0
-    extrap = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+    extrap = int(sys.argv[5]) if len(sys.argv) > 5 else 4
     dt = 1./512
     femp, sm, rhsd = bench.build_problem(N=2, Re=100.)
     M, A, J = sm['M'], sm['A'], sm['J']

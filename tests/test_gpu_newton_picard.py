@@ -469,8 +469,7 @@ def test_sweeps_over_2048_steps_of_developed_shedding(shedding):
     which, lindict = 0, lin
     for name, picard in (('picard', True), ('newton', False)):
         t0 = time.perf_counter()
-        got_v, got_p, upd, st = stp.sweep(tr, vs[0], which, picard, opts=opts,
-                                          extrapolate=3)
+        got_v, got_p, upd, st = stp.sweep(tr, vs[0], which, picard, opts=opts)
         t_gpu = time.perf_counter() - t0
         t0 = time.perf_counter()
         wv, wp = against_oracle(got_v, got_p, lindict, picard)
