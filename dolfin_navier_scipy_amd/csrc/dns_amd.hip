@@ -2126,24 +2126,26 @@ static int dns_saddle_solve_multi_impl(dns_saddle *h, int32_t ncols,
     DNS_TRY(h->msol.zero(h->stream));
     {
         // the caller's blocks are borrowed for the whole call: the copies are
-        // only enqueued, ONE wait for all of them (on every way out)
+        // only enqueued, ONE wait for all of them (on every way out).  Plain
+        // 1-D copies, column by column: a pitched hipMemcpy2DAsync out of
+        // pageable host memory faulted the GPU at a host heap address
+        // (intermittently, gpurun_out/r4_t: its blit reads past the rows it
+        // was given); the 1-D path is the one every other upload takes
         SyncOnExit arrived(h->stream);
-        DNS_HIP(hipMemcpy2DAsync(h->mrhs.p, ld * sizeof(double), rhs_v,
-                                 nv * sizeof(double), nv * sizeof(double), k,
-                                 hipMemcpyHostToDevice, h->stream));
-        if (rhs_p && np > 0)
-            DNS_HIP(hipMemcpy2DAsync(h->mrhs.p + nv, ld * sizeof(double), rhs_p,
-                                     np * sizeof(double), np * sizeof(double),
-                                     k, hipMemcpyHostToDevice, h->stream));
-        if (x0_cols > 1)
-            DNS_HIP(hipMemcpy2DAsync(h->msol.p, ld * sizeof(double), x0,
-                                     n * sizeof(double), n * sizeof(double), k,
-                                     hipMemcpyHostToDevice, h->stream));
-        else if (x0_cols == 1)
-            for (size_t c = 0; c < k; ++c)
-                DNS_HIP(hipMemcpyAsync(h->msol.p + c * ld, x0,
+        for (size_t c = 0; c < k; ++c) {
+            DNS_HIP(hipMemcpyAsync(h->mrhs.p + c * ld, rhs_v + c * nv,
+                                   nv * sizeof(double), hipMemcpyHostToDevice,
+                                   h->stream));
+            if (rhs_p && np > 0)
+                DNS_HIP(hipMemcpyAsync(h->mrhs.p + c * ld + nv, rhs_p + c * np,
+                                       np * sizeof(double),
+                                       hipMemcpyHostToDevice, h->stream));
+            if (x0_cols > 0)
+                DNS_HIP(hipMemcpyAsync(h->msol.p + c * ld,
+                                       x0 + (x0_cols > 1 ? c * n : 0),
                                        n * sizeof(double),
                                        hipMemcpyHostToDevice, h->stream));
+        }
     }
     h->col_history.assign(k, std::vector<double>());
     int worst = DNS_OK;
@@ -2155,10 +2157,13 @@ static int dns_saddle_solve_multi_impl(dns_saddle *h, int32_t ncols,
         h->col_history[c] = h->history;
         if (st->status != DNS_OK && worst == DNS_OK) worst = st->status;
     }
-    DNS_HIP(hipMemcpy2DAsync(out_vp, n * sizeof(double), h->msol.p,
-                             ld * sizeof(double), n * sizeof(double), k,
-                             hipMemcpyDeviceToHost, h->stream));
-    DNS_HIP(hipStreamSynchronize(h->stream));
+    {
+        SyncOnExit arrived(h->stream);
+        for (size_t c = 0; c < k; ++c)
+            DNS_HIP(hipMemcpyAsync(out_vp + c * n, h->msol.p + c * ld,
+                                   n * sizeof(double), hipMemcpyDeviceToHost,
+                                   h->stream));
+    }
     (void)worst;       // (per-column statuses are in `stats`, like the single solve)
     return DNS_OK;
 }
