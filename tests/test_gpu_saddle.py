@@ -281,6 +281,31 @@ def test_multi_column_solve_is_the_column_by_column_solve(sad, small):
     system.close()
 
 
+def test_multi_column_solve_many_calls_of_changing_width(sad, small):
+    """blocks of 1..7 columns, 120 calls on one resident system, host arrays
+    that die right behind the call (the block copies of the boundary: a pitched
+    2-D copy out of pageable memory once faulted the GPU here)"""
+    F, J = small['F'], small['J']
+    NP, NV = J.shape
+    rng = np.random.default_rng(5)
+    system = sad.SaddleSystem(F, J)
+    system.setup_precond(cheb_degree=4, schur='dense')
+    ref = {}
+    for call in range(120):
+        k = 1 + call % 7
+        RV = small['M'] @ rng.standard_normal((NV, k))
+        RP = 1e-3*rng.standard_normal((NP, k)) if call % 3 else None
+        X = system.solve_multi(RV, RP, rtol=1e-10, use_graph=True)
+        assert X.shape == (NV + NP, k)
+        if call % 20 == 0:
+            for c in range(k):
+                rp = None if RP is None else RP[:, c]
+                ref = system.solve(RV[:, c], rp, rtol=1e-10, use_graph=True)
+                assert np.array_equal(ref, X[:, c])
+        del RV, RP, X
+    system.close()
+
+
 def test_zero_rhs_and_no_rhsp(sad, small):
     system = sad.SaddleSystem(small['F'], small['J'])
     system.setup_precond(cheb_degree=3, schur='dense')
