@@ -87,6 +87,20 @@ def bandwidth_ladder(world):
     return BANDWIDTH_LADDER[best]
 
 
+def ladder_rtol(rtol, nts0, nts):
+    """Krylov tolerance of a weak-ladder leg: the N=1 workload's own, and for
+    the finer meshes (smaller dt) a tolerance that follows the time step --
+    `p = -p~/dt` amplifies a solve's residual by 1/dt, and at the N=1 tolerance
+    those meshes sit ON the edge of one Krylov step per time step (some steps
+    need none, the others end at 0.9 x the tolerance): the slack step of the
+    cycle stays, the one-step cycle with its single all-reduce is never taken
+    (level 3: 10.5k against 15.9k steps/s on one rank, p parity 7.5e-9 against
+    4.1e-10; `profiles/r04_partitioned/ladder_meshes_one_rank.txt`)"""
+    if nts <= nts0:
+        return rtol
+    return min(rtol, 3e-11*1024./nts)
+
+
 def weak_ladder(world):
     """the mesh whose size relative to the N=1 workload is closest to the
     number of ranks (rows per rank ~ constant)"""
@@ -880,8 +894,8 @@ def multi_gpu_main(args, world, rank, local_rank):
         dist.init_process_group('gloo')
         dist.barrier()
     base_port = int(os.environ.get('MASTER_PORT', '29500'))
-    common = ['--Re', str(args.Re), '--cheb', str(args.cheb), '--rtol',
-              str(args.rtol), '--extrap', str(args.extrap), '--fp32',
+    common = ['--Re', str(args.Re), '--cheb', str(args.cheb),
+              '--extrap', str(args.extrap), '--fp32',
               str(args.fp32), '--drop', str(args.drop), '--fhat', args.fhat,
               '--fact', args.fact, '--reorth', str(args.reorth),
               '--check-every', str(args.check_every), '--carry',
@@ -916,14 +930,16 @@ def multi_gpu_main(args, world, rank, local_rank):
         dist.broadcast(t, 0)
         return int(t.item()), held
 
-    def partitioned(port_offset, level, refine, nts, start, timeout=None):
+    def partitioned(port_offset, level, refine, nts, start, timeout=None,
+                    rtol=None):
         timeout = args.partitioned_timeout if timeout is None else timeout
+        rtol = args.rtol if rtol is None else rtol
         cmd = [sys.executable, os.path.abspath(__file__), '--partitioned-only',
                '--gpus', str(world), '--steps', str(args.steps), '--warmup',
                str(args.warmup), '--spinup', str(args.spinup), '--level',
                str(level), '--refine', str(refine), '--nts', str(nts),
                '--dense-max', str(args.dense_max), '--partitioned-timeout',
-               str(timeout), '--start', start] + common
+               str(timeout), '--start', start, '--rtol', str(rtol)] + common
         tries = [0]
 
         def attempt(extra_env):
@@ -964,7 +980,8 @@ def multi_gpu_main(args, world, rank, local_rank):
     # latency-regime legs start from the steady Stokes state like the N=1
     # headline; the bandwidth ladder starts from rest on every N (its N=1
     # point, `refined_bench.run`, does too)
-    weak = partitioned(17, level, refine, nts_w, 'stokes')
+    weak = partitioned(17, level, refine, nts_w, 'stokes',
+                       rtol=ladder_rtol(args.rtol, args.nts, nts_w))
     # the same loop in the bandwidth regime (>= 7e5 rows per rank)
     bandwidth = None
     if not args.no_bandwidth:
@@ -995,7 +1012,7 @@ def multi_gpu_main(args, world, rank, local_rank):
                '--nts', str(args.nts), '--device',
                '0' if one_gpu else str(local_rank), '--no-cpu', '--no-refined',
                '--no-picard', '--roofline-refine', '0', '--no-force-dist',
-               '--no-window-400'] + common
+               '--no-window-400', '--rtol', str(args.rtol)] + common
         dist.barrier()
         one = run_child(cmd, env, args.partitioned_timeout, True)
         ms = torch.tensor([one.get('ms_per_step', float('inf'))
