@@ -559,17 +559,32 @@ k_arn_tail6(int c, int n, int nrow_blocks,
         cq = t & 7;
         clive = cslot < tc.ncells;
         ccell = clive ? cslot : 0;
+        // one lane per slot asks the memory (lane q of the cell's eight: slots
+        // q and q + 8), shuffles hand map entries and values round: 6 loads
+        // per lane instead of 36 in front of the element arithmetic
+        const int lane0 = (threadIdx.x & 63) & ~7;
+        const int m_a = tc.cellmap[(size_t)cq * tc.ncells + ccell];
+        const int m_b =
+            (cq < 4) ? tc.cellmap[(size_t)(cq + 8) * tc.ncells + ccell] : -1;
+        const double x_a = (m_a >= 0) ? t6.x0[m_a] : dbcvals[-m_a - 1];
+        const double z_a = (m_a >= 0 && c > 0) ? Z[m_a] : 0.0;
+        double x_b = 0.0, z_b = 0.0;
+        if (cq < 4) {
+            x_b = (m_b >= 0) ? t6.x0[m_b] : dbcvals[-m_b - 1];
+            z_b = (m_b >= 0 && c > 0) ? Z[m_b] : 0.0;
+        }
 #pragma unroll
-        for (int k = 0; k < 12; ++k)
-            cmap[k] = tc.cellmap[(size_t)k * tc.ncells + ccell];
+        for (int k = 0; k < 8; ++k) {
+            cmap[k] = __shfl(m_a, lane0 + k, 64);
+            u0[k >> 1][k & 1] = __shfl(x_a, lane0 + k, 64);
+            uz[k >> 1][k & 1] = __shfl(z_a, lane0 + k, 64);
+        }
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = cmap[2 * a + i];
-                u0[a][i] = (m >= 0) ? t6.x0[m] : dbcvals[-m - 1];
-                uz[a][i] = (m >= 0 && c > 0) ? Z[m] : 0.0;
-            }
+        for (int k = 8; k < 12; ++k) {
+            cmap[k] = __shfl(m_b, lane0 + k - 8, 64);
+            u0[k >> 1][k & 1] = __shfl(x_b, lane0 + k - 8, 64);
+            uz[k >> 1][k & 1] = __shfl(z_b, lane0 + k - 8, 64);
+        }
     }
     if (rowblk && ef < n) {
         pfx = t6.x0[ef];
@@ -875,14 +890,28 @@ k_arn_tail_lazy1(int n, const double *__restrict__ hs, DnsCtl *ctl,
         cq = t & 7;
         clive = tc.sel ? cslot < tc.nsel : cslot < tc.ncells;
         ccell = clive ? (tc.sel ? tc.sel[cslot] : cslot) : 0;
+        // (one lane per slot asks the memory, as in k_arn_tail6)
+        const int lane0 = (threadIdx.x & 63) & ~7;
+        const int m_a = tc.cellmap[(size_t)cq * tc.ncells + ccell];
+        const int m_b =
+            (cq < 4) ? tc.cellmap[(size_t)(cq + 8) * tc.ncells + ccell] : -1;
+        const double x_a = (m_a >= 0) ? x0copy[m_a] : dbcvals[-m_a - 1];
+        const double z_a = (m_a >= 0) ? Z[m_a] : 0.0;
+        double x_b = 0.0, z_b = 0.0;
+        if (cq < 4) {
+            x_b = (m_b >= 0) ? x0copy[m_b] : dbcvals[-m_b - 1];
+            z_b = (m_b >= 0) ? Z[m_b] : 0.0;
+        }
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+        for (int k = 0; k < 8; ++k) {
+            u0[k >> 1][k & 1] = __shfl(x_a, lane0 + k, 64);
+            uz[k >> 1][k & 1] = __shfl(z_a, lane0 + k, 64);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int m = tc.cellmap[(size_t)(2 * a + i) * tc.ncells + ccell];
-                u0[a][i] = (m >= 0) ? x0copy[m] : dbcvals[-m - 1];
-                uz[a][i] = (m >= 0) ? Z[m] : 0.0;
-            }
+        for (int k = 8; k < 12; ++k) {
+            u0[k >> 1][k & 1] = __shfl(x_b, lane0 + k - 8, 64);
+            uz[k >> 1][k & 1] = __shfl(z_b, lane0 + k - 8, 64);
+        }
     } else if (ef < n) {
         pfx = x[ef];
         pz0 = Z[ef];
