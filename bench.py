@@ -87,20 +87,6 @@ def bandwidth_ladder(world):
     return BANDWIDTH_LADDER[best]
 
 
-def ladder_rtol(rtol, nts0, nts):
-    """Krylov tolerance of a weak-ladder leg: the N=1 workload's own, and for
-    the finer meshes (smaller dt) a tolerance that follows the time step --
-    `p = -p~/dt` amplifies a solve's residual by 1/dt, and at the N=1 tolerance
-    those meshes sit ON the edge of one Krylov step per time step (some steps
-    need none, the others end at 0.9 x the tolerance): the slack step of the
-    cycle stays, the one-step cycle with its single all-reduce is never taken
-    (level 3: 10.5k against 15.9k steps/s on one rank, p parity 7.5e-9 against
-    4.1e-10; `profiles/r04_partitioned/ladder_meshes_one_rank.txt`)"""
-    if nts <= nts0:
-        return rtol
-    return min(rtol, 3e-11*1024./nts)
-
-
 def weak_ladder(world):
     """the mesh whose size relative to the N=1 workload is closest to the
     number of ranks (rows per rank ~ constant)"""
@@ -980,8 +966,7 @@ def multi_gpu_main(args, world, rank, local_rank):
     # latency-regime legs start from the steady Stokes state like the N=1
     # headline; the bandwidth ladder starts from rest on every N (its N=1
     # point, `refined_bench.run`, does too)
-    weak = partitioned(17, level, refine, nts_w, 'stokes',
-                       rtol=ladder_rtol(args.rtol, args.nts, nts_w))
+    weak = partitioned(17, level, refine, nts_w, 'stokes')
     # the same loop in the bandwidth regime (>= 7e5 rows per rank)
     bandwidth = None
     if not args.no_bandwidth:
