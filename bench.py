@@ -1168,7 +1168,7 @@ def main():
     ap.add_argument('--partitioned-only', action='store_true',
                     help='(internal) one row-partitioned simulation on the '
                     'ranks of this launch; prints its figures')
-    ap.add_argument('--partitioned-timeout', type=float, default=300.,
+    ap.add_argument('--partitioned-timeout', type=float, default=420.,
                     help='time limit [s] of a row-partitioned child run')
     ap.add_argument('--dry-run', action='store_true',
                     help='(tests) the child processes of a multi-rank launch '
