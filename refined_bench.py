@@ -56,7 +56,7 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True,
     cf = saddle.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
                                    pscale=-1./dt, extrapolate=4)
     opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=graph,
-                             reorth=2)
+                             reorth=int(os.environ.get('MG_REORTH', '2')))
     # untimed steps between the start from rest (inflow switched on at t=0) and
     # the timed window: like bench.py's --spinup the window then samples the
     # run, not the first instants of the start-up transient
