@@ -244,7 +244,8 @@ struct dns_conv {
                               double *rhsbc, const double *fv,
                               const double *rhscon, double *fvn,
                               hipStream_t s, const int *kpos = nullptr,
-                              double *kvals = nullptr);
+                              double *kvals = nullptr,
+                              bool rhscon_from_cells = false);
     // element kernel alone (the gather is fused into the step prologue)
     int enqueue_cells(const double *v_dev, hipStream_t s,
                       const int *sel = nullptr, int nsel = 0) {
@@ -432,7 +433,10 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
                      const double *__restrict__ rhscon,
                      double *__restrict__ fvn,
                      const int *__restrict__ kpos = nullptr,
-                     double *__restrict__ kvals = nullptr) {
+                     double *__restrict__ kvals = nullptr,
+                     const int *__restrict__ gptr = nullptr,
+                     const int *__restrict__ gidx = nullptr,
+                     const double *__restrict__ cellvals = nullptr) {
     // kpos / kvals: the new value of F goes straight into its place in the
     // assembled K = [[F, JT], [J, 0]] as well (a scatter kernel of its own
     // before)
@@ -457,7 +461,15 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
         for (int k = bptr[r]; k < bptr[r + 1]; ++k)
             s = fma(L[bidx[k]], dbcvals[bbc[k]], s);
         rhsbc[r] = -s;
-        if (fvn) fvn[r] = fv[r] - s + (rhscon ? rhscon[r] : 0.0);
+        // gptr: rhscon = N(u)u gathered here from the cell values of the
+        // convection vector (a gather kernel of its own before)
+        double rc = 0.0;
+        if (gptr) {
+            for (int k = gptr[r]; k < gptr[r + 1]; ++k) rc += cellvals[gidx[k]];
+        } else if (rhscon) {
+            rc = rhscon[r];
+        }
+        if (fvn) fvn[r] = fv[r] - s + rc;
     }
 }
 
@@ -500,7 +512,8 @@ inline int dns_conv::enqueue_mat_bc_gather(double *nvals, const double *mvals,
                                            const double *fv,
                                            const double *rhscon, double *fvn,
                                            hipStream_t s, const int *kpos,
-                                           double *kvals) {
+                                           double *kvals,
+                                           bool rhscon_from_cells) {
     const int gm = std::max(1, std::min((mat->nnz + dns::kBlock - 1) /
                                             dns::kBlock, 4096));
     const int gb = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
@@ -509,7 +522,10 @@ inline int dns_conv::enqueue_mat_bc_gather(double *nvals, const double *mvals,
                        gm, mat->nnz, mat->mptr.p, mat->midx.p, mat->L.p, nvals,
                        mvals, avals, tdt, fvals, nv_inner, mat->bptr.p,
                        mat->bidx.p, mat->bbc.p, dbc_ref(), rhsbc, fv, rhscon,
-                       fvn, kpos, kvals);
+                       fvn, kpos, kvals,
+                       rhscon_from_cells ? gptr.p : (const int *)nullptr,
+                       rhscon_from_cells ? gidx.p : (const int *)nullptr,
+                       rhscon_from_cells ? cellvals.p : (const double *)nullptr);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }
