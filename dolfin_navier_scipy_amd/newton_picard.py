@@ -304,7 +304,7 @@ class TrapezoidalStepper(object):
                 self.nslots))
         newton = not picard
         steps = np.diff(trange)
-        uniform = steps.size > 3 and \
+        uniform = steps.size > 7 and \
             np.abs(steps - steps[0]).max() <= 1e-12*abs(steps[0])
         batch = self.batch if batch is None else int(batch)
         nt = trange.size
@@ -358,7 +358,10 @@ class TrapezoidalStepper(object):
                 tot['refreshes'] += 1
 
         pipelined = pipeline and uniform
-        k = min(nt, 3) if pipelined else 1
+        # (synchronous until the warm start has its full order -- five
+        # solutions for the quartic one: the steps before need more Krylov
+        # steps than the run will, and a first batch sized by them fails)
+        k = min(nt, 7) if pipelined else 1
         if pipelined:
             its, worst = sync_steps(1, k)
             tot['iters'] += its
