@@ -298,7 +298,7 @@ def cpu_baseline_extras(sm, rhsd, v0, nfc0, dt, nsteps_gmres=1,
     return out
 
 
-def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=64,
+def picard_sweep_figures(femp, sm, rhsd, v0, dt, device, nsteps=256,
                          precond_at_v0=True, use_graph=True):
     """secondary workload (BASELINE config 3): one Picard
     and one Newton trapezoidal sweep over `nsteps` steps, everything on the
