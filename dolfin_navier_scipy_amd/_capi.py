@@ -102,6 +102,11 @@ SIGNATURES = {
     'dns_saddle_create': (ct.c_int, [ct.c_int, ct.POINTER(dns_csr),
                                      ct.POINTER(dns_csr), ct.POINTER(dns_csr),
                                      ct.POINTER(_VP)]),
+    'dns_saddle_create_rows': (ct.c_int, [ct.c_int, _VP, ct.c_int32,
+                                          ct.c_int32, ct.POINTER(dns_csr),
+                                          ct.POINTER(dns_csr),
+                                          ct.POINTER(dns_csr),
+                                          ct.POINTER(_VP)]),
     'dns_saddle_destroy': (None, [_VP]),
     'dns_saddle_update_values': (ct.c_int, [_VP, c_double_p]),
     'dns_saddle_setup_precond': (ct.c_int, [_VP,

@@ -60,18 +60,9 @@ dns_saddle::~dns_saddle() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
-int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
-                     const dns_csr *jt) {
-    DNS_TRY(check_csr(f, "F"));
-    DNS_TRY(check_csr(j, "J"));
-    if (f->nrows != f->ncols)
-        return fail(DNS_ERR_BAD_ARGUMENT, "F must be square");
-    if (j->ncols != f->nrows)
-        return fail(DNS_ERR_BAD_ARGUMENT, "J has %d columns, F has %d rows",
-                    j->ncols, f->nrows);
+// device, stream, knobs read once, pinned scratch (nv, np are set)
+int dns_saddle::init_device(int dev) {
     device = dev;
-    nv = f->nrows;
-    np = j->nrows;
     n = nv + np;
     ld = ((size_t)n + 63) / 64 * 64;
     DNS_HIP(hipSetDevice(device));
@@ -124,6 +115,21 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
                           sizeof(CtlHeaderAcc)));
     DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&scal_host),
                           16 * sizeof(double)));
+    return DNS_OK;
+}
+
+int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
+                     const dns_csr *jt) {
+    DNS_TRY(check_csr(f, "F"));
+    DNS_TRY(check_csr(j, "J"));
+    if (f->nrows != f->ncols)
+        return fail(DNS_ERR_BAD_ARGUMENT, "F must be square");
+    if (j->ncols != f->nrows)
+        return fail(DNS_ERR_BAD_ARGUMENT, "J has %d columns, F has %d rows",
+                    j->ncols, f->nrows);
+    nv = f->nrows;
+    np = j->nrows;
+    DNS_TRY(init_device(dev));
     // J^T: given or formed here
     std::vector<int> trp, tci;
     std::vector<double> tva;
@@ -189,6 +195,11 @@ int dns_saddle::init(int dev, const dns_csr *f, const dns_csr *j,
     hipLaunchKernelGGL(k_diag_inv, grid_for_elems(nv), kBlock, 0, stream, nv,
                        F.rowptr.p, F.colidx.p, F.vals.p, dinv.p);
     DNS_HIP(hipGetLastError());
+    return init_workspace();
+}
+
+// control blocks, Krylov vectors, partial sums (K.lpr is set)
+int dns_saddle::init_workspace() {
     nred = (int)std::min<int64_t>(1024, std::max<int64_t>(64, (n + 255) / 256));
     DNS_TRY(ctl.alloc(1));
     DNS_TRY(ctl.zero(stream));
@@ -241,12 +252,14 @@ int dns_saddle::build_pair() {
 
 int dns_saddle::update_values(const double *fvals) {
     DNS_HIP(hipSetDevice(device));
-    if (dist_sliced) {
+    if (dist_sliced || rank_local) {
         // the device holds this rank's rows of K only: new values through the
-        // host copy
+        // host copy (created from rows: `fvals` are the values of the own
+        // rows, which is all Fh holds)
         Fh.vals.assign(fvals, fvals + Fh.vals.size());
         fh_stale = false;
         drop_graphs();
+        if (!dist_sliced) return DNS_OK;      // (before the first set-up)
         return update_values_dist();
     }
     Fh.vals.assign(fvals, fvals + F.nnz);
@@ -266,6 +279,10 @@ int dns_saddle::update_values(const double *fvals) {
 // F.vals was re-valued by a device kernel (trapezoidal stepper): bring K and
 // D^-1 along; the host copy is fetched lazily before the next set-up
 int dns_saddle::ensure_F_device() {
+    if (rank_local)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "not available on a handle created from rows (the whole F "
+                    "is nowhere)");
     if (F.nnz > 0 || !dist_sliced) return DNS_OK;
     // (released when the handle was sliced; the trapezoidal stepper assembles
     // F = M + dt/2 (A + N) in full on every rank and scatters its rows into
@@ -542,6 +559,26 @@ int dns_saddle::build_explicit(bool dense_schur) {
         fprintf(stderr, "[dns] setup %-28s %8.1f ms\n", what, 1e3 * (t1 - t0));
         t0 = t1;
     };
+    if (rank_local) {
+        // the rows of F and J^T this rank's rows of the polynomial reach
+        HostCsr DF, JTx;
+        std::vector<double> dvx;
+        DNS_TRY(extend_rows_for_setup(DF, JTx, dvx));
+        lap("ghost rows of F, JT");
+        // convection-dominated F (setup_precond): refused here, by a bound of
+        // the skew radius from the own rows and their first ring
+        DNS_TRY(skew_bound_rows(DF, &skew_eta));
+        if (skew_eta * skew_eta > 0.25 * lam_lo * lam_hi)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "convection-dominated F (bound of the skew radius "
+                        "%.2e against Chebyshev bounds [%.2e, %.2e]): the "
+                        "polynomial of the symmetric part needs a handle "
+                        "created from whole matrices",
+                        skew_eta, lam_lo, lam_hi);
+        host_scale_rows(dvx, DF);
+        tmp_presliced = false;
+        return build_explicit_part(dense_schur, DF, dvx, JTx);
+    }
     const HostCsr &Fsrc = pc_sym ? Fpc_h : Fh;
     std::vector<double> dv((size_t)nv, 1.0);
     for (int i = 0; i < nv; ++i) {
@@ -553,7 +590,8 @@ int dns_saddle::build_explicit(bool dense_schur) {
     HostCsr DF = Fsrc;
     host_scale_rows(dv, DF);
     tmp_presliced = false;
-    if (comm && part_setup) return build_explicit_part(dense_schur, DF, dv);
+    if (comm && part_setup)
+        return build_explicit_part(dense_schur, DF, dv, JTh);
     // (with drop_tol == 0 the zero entries of the pattern of F^(k-1) stay)
     HostCsr G = host_cheb_poly(DF, dv, theta, c1, c2, popts.drop_tol);
     lap("polynomial G (row recurrences)");
@@ -1042,6 +1080,17 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     drop_graphs();   // captured kernel arguments (coefficients, buffers)
     // (values a device kernel wrote -- trapezoidal stepper -- first: a sliced
     // handle gets its matrices back from the HOST copies)
+    if (rank_local) {
+        if (popts.fhat == DNS_FHAT_CHEB || popts.cheb_degree < 2 ||
+            popts.cheb_degree > 12)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "a handle created from rows needs the explicit Fh^-1 "
+                        "(degree 2..12)");
+        if (popts.schur == DNS_SCHUR_JACOBI)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "a handle created from rows needs the dense or the "
+                        "multigrid Schur block");
+    }
     if (fh_stale && F.nnz > 0) {
         DNS_TRY(F.vals.download(Fh.vals.data(), (size_t)F.nnz, stream));
         DNS_HIP(hipStreamSynchronize(stream));
@@ -1062,6 +1111,8 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     if (popts.eig_lo > 0.0 && popts.eig_hi > popts.eig_lo) {
         lam_lo = popts.eig_lo;
         lam_hi = popts.eig_hi;
+    } else if (rank_local) {
+        DNS_TRY(estimate_bounds_rows());
     } else {
         DNS_TRY(estimate_bounds());
         // Nonsymmetric F: the eigenvalues of D^-1 F leave the real axis by up
@@ -1133,7 +1184,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
                     "dense Schur inverse too large for NP=%d", np);
     // explicit polynomial matrix: worth it while the apply is launch-latency
     // bound (pattern of F^(k-1): more bytes, far fewer dependent launches)
-    fhat_explicit = (popts.fhat == DNS_FHAT_EXPLICIT) || pc_sym ||
+    fhat_explicit = (popts.fhat == DNS_FHAT_EXPLICIT) || pc_sym || rank_local ||
                     (popts.fhat == DNS_FHAT_AUTO && nv <= 1000000 &&
                      popts.cheb_degree >= 2 && popts.cheb_degree <= 12);
     fp32_store = popts.fp32_store != 0;
@@ -2324,6 +2375,10 @@ int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather) {
 
 static int dns_saddle_set_comm_impl(dns_saddle *h, dns_comm *c) {
     if (!h) return fail(DNS_ERR_BAD_ARGUMENT, "null handle");
+    if (h->rank_local && c != h->comm)
+        return fail(DNS_ERR_BAD_ARGUMENT,
+                    "a handle created from rows keeps the communicator it was "
+                    "created on");
     h->drop_graphs();
     DNS_HIP(hipSetDevice(h->device));
     DNS_TRY(h->restore_full_device()); // (a sliced handle gets its matrices back)
@@ -2891,6 +2946,7 @@ int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
 }  // extern "C"
 
 #include "dist_solve.inc"
+#include "rank_local.inc"
 static void free_dist_data(dns_dist_data *d) { delete d; }
 dns::RowMap dns_saddle::dist_rowmap() const { return dd->kmap; }
 #include "imex_capi.inc"

@@ -91,6 +91,45 @@ inline HostCsr host_diag(const std::vector<double> &d) {
     return h;
 }
 
+// Rank-local construction: a matrix keeps its GLOBAL shape and row numbering,
+// but only some rows are populated (the rank's own rows, later the ghost rows
+// fetched from their owners); every other row is empty.  The row-wise set-up
+// algebra (polynomial rows, products, slices) reads populated rows only.
+// rows [r0, r0 + a->nrows) of an `nrows`-row matrix from a block of rows
+inline HostCsr host_embed_rows(const dns_csr *a, int r0, int nrows) {
+    HostCsr h;
+    h.nrows = nrows;
+    h.ncols = a->ncols;
+    h.rowptr.assign((size_t)nrows + 1, 0);
+    for (int i = 0; i < a->nrows; ++i)
+        h.rowptr[(size_t)r0 + i + 1] = a->rowptr[i + 1];
+    for (int i = r0 + a->nrows; i < nrows; ++i)
+        h.rowptr[(size_t)i + 1] = (int)a->nnz;
+    h.colidx.assign(a->colidx, a->colidx + a->nnz);
+    h.vals.assign(a->vals, a->vals + a->nnz);
+    return h;
+}
+
+// the populated rows of A and of B in one matrix (same shape; a row populated
+// in both is taken from A)
+inline HostCsr host_merge_rows(const HostCsr &A, const HostCsr &B) {
+    HostCsr C;
+    C.nrows = A.nrows;
+    C.ncols = A.ncols;
+    C.rowptr.assign((size_t)A.nrows + 1, 0);
+    C.colidx.reserve(A.colidx.size() + B.colidx.size());
+    C.vals.reserve(A.vals.size() + B.vals.size());
+    for (int i = 0; i < A.nrows; ++i) {
+        const HostCsr &S = (A.rowptr[i + 1] > A.rowptr[i]) ? A : B;
+        C.colidx.insert(C.colidx.end(), S.colidx.begin() + S.rowptr[i],
+                        S.colidx.begin() + S.rowptr[i + 1]);
+        C.vals.insert(C.vals.end(), S.vals.begin() + S.rowptr[i],
+                      S.vals.begin() + S.rowptr[i + 1]);
+        C.rowptr[(size_t)i + 1] = (int)C.colidx.size();
+    }
+    return C;
+}
+
 // rows [r0, r1) of C = A * B  (Gustavson, dense accumulator per row, sorted
 // columns); rowlen[i - r0] = entries of row i
 inline void host_spgemm_rows(const HostCsr &A, const HostCsr &B, int r0, int r1,

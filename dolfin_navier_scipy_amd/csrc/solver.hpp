@@ -400,13 +400,28 @@ struct dns_saddle {
                    bool presliced = false);
     // partitioned set-up (every rank forms the rows of its blocks only)
     int build_explicit_part(bool dense_schur, const dns::HostCsr &DF,
-                            const std::vector<double> &dv);
+                            const std::vector<double> &dv,
+                            const dns::HostCsr &JTx);
     int gather_need_lists(const std::vector<std::vector<int>> &mine,
                           std::vector<std::vector<std::vector<int>>> &all);
     int gather_csr_rows(const dns::HostCsr &loc, const std::vector<int> &starts,
                         int ncols, dns::HostCsr &out);
     int restore_full_device();
     int update_values_dist();
+    // rank-local construction (rank_local.inc): the handle was created from
+    // this rank's rows only; Fh, Jh, JTh keep the global shape with the own
+    // rows populated, no whole matrix ever reaches the host or the HBM
+    bool rank_local = false;
+    int64_t nnz_f_all = 0, nnz_j_all = 0;     // entries of the whole F and J
+    int init_rows(int dev, dns_comm *c, int nv_all, int np_all,
+                  const dns_csr *f, const dns_csr *jt, const dns_csr *j);
+    int fetch_rows(const dns::HostCsr &A, const std::vector<int> &starts,
+                   const std::vector<int> &want, dns::HostCsr &out);
+    int all_ranks_max(double mine, double *out);
+    int estimate_bounds_rows();
+    int extend_rows_for_setup(dns::HostCsr &Fx, dns::HostCsr &JTx,
+                              std::vector<double> &dv);
+    int skew_bound_rows(const dns::HostCsr &Fx, double *eta);
     int enqueue_cycle_dist(const double *b, double *x, int c,
                            const dns_solve_opts *o, int first,
                            bool have_resid = false);
@@ -584,6 +599,8 @@ struct dns_saddle {
 
     ~dns_saddle();
     int init(int dev, const dns_csr *f, const dns_csr *j, const dns_csr *jt);
+    int init_device(int dev);
+    int init_workspace();
     int update_values(const double *fvals);
     int setup_precond(const dns_precond_opts *o);
     int estimate_bounds();

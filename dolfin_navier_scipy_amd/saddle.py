@@ -70,6 +70,43 @@ class SaddleSystem(object):
         self.last_stats = None
         self.precond_ready = False
 
+    @classmethod
+    def from_rows(cls, F_rows, JT_rows, J_rows, NV, NP, comm, device=0):
+        """rank-local construction (`dns_saddle_create_rows`): this rank's rows
+        of `F` and `J^T` -- rows `comm.partition_range(NV)` -- and of `J` --
+        rows `partition_range(NP)` -- with global column indices; no rank
+        holds a whole matrix.  Collective over `comm`."""
+        self = cls.__new__(cls)
+        self.lib = C.load_library()
+        self._f = C.CsrView(F_rows)
+        self._jt = C.CsrView(JT_rows)
+        self._j = C.CsrView(J_rows)
+        self.NP, self.NV = int(NP), int(NV)
+        self.n = self.NV + self.NP
+        self.device = device
+        self._comm = comm
+        self._h = ct.c_void_p()
+        C.check(self.lib.dns_saddle_create_rows(
+            device, comm._h, self.NV, self.NP, self._f.byref(),
+            self._jt.byref(), self._j.byref(), ct.byref(self._h)))
+        self.last_stats = None
+        self.precond_ready = False
+        return self
+
+    @classmethod
+    def from_rows_of(cls, F, J, comm, device=0):
+        """`from_rows` with the rows cut out of whole SciPy matrices (tests,
+        the bench: a distributed assembler hands its rows over directly)"""
+        import scipy.sparse as sps
+        from .comm import partition_range
+        NP, NV = J.shape
+        v0, v1 = partition_range(NV, comm.nranks, comm.rank)
+        p0, p1 = partition_range(NP, comm.nranks, comm.rank)
+        F, J = sps.csr_matrix(F), sps.csr_matrix(J)
+        JT = sps.csr_matrix(J[:, v0:v1].T)
+        return cls.from_rows(F[v0:v1, :], JT, J[p0:p1, :], NV, NP, comm,
+                             device=device)
+
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
             self.lib.dns_saddle_destroy(self._h)

@@ -271,6 +271,29 @@ int dns_halo_lists(const dns_csr *a, int32_t row0, int32_t row1,
 int dns_saddle_device_bytes(dns_saddle *h, int64_t *matrix_bytes);
 /* attach before dns_saddle_setup_precond; NULL detaches */
 int dns_saddle_set_comm(dns_saddle *h, dns_comm *c);
+/* Rank-local construction of a row-partitioned handle: rank r of `comm` hands
+ * over ITS rows of K = [[F, JT], [J, 0]] only -- `f_rows` = rows [v0, v1) of F
+ * (v1 - v0 rows, `nv` columns, GLOBAL column indices), `jt_rows` = the same rows
+ * of J^T (`np` columns), `j_rows` = rows [p0, p1) of J (`nv` columns), with
+ * [v0, v1) = dns_partition_range(nv, ...) and [p0, p1) =
+ * dns_partition_range(np, ...).  No rank ever holds a whole matrix, on the host
+ * or in HBM: the rows of F and J^T a rank's part of the polynomial
+ * preconditioner reaches beyond its own are fetched from their owners during
+ * dns_saddle_setup_precond (degree - 1 rings of the pattern of F) and dropped
+ * again; the spectral bounds come from power iterations whose product is formed
+ * by rows.  The preconditioner, hence every iterate, equals bit for bit the one
+ * of a handle created from whole matrices with the same communicator attached.
+ * Collective (every rank of `comm` calls it).  Restrictions: explicit Fh^-1
+ * (degree 2..12), dense or multigrid Schur block (its hierarchy is still built
+ * from the all-gathered Schur complement); F close to symmetric (the
+ * convection-dominated set-up of dns_saddle_setup_precond needs whole
+ * matrices); dns_saddle_update_values takes the values of the own rows;
+ * the communicator cannot be exchanged.  The reference has no counterpart (one
+ * process: `lau.solve_sadpnt_smw(amat=, jmat=)`, stokes_navier_utils.py:1512);
+ * this is the entry a distributed assembler binds. */
+int dns_saddle_create_rows(int device, dns_comm *comm, int32_t nv, int32_t np,
+                           const dns_csr *f_rows, const dns_csr *jt_rows,
+                           const dns_csr *j_rows, dns_saddle **out);
 /* the block partition used for n rows: [start, end) of `rank` (chunks of
  * ceil(n / nranks) rows rounded up to an even number: the two velocity dofs of
  * a node stay on one rank) */

@@ -122,6 +122,11 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
         if fhat.endswith('_nolazy'):
             knobs['DNS_DIST_LAZY1'] = '0'
         fhat = fhat[:fhat.rindex('_')]
+    from_rows = fhat.endswith('_loc')
+    if from_rows:
+        # rank-local construction: the handle is created from this rank's rows
+        # of F, JT and J only (`dns_saddle_create_rows`)
+        fhat = fhat[:-4]
     if fhat.endswith('_rep'):
         # the set-up replicated (every rank forms every row) instead of
         # partitioned (the default with a communicator)
@@ -142,10 +147,13 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
     cyl3 = fhat in ('cyl3', 'cyl3s')
     pr = (_mg3_problem() if three else _mg_problem()) if mgs else (
         _cyl3_problem() if cyl3 else _problem())
-    system = sad.SaddleSystem(pr['F'], pr['J'])
+    if from_rows:
+        system = sad.SaddleSystem.from_rows_of(pr['F'], pr['J'], comm)
+    else:
+        system = sad.SaddleSystem(pr['F'], pr['J'])
     for k, v in knobs.items():        # per-handle options, no process state
         system.set_option(k[len('DNS_'):].lower(), float(v))
-    if comm is not None:
+    if comm is not None and not from_rows:
         system.set_comm(comm)
     if cyl3:
         fhat, fact = 'explicit', 'full'
@@ -277,7 +285,7 @@ def test_rccl_world_size_one_equals_plain_solve():
     assert _capi.device_count() > 0
     x0, st0, v0, p0 = _solve_and_step(saddle, None, 'explicit', True)
     cm = dcomm.Comm.rccl(0, 1, 0, dcomm.rccl_unique_id())
-    for fhat in ('explicit', 'full'):
+    for fhat in ('explicit', 'full', 'full_loc'):
         x1, st1, v1, p1 = _solve_and_step(saddle, cm, fhat, True)
         assert st1['status'] == 0 and st1['true_relres'] <= 5e-12
         assert np.linalg.norm(x1 - x0) <= 1e-9*np.linalg.norm(x0)
@@ -369,7 +377,9 @@ def _worker(rank, world, port, outdir):
                          ('cyl3s', False), ('full_lazy', 2),
                          ('full_nolazy', 2), ('mg3part_lazy', 2),
                          ('full_rep', False),
-                         ('mg3part_rep', False), ('cyl3_rep', False)):
+                         ('mg3part_rep', False), ('cyl3_rep', False),
+                         ('full_loc', False), ('mg3part_loc', False),
+                         ('cyl3_loc', False)):
         info = {}
         before = cm.stats()
         x, st, v, p = _solve_and_step(saddle, cm, fhat, reorth, info=info)
@@ -483,6 +493,16 @@ def test_two_ranks_one_gpu_gloo_staged(tmp_path):
             assert np.array_equal(r0[key + '_%d' % i],
                                   r0[key + '_rep_%d' % i]), (key, i)
         assert int(r0[key + '_3']) == int(r0[key + '_rep_3'])
+    # rank-local construction (every rank hands over its rows of F, JT, J
+    # only; ghost rows fetched ring by ring, spectral bounds by rows) == the
+    # handle created from whole matrices, bit for bit
+    for key in ('full', 'mg3part', 'cyl3'):
+        for rr in (r0, r1):
+            for i in (0, 1, 2):
+                assert np.array_equal(rr[key + '_%d' % i],
+                                      rr[key + '_loc_%d' % i]), (key, i)
+            assert int(rr[key + '_3']) == int(rr[key + '_loc_3'])
+            assert int(rr[key + '_loc_5']) <= int(rr[key + '_5'])
     # per-rank storage: the row blocks, not the matrices
     for rr in (r0, r1):
         assert int(rr['cyl3_5']) < 0.6*info['matrix_bytes'], \
