@@ -574,7 +574,6 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
     else:
         v0, start_kind = np.zeros((NV, 1)), 'rest'
 
-    system = saddle.SaddleSystem(F, J, device=device)
     with stdout_to_stderr():
         if one_gpu:
             comm_obj = dcomm.Comm.gloo(device)
@@ -582,10 +581,20 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
             comm_obj = dcomm.Comm.rccl_from_torch(device)
         else:
             comm_obj = dcomm.Comm.rccl(device, 1, 0, dcomm.rccl_unique_id())
-    system.set_comm(comm_obj)
+    # rank-local construction (`dns_saddle_create_rows`): the library is handed
+    # this rank's rows of F, JT, J and R1 only (the assembler of this script is
+    # replicated: the rows are cut out of its matrices)
+    by_rows = args.construction == 'rows' or (
+        args.construction == 'auto' and world > 1)
+    t_setup = time.perf_counter()
+    if by_rows:
+        system = saddle.SaddleSystem.from_rows_of(F, J, comm_obj,
+                                                  device=device)
+    else:
+        system = saddle.SaddleSystem(F, J, device=device)
+        system.set_comm(comm_obj)
     if prols is not None:
         system.set_schur_mg(prols)
-    t_setup = time.perf_counter()
     # bandwidth regime: the partitioned solve needs the explicit polynomial
     # matrix; degree 8 from 1e6 unknowns on (refined_bench.py's setting)
     fhat = 'explicit' if (args.fhat == 'auto' and NV > 200000) else args.fhat
@@ -675,6 +684,9 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
     glob = over_ranks([info['nnz_K'], info['nnz_Gc'], info['nnz_JG']], SUM)
     mbytes = system.device_matrix_bytes()
     mb = over_ranks([mbytes], MAX)[0]
+    host_bytes = [int(x) for x in over_ranks(
+        [float(x) for x in system.host_matrix_bytes()], MAX)]
+    t_setup = over_ranks([t_setup], MAX)[0]
     ginfo = dict(info, nnz_K=int(glob[0]), nnz_Gc=int(glob[1]),
                  nnz_JG=int(glob[2]))
     roof = perfmodel.step_roofline(
@@ -754,6 +766,15 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
             'peer; halo_exchange = the ncclSend/Recv group without its pack '
             '/ unpack kernels'.format(ntime)),
         matrix_bytes_per_rank_max=int(mb), precond_setup_s=t_setup,
+        construction=dict(
+            zip(('host_matrix_bytes_kept', 'host_matrix_bytes_setup'),
+                host_bytes),
+            kind='rows: every rank hands over its rows of F, JT, J, R1 only '
+            '(dns_saddle_create_rows)' if by_rows else
+            'whole matrices on every rank (dns_saddle_create + set_comm)',
+            create_and_setup_s=t_setup,
+            what='max over the ranks; host bytes = matrix copies the handle '
+            'keeps / matrices alive at the end of the explicit set-up'),
         backend='gloo, host staged (one-GPU rehearsal)' if one_gpu
         else 'RCCL', roofline_step=roof,
         what='one simulation; every rank holds its row blocks of K, Fh^-1, '
@@ -767,9 +788,10 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
                             PARITY_TOL))
     stp.close()
     cvop.close()
-    system.set_comm(None)
-    comm_obj.close()
+    if not by_rows:
+        system.set_comm(None)
     system.close()
+    comm_obj.close()
     return res
 
 
@@ -1157,6 +1179,11 @@ def main():
                     'WHOLE run is repeated un-partitioned on rank 0 for the '
                     'parity record; beyond it the first {0} steps'.format(
                         PARITY_PREFIX_STEPS))
+    ap.add_argument('--construction', default='auto',
+                    choices=['auto', 'rows', 'whole'],
+                    help='partitioned runs: hand the library this rank\'s '
+                    'rows only (dns_saddle_create_rows) or whole matrices; '
+                    'auto = rows on more than one rank')
     ap.add_argument('--no-parity', action='store_true',
                     help='(partitioned runs, profiling aid) no un-partitioned '
                     'reference run: the kernel table of a profiled child is '

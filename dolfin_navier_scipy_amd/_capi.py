@@ -140,6 +140,8 @@ SIGNATURES = {
     'dns_comm_destroy': (None, [_VP]),
     'dns_comm_stats': (ct.c_int, [_VP, ct.POINTER(ct.c_int64),
                                   ct.POINTER(ct.c_int64)]),
+    'dns_saddle_host_bytes': (ct.c_int, [_VP, ct.POINTER(ct.c_int64),
+                                         ct.POINTER(ct.c_int64)]),
     'dns_saddle_set_comm': (ct.c_int, [_VP, _VP]),
     'dns_partition_range': (ct.c_int, [ct.c_int32, ct.c_int32, ct.c_int32,
                                        c_int32_p, c_int32_p]),
@@ -149,6 +151,8 @@ SIGNATURES = {
     'dns_default_solve_opts': (None, [ct.POINTER(dns_solve_opts)]),
     'dns_imex_create': (ct.c_int, [_VP, ct.POINTER(dns_csr),
                                    ct.POINTER(_VP)]),
+    'dns_imex_create_rows': (ct.c_int, [_VP, ct.POINTER(dns_csr),
+                                        ct.POINTER(_VP)]),
     'dns_imex_destroy': (None, [_VP]),
     'dns_imex_set_state': (ct.c_int, [_VP, c_double_p, c_double_p, c_double_p,
                                       c_double_p, c_double_p]),

@@ -101,6 +101,7 @@ int dns_saddle::init_device(int dev) {
     if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
     if (const char *sn = getenv("DNS_PAIR")) pair_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_PART_SETUP")) part_setup = sn[0] != '0';
+    if (const char *sn = getenv("DNS_MG_ROWS")) mg_rows_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_DIST_GRAPH")) dist_graph_ok = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_CHEB")) mg_cheb = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_CYCLES"))
@@ -698,7 +699,7 @@ int dns_saddle::build_dense_schur() {
 // Multigrid hierarchy of the Schur block: S_0 given (sparse), Galerkin coarse
 // operators through the prolongations handed over by dns_saddle_set_schur_mg,
 // dense inverse on the coarsest level.
-int dns_saddle::build_mg_schur(const HostCsr &S0) {
+int dns_saddle::mg_prepare(int n0) {
     mg_ready = false;
     if (!mg_set)
         return fail(DNS_ERR_NOT_READY,
@@ -715,7 +716,7 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
     const int dense_max = mg_dense_max;
     int L = (int)mg_prol_h.size() + 1;
     {
-        int nl = S0.nrows;
+        int nl = n0;
         for (int l = 0; l + 1 < L; ++l) {
             if (nl <= dense_max) {
                 L = l + 1;
@@ -729,8 +730,19 @@ int dns_saddle::build_mg_schur(const HostCsr &S0) {
     // two sweeps each way: the cycle runs on fused operators (9 launches for
     // three levels instead of 16); DNS_MG_FUSED=0 keeps the plain cycle
     mg_fused = mg_nu == 2 && mg_fused_knob;
-    HostCsr Sl = S0;
-    for (int l = 0; l < L; ++l) {
+    mg_rows_parts = 0;
+    return DNS_OK;
+}
+
+int dns_saddle::build_mg_schur(const HostCsr &S0) {
+    DNS_TRY(mg_prepare(S0.nrows));
+    return build_mg_levels(0, S0);
+}
+
+// levels l0 .. of the hierarchy from the WHOLE operator of level l0
+int dns_saddle::build_mg_levels(int l0, HostCsr Sl) {
+    const int L = (int)mg.size();
+    for (int l = l0; l < L; ++l) {
         MgLevel &lv = mg[l];
         lv.n = Sl.nrows;
         DNS_TRY(lv.x.alloc((size_t)lv.n));
@@ -2079,6 +2091,7 @@ static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double va
     if (k == "stream_nnz") h->stream_nnz = (int64_t)value;
     else if (k == "pair") h->pair_knob = value != 0.0;
     else if (k == "part_setup") h->part_setup = value != 0.0;
+    else if (k == "mg_rows") h->mg_rows_knob = value != 0.0;
     else if (k == "dist_x0_exchange") h->dist_x0_exchange = value != 0.0;
     else if (k == "dist_lazy1") h->dist_lazy1 = value != 0.0;
     else if (k == "cycle_first") h->cycle_first = (int)value;
@@ -2947,6 +2960,7 @@ int dns_hbm_probe(int device, int64_t bytes, int32_t kind, int32_t reps,
 
 #include "dist_solve.inc"
 #include "rank_local.inc"
+#include "mg_rows.inc"
 static void free_dist_data(dns_dist_data *d) { delete d; }
 dns::RowMap dns_saddle::dist_rowmap() const { return dd->kmap; }
 #include "imex_capi.inc"

@@ -9,6 +9,8 @@ struct dns_imex {
     dns_saddle *sys = nullptr;
     dns::CsrDev R1;                // all rows, or this rank's (partitioned)
     dns::HostCsr R1h;              // host copy (row blocks are cut from it)
+    bool r1_rows = false;          // R1h holds this rank's rows only
+                                   // (dns_imex_create_rows)
     // pair format of R1 (2x2 node blocks, pair.hpp) for the streamed
     // right-hand-side product of the bandwidth regime: R1 = M - theta dt A has
     // the block structure of F (8.5 instead of 10 bytes per non-zero, a third

@@ -413,11 +413,16 @@ struct dns_saddle {
     // rows populated, no whole matrix ever reaches the host or the HBM
     bool rank_local = false;
     int64_t nnz_f_all = 0, nnz_j_all = 0;     // entries of the whole F and J
+    // bytes of the host matrices the last explicit set-up had alive at its
+    // end (scaled F, J^T, polynomial rows and their products), beside the
+    // copies the handle keeps (dns_saddle_host_bytes)
+    int64_t host_setup_bytes = 0;
     int init_rows(int dev, dns_comm *c, int nv_all, int np_all,
                   const dns_csr *f, const dns_csr *jt, const dns_csr *j);
     int fetch_rows(const dns::HostCsr &A, const std::vector<int> &starts,
                    const std::vector<int> &want, dns::HostCsr &out);
     int all_ranks_max(double mine, double *out);
+    int allgather_host(std::vector<double> &v, const std::vector<int> &st);
     int estimate_bounds_rows();
     int extend_rows_for_setup(dns::HostCsr &Fx, dns::HostCsr &JTx,
                               std::vector<double> &dv);
@@ -545,6 +550,14 @@ struct dns_saddle {
                                           // beats 4 and 8 at refine 2-4)
     bool mg_ready = false, mg_set = false;
     int build_mg_schur(const dns::HostCsr &S0);
+    int mg_prepare(int n0);               // level count, fresh levels
+    int build_mg_levels(int l0, dns::HostCsr Sl);
+    // the hierarchy formed BY ROWS (mg_rows.inc): the levels that run row-
+    // partitioned never exist as whole matrices; the first replicated level is
+    // all-gathered, the rest is built from it as on one GPU
+    int build_mg_schur_rows(const dns::HostCsr &S0loc);
+    int mg_rows_parts = 0;                // levels built (and kept) by rows
+    bool mg_rows_knob = true;             // DNS_MG_ROWS / option `mg_rows`
     int mg_op(const dns::CsrDev &A, const double *xa, int nsplit,
               const double *xb, const MgLevel *add, const double *b,
               double *out, const int *guard);

@@ -91,6 +91,7 @@ class SaddleSystem(object):
             self._jt.byref(), self._j.byref(), ct.byref(self._h)))
         self.last_stats = None
         self.precond_ready = False
+        self.from_rows_handle = True
         return self
 
     @classmethod
@@ -132,6 +133,14 @@ class SaddleSystem(object):
         out = ct.c_int64(0)
         C.check(self.lib.dns_saddle_device_bytes(self._h, ct.byref(out)))
         return out.value
+
+    def host_matrix_bytes(self):
+        """`(kept, setup)` bytes of host matrices (`dns_saddle_host_bytes`):
+        what the handle keeps, and what its last partitioned set-up held"""
+        a, b = ct.c_int64(0), ct.c_int64(0)
+        C.check(self.lib.dns_saddle_host_bytes(self._h, ct.byref(a),
+                                               ct.byref(b)))
+        return a.value, b.value
 
     def set_schur_mg(self, prolongations, smooth_steps=2):
         """nested pressure spaces for `schur='mg'`: `prolongations[l]` maps
@@ -291,13 +300,29 @@ class SaddleSystem(object):
 class ImexStepper(object):
     """device-resident CNAB/SBDF2 state (`dns_imex_*`)"""
 
-    def __init__(self, system, R1):
+    def __init__(self, system, R1, rows=None):
+        """`rows=True` (default on a system created from rows): `R1` holds
+        this rank's rows only, or is cut down to them here when it is whole
+        (`dns_imex_create_rows`)"""
         self.sys = system
         self.lib = system.lib
-        self._r1 = C.CsrView(R1)
+        if rows is None:
+            rows = getattr(system, 'from_rows_handle', False)
         self._h = ct.c_void_p()
-        C.check(self.lib.dns_imex_create(system._h, self._r1.byref(),
-                                         ct.byref(self._h)))
+        if rows:
+            from .comm import partition_range
+            cm = system._comm
+            v0, v1 = partition_range(system.NV, cm.nranks, cm.rank)
+            if R1.shape[0] == system.NV and (v1 - v0) != system.NV:
+                import scipy.sparse as sps
+                R1 = sps.csr_matrix(R1)[v0:v1, :]
+            self._r1 = C.CsrView(R1)
+            C.check(self.lib.dns_imex_create_rows(
+                system._h, self._r1.byref(), ct.byref(self._h)))
+        else:
+            self._r1 = C.CsrView(R1)
+            C.check(self.lib.dns_imex_create(system._h, self._r1.byref(),
+                                             ct.byref(self._h)))
         self.last_stats = None
 
     def close(self):

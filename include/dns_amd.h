@@ -269,6 +269,11 @@ int dns_halo_lists(const dns_csr *a, int32_t row0, int32_t row1,
 /* bytes of HBM the handle's matrices occupy on this rank (K, Fh^-1, J Fh^-1,
  * Schur block, F/J/JT copies): shrinks with the number of ranks */
 int dns_saddle_device_bytes(dns_saddle *h, int64_t *matrix_bytes);
+/* bytes of HOST memory: `kept` = the matrix copies the handle keeps (F, J, JT
+ * -- whole, or the own rows of a handle created from rows --, prolongations,
+ * level operators of a partitioned multigrid); `setup` = the matrices the last
+ * partitioned explicit set-up had alive at its end (0 otherwise) */
+int dns_saddle_host_bytes(dns_saddle *h, int64_t *kept, int64_t *setup);
 /* attach before dns_saddle_setup_precond; NULL detaches */
 int dns_saddle_set_comm(dns_saddle *h, dns_comm *c);
 /* Rank-local construction of a row-partitioned handle: rank r of `comm` hands
@@ -334,6 +339,12 @@ typedef struct dns_imex_coeffs {
 } dns_imex_coeffs;
 
 int dns_imex_create(dns_saddle *sys, const dns_csr *r1, dns_imex **out);
+/* ... on a system created from rows (dns_saddle_create_rows): `r1_rows` = this
+ * rank's rows of R1 -- rows dns_partition_range(NV, ...), NV columns, global
+ * column indices; the halo lists of the stepper are exchanged instead of being
+ * computed from a replicated pattern.  Collective at the first step. */
+int dns_imex_create_rows(dns_saddle *sys, const dns_csr *r1_rows,
+                         dns_imex **out);
 void dns_imex_destroy(dns_imex *st);
 /* set the state: current / previous velocity (v_p may be NULL), current p~
  * (may be NULL = 0; only seeds the warm start), the two convection history

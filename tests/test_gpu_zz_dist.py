@@ -396,6 +396,58 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
+def _worker_rows(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      RANK=str(rank), WORLD_SIZE=str(world),
+                      GLOO_SOCKET_IFNAME='lo')
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import datetime
+    import faulthandler
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(100, exit=True)
+    dist.init_process_group('gloo', rank=rank, world_size=world,
+                            timeout=datetime.timedelta(seconds=60))
+    from dolfin_navier_scipy_amd import saddle, comm as dcomm
+    cm = dcomm.Comm.gloo(0)
+    out = {}
+    for fhat in ('full', 'full_loc', 'mg3part', 'mg3part_loc', 'mg3part_rep'):
+        info = {}
+        x, st, v, p = _solve_and_step(saddle, cm, fhat, False, info=info)
+        out[fhat] = (x, v, p, st['iters'], st['true_relres'])
+    np.savez(os.path.join(outdir, 'rank{0}.npz'.format(rank)),
+             **{'{0}_{1}'.format(k, i): np.asarray(val)
+                for k, tup in out.items() for i, val in enumerate(tup)})
+    cm.close()
+    dist.destroy_process_group()
+
+
+def test_construction_from_rows_over_three_ranks(tmp_path):
+    """`dns_saddle_create_rows` / `dns_imex_create_rows` over THREE ranks
+    sharing the GPU (the middle rank has neighbours on both sides, ghost rows
+    come from two owners): solutions and time steps equal, bit for bit, the
+    ones of handles created from whole matrices on the same communicator"""
+    from spawn_util import spawn_ranks
+    spawn_ranks(_worker_rows, 3, str(tmp_path))
+    rs = [np.load(tmp_path / 'rank{0}.npz'.format(r)) for r in range(3)]
+    for key in ('full', 'mg3part'):
+        for rr in rs:
+            assert float(rr[key + '_loc_4']) <= 5e-12
+            for i in (0, 1, 2):
+                assert np.array_equal(rr[key + '_%d' % i],
+                                      rr[key + '_loc_%d' % i]), (key, i)
+                assert np.array_equal(rr[key + '_%d' % i],
+                                      rs[0][key + '_%d' % i]), (key, i)
+            assert int(rr[key + '_3']) == int(rr[key + '_loc_3'])
+    # the multigrid levels formed by rows (mg_rows.inc) == cut out of the whole
+    # hierarchy every rank builds in the replicated set-up
+    for rr in rs:
+        for i in (0, 1, 2):
+            assert np.array_equal(rr['mg3part_%d' % i],
+                                  rr['mg3part_rep_%d' % i]), i
+
+
 def test_two_ranks_one_gpu_gloo_staged(tmp_path):
     from dolfin_navier_scipy_amd import saddle
     from oracle import saddle_oracle
