@@ -130,6 +130,36 @@ inline HostCsr host_merge_rows(const HostCsr &A, const HostCsr &B) {
     return C;
 }
 
+// the rows `R` (sorted) of A as a matrix of their own, in that order; with
+// `loc_of` (global index -> position in R, -1: not there) the columns are
+// renumbered too and entries outside R dropped (a square matrix on the index
+// set R), without it they stay global
+inline HostCsr host_compact_rows(const HostCsr &A, const std::vector<int> &R,
+                                 const std::vector<int> *loc_of) {
+    HostCsr C;
+    C.nrows = (int)R.size();
+    C.ncols = loc_of ? (int)R.size() : A.ncols;
+    C.rowptr.assign(R.size() + 1, 0);
+    size_t cap = 0;
+    for (int i : R) cap += (size_t)(A.rowptr[i + 1] - A.rowptr[i]);
+    C.colidx.reserve(cap);
+    C.vals.reserve(cap);
+    for (size_t q = 0; q < R.size(); ++q) {
+        const int i = R[q];
+        for (int k = A.rowptr[i]; k < A.rowptr[i + 1]; ++k) {
+            int c = A.colidx[k];
+            if (loc_of) {
+                c = (*loc_of)[c];
+                if (c < 0) continue;
+            }
+            C.colidx.push_back(c);
+            C.vals.push_back(A.vals[k]);
+        }
+        C.rowptr[q + 1] = (int)C.colidx.size();
+    }
+    return C;
+}
+
 // rows [r0, r1) of C = A * B  (Gustavson, dense accumulator per row, sorted
 // columns); rowlen[i - r0] = entries of row i
 inline void host_spgemm_rows(const HostCsr &A, const HostCsr &B, int r0, int r1,

@@ -14,7 +14,7 @@ cd $R
 export DNS_BENCH_REHEARSE_ONE_GPU=1 GLOO_SOCKET_IFNAME=lo DNS_DEBUG=1
 PORT=29711
 for kind in rows whole; do
-  timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $NR --master-addr 127.0.0.1 --master-port $PORT \
+  timeout -k 10 ${LIMIT:-500} python -m torch.distributed.run --nnodes=1 --nproc-per-node $NR --master-addr 127.0.0.1 --master-port $PORT \
     bench.py --partitioned-only --gpus $NR --level 2 --refine $REFINE --nts $NTS --steps 10 --warmup 2 --spinup 8 --construction $kind \
     > $OUT/refine${REFINE}_${NR}ranks_$kind.json 2> $OUT/refine${REFINE}_${NR}ranks_$kind.err || echo "$kind failed"
   PORT=$((PORT + 20))
