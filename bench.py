@@ -586,6 +586,8 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
     # replicated: the rows are cut out of its matrices)
     by_rows = args.construction == 'rows' or (
         args.construction == 'auto' and world > 1)
+    import resource
+    rss_before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss/1024.
     t_setup = time.perf_counter()
     if by_rows:
         system = saddle.SaddleSystem.from_rows_of(F, J, comm_obj,
@@ -610,6 +612,7 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
     system.setup_precond(**pkw)
     _capi.device_synchronize(device)
     t_setup = time.perf_counter() - t_setup
+    rss_setup = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss/1024.
     cvop = convection.ConvectionP2.from_taylor_hood(
         th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
     nfc = cvop.apply(v0, scale=-1.0)
@@ -773,8 +776,14 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
             '(dns_saddle_create_rows)' if by_rows else
             'whole matrices on every rank (dns_saddle_create + set_comm)',
             create_and_setup_s=t_setup,
+            process_peak_rss_mb=dict(before_create=rss_before,
+                                     after_setup=rss_setup),
+            host_threads=os.environ.get('DNS_HOST_THREADS'),
             what='max over the ranks; host bytes = matrix copies the handle '
-            'keeps / matrices alive at the end of the explicit set-up'),
+            'keeps / matrices alive at the end of the explicit set-up; the '
+            'peak resident set of rank 0\'s process (it holds this script\'s '
+            'whole assembled matrices as well) before the handle is created '
+            'and after its set-up'),
         backend='gloo, host staged (one-GPU rehearsal)' if one_gpu
         else 'RCCL', roofline_step=roof,
         what='one simulation; every rank holds its row blocks of K, Fh^-1, '

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <exception>
 #include <thread>
 #include <vector>
@@ -17,6 +18,19 @@
 // instead; every started thread is joined; an exception out of `fn` (a
 // std::bad_alloc of a worker's scratch vectors) is rethrown by the caller
 // after the join.
+// host threads of the set-up algebra: up to 16, the cores there are, or
+// DNS_HOST_THREADS (several ranks sharing the cores of one box)
+inline int dns_host_threads() {
+    static const int nt = [] {
+        int n = (int)std::min<unsigned>(
+            16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *e = getenv("DNS_HOST_THREADS"))
+            n = std::max(1, std::min(64, atoi(e)));
+        return n;
+    }();
+    return nt;
+}
+
 template <typename Fn>
 inline void dns_run_threads(int nt, Fn fn) {
     if (nt <= 1) {
@@ -199,8 +213,7 @@ inline HostCsr host_spgemm(const HostCsr &A, const HostCsr &B) {
     C.nrows = A.nrows;
     C.ncols = B.ncols;
     C.rowptr.assign((size_t)A.nrows + 1, 0);
-    int nt = (int)std::min<unsigned>(16u, std::max(1u,
-                                     std::thread::hardware_concurrency()));
+    int nt = dns_host_threads();
     if (A.nnz() < 20000) nt = 1;
     nt = std::max(1, std::min(nt, A.nrows));
     std::vector<std::vector<int>> rl((size_t)nt), cis((size_t)nt);
@@ -308,8 +321,7 @@ inline HostCsr host_cheb_poly(const HostCsr &DF, const std::vector<double> &dv,
     HostCsr G;
     G.nrows = G.ncols = n;
     G.rowptr.assign((size_t)n + 1, 0);
-    int nt = (int)std::min<unsigned>(16u, std::max(1u,
-                                     std::thread::hardware_concurrency()));
+    int nt = dns_host_threads();
     nt = std::max(1, std::min(nt, nr / 64 + 1));
     std::vector<std::vector<int>> rl((size_t)nt), cis((size_t)nt);
     std::vector<std::vector<double>> vas((size_t)nt);

@@ -227,6 +227,104 @@ static void test_polynomial_rows(const HostCsr &F) {
     }
 }
 
+// Rank-local construction: a block of rows embedded in the global shape, ghost
+// rows merged in ring by ring, the polynomial rows of the block formed on the
+// renumbered index set they reach -- equal, bit for bit, to the rows of the
+// polynomial of the whole matrix (dist_solve.inc, build_explicit_part;
+// rank_local.inc, extend_rows_for_setup)
+static void test_rows_on_their_reach(const HostCsr &F) {
+    const int nv = F.nrows;
+    std::vector<double> dv((size_t)nv);
+    for (int i = 0; i < nv; ++i) {
+        double d = 1.0;
+        for (int k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k)
+            if (F.colidx[k] == i) d = F.vals[k];
+        dv[i] = 1.0 / d;
+    }
+    const std::vector<double> c1 = {0.1, 0.05, 0.02}, c2 = {0.9, 0.8, 0.7};
+    const int degree = (int)c1.size() + 1;
+    HostCsr DFw = F;
+    dns::host_scale_rows(dv, DFw);
+    const HostCsr Gw = dns::host_cheb_poly(DFw, dv, 1.0, c1, c2, 1e-3);
+    for (int nranks : {1, 2, 3}) {
+        const std::vector<int> st = dns::partition_starts(nv, nranks);
+        for (int me = 0; me < nranks; ++me) {
+            const int v0 = st[me], v1 = st[me + 1];
+            // the own rows in the global shape
+            const HostCsr blk = host_row_slice(F, v0, v1);
+            const dns_csr bv = blk.view();
+            HostCsr Fx = dns::host_embed_rows(&bv, v0, nv);
+            CHECK(Fx.nrows == nv && Fx.nnz() == blk.nnz());
+            for (int i = 0; i < nv; ++i)
+                CHECK(Fx.rowptr[i + 1] - Fx.rowptr[i] ==
+                      ((i >= v0 && i < v1) ? F.rowptr[i + 1] - F.rowptr[i] : 0));
+            // ghost rows ring by ring (here: cut out of the whole matrix)
+            std::vector<char> in((size_t)nv, 0);
+            std::vector<int> fresh, rows;
+            for (int i = v0; i < v1; ++i) {
+                in[i] = 1;
+                fresh.push_back(i);
+                rows.push_back(i);
+            }
+            for (int s = 0; s < degree; ++s) {
+                std::vector<int> want;
+                for (int i : fresh)
+                    if (i < v0 || i >= v1) want.push_back(i);
+                HostCsr got;
+                got.nrows = nv;
+                got.ncols = nv;
+                got.rowptr.assign((size_t)nv + 1, 0);
+                for (int i : want) got.rowptr[(size_t)i + 1] = F.rowptr[i + 1] - F.rowptr[i];
+                for (int i = 0; i < nv; ++i) got.rowptr[(size_t)i + 1] += got.rowptr[i];
+                for (int i : want)
+                    for (int k = F.rowptr[i]; k < F.rowptr[i + 1]; ++k) {
+                        got.colidx.push_back(F.colidx[k]);
+                        got.vals.push_back(F.vals[k]);
+                    }
+                if (!want.empty()) Fx = dns::host_merge_rows(Fx, got);
+                if (s + 1 == degree) break;
+                std::vector<int> next;
+                for (int i : fresh)
+                    for (int k = Fx.rowptr[i]; k < Fx.rowptr[i + 1]; ++k)
+                        if (!in[Fx.colidx[k]]) {
+                            in[Fx.colidx[k]] = 1;
+                            next.push_back(Fx.colidx[k]);
+                        }
+                std::sort(next.begin(), next.end());
+                fresh.swap(next);
+            }
+            // the index set the rows reach, renumbered
+            std::vector<int> R, loc_of((size_t)nv, -1);
+            for (int i = 0; i < nv; ++i)
+                if (in[i]) R.push_back(i);
+            for (size_t q = 0; q < R.size(); ++q) loc_of[R[q]] = (int)q;
+            HostCsr DFx = Fx;
+            dns::host_scale_rows(dv, DFx);
+            const HostCsr DFc = dns::host_compact_rows(DFx, R, &loc_of);
+            CHECK(DFc.nrows == (int)R.size() && DFc.ncols == (int)R.size());
+            std::vector<double> dvc(R.size());
+            for (size_t q = 0; q < R.size(); ++q) dvc[q] = dv[R[q]];
+            std::vector<int> rows_c;
+            for (int i : rows) rows_c.push_back(loc_of[i]);
+            const HostCsr Gc = dns::host_cheb_poly(DFc, dvc, 1.0, c1, c2, 1e-3,
+                                                   &rows_c);
+            for (int i = v0; i < v1; ++i) {
+                const int q = loc_of[i];
+                const int len = Gc.rowptr[q + 1] - Gc.rowptr[q];
+                CHECK(len == Gw.rowptr[i + 1] - Gw.rowptr[i]);
+                for (int k = 0; k < len && k < Gw.rowptr[i + 1] - Gw.rowptr[i]; ++k) {
+                    CHECK(R[Gc.colidx[Gc.rowptr[q] + k]] ==
+                          Gw.colidx[Gw.rowptr[i] + k]);
+                    CHECK(Gc.vals[Gc.rowptr[q] + k] == Gw.vals[Gw.rowptr[i] + k]);
+                }
+            }
+            // rows kept global when no map is given
+            const HostCsr Fr = dns::host_compact_rows(Fx, R, nullptr);
+            CHECK(Fr.ncols == nv && Fr.nnz() == Fx.nnz());
+        }
+    }
+}
+
 static void test_pair_format(const HostCsr &F, const HostCsr &J) {
     const int nv = F.nrows, np = J.nrows, n = nv + np;
     const HostCsr JT = dns::host_transpose(J);
@@ -345,6 +443,7 @@ int main() {
         build_system(dims.first, dims.second, F, J);
         test_products_and_slices(F, J);
         test_polynomial_rows(F);
+        test_rows_on_their_reach(F);
         test_pair_format(F, J);
         test_halo_lists(F, J);
         test_misc(F);
