@@ -296,6 +296,22 @@ def test_rccl_world_size_one_equals_plain_solve():
     # the recurrence form of Fh^-1 has no row-partitioned path
     with pytest.raises(_capi.DnsError):
         _solve_and_step(saddle, cm, 'cheb', True)
+    # construction from rows: rows that do not fit the partition are refused
+    # (by all ranks together), and so are the set-ups that need whole matrices
+    pr = _problem()
+    NP, NV = pr['J'].shape
+    JT = pr['J'].T.tocsr()
+    with pytest.raises(_capi.DnsError):
+        saddle.SaddleSystem.from_rows(pr['F'][:-2, :], JT[:-2, :], pr['J'],
+                                      NV, NP, cm)
+    rows = saddle.SaddleSystem.from_rows_of(pr['F'], pr['J'], cm)
+    with pytest.raises(_capi.DnsError):
+        rows.setup_precond(cheb_degree=4, schur='jacobi', fhat='explicit')
+    with pytest.raises(_capi.DnsError):
+        rows.set_comm(None)
+    kept, _ = rows.host_matrix_bytes()
+    assert kept > 0
+    rows.close()
     cm.close()
 
 
