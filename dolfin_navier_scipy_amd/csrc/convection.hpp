@@ -51,29 +51,26 @@ struct ConvFromCombo {
     }
 };
 
-// The element computation on twelve local values already in registers
+// One quadrature point of a cell: ph[a] = phi_a(x_q), cv_i = w_q |T| (u . grad)
+// u_i (x_q).  Every product and sum is spelled out (fma / __dmul_rn): the
+// eight-lanes-per-cell kernel and the one-lane-per-cell kernel of the streaming
+// regime call this with the same operands and get the same bits, whatever the
+// compiler would contract on its own.
 __device__ __forceinline__ void
-conv_cells_compute(const double (&ul)[6][2], int ncells, int cc, int c, int q,
-                   bool live, const double *__restrict__ glam,
-                   const double *__restrict__ area,
-                   double *__restrict__ cellvals) {
-    const int qq = (q < 7) ? q : 0;
-    double gl[3][2];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        gl[k][0] = glam[(size_t)(2 * k) * ncells + cc];
-        gl[k][1] = glam[(size_t)(2 * k + 1) * ncells + cc];
-    }
+conv_point(int q, const double (&gl)[3][2], const double (&ul)[6][2],
+           double wq, double (&ph)[6], double &cv0, double &cv1) {
+#pragma clang fp contract(off)
     double uq[2] = {0.0, 0.0};
-    double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-    double ph[6];
+    double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // g[i][d] = d_d u_i
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-        ph[a] = c_conv.phi[qq][a];
-        const double d0 = c_conv.dphi[qq][a][0], d1 = c_conv.dphi[qq][a][1],
-                     d2 = c_conv.dphi[qq][a][2];
-        const double gx = d0 * gl[0][0] + d1 * gl[1][0] + d2 * gl[2][0];
-        const double gy = d0 * gl[0][1] + d1 * gl[1][1] + d2 * gl[2][1];
+        ph[a] = c_conv.phi[q][a];
+        const double d0 = c_conv.dphi[q][a][0], d1 = c_conv.dphi[q][a][1],
+                     d2 = c_conv.dphi[q][a][2];
+        const double gx =
+            fma(d2, gl[2][0], fma(d1, gl[1][0], __dmul_rn(d0, gl[0][0])));
+        const double gy =
+            fma(d2, gl[2][1], fma(d1, gl[1][1], __dmul_rn(d0, gl[0][1])));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             uq[i] = fma(ph[a], ul[a][i], uq[i]);
@@ -81,13 +78,33 @@ conv_cells_compute(const double (&ul)[6][2], int ncells, int cc, int c, int q,
             g[i][1] = fma(gy, ul[a][i], g[i][1]);
         }
     }
-    const double wq = (q < 7 && live) ? c_conv.qw[qq] * area[cc] : 0.0;
-    const double cv0 = wq * (g[0][0] * uq[0] + g[0][1] * uq[1]);
-    const double cv1 = wq * (g[1][0] * uq[0] + g[1][1] * uq[1]);
+    cv0 = __dmul_rn(wq, fma(g[0][1], uq[1], __dmul_rn(g[0][0], uq[0])));
+    cv1 = __dmul_rn(wq, fma(g[1][1], uq[1], __dmul_rn(g[1][0], uq[0])));
+}
+
+// The element computation on twelve local values already in registers
+__device__ __forceinline__ void
+conv_cells_compute(const double (&ul)[6][2], int ncells, int cc, int c, int q,
+                   bool live, const double *__restrict__ glam,
+                   const double *__restrict__ area,
+                   double *__restrict__ cellvals) {
+#pragma clang fp contract(off)
+    const int qq = (q < 7) ? q : 0;
+    double gl[3][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gl[k][0] = glam[(size_t)(2 * k) * ncells + cc];
+        gl[k][1] = glam[(size_t)(2 * k + 1) * ncells + cc];
+    }
+    double ph[6];
+    const double wq =
+        (q < 7 && live) ? __dmul_rn(c_conv.qw[qq], area[cc]) : 0.0;
+    double cv0, cv1;
+    conv_point(qq, gl, ul, wq, ph, cv0, cv1);
     double mine = 0.0, mine8 = 0.0;
 #pragma unroll
     for (int sl = 0; sl < 12; ++sl) {
-        double v = ph[sl >> 1] * ((sl & 1) ? cv1 : cv0);
+        double v = __dmul_rn(ph[sl >> 1], (sl & 1) ? cv1 : cv0);
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
@@ -111,6 +128,7 @@ conv_cells_block(int bid, int ncells, const int *__restrict__ cellmap,   // [12]
              const VAL vsrc, TabRef dbctab,
              double *__restrict__ cellvals,                 // [12][ncells]
              const int *__restrict__ sel = nullptr, int nsel = 0) {
+#pragma clang fp contract(off)
     // sel: only the cells sel[0..nsel) (row-partitioned time steppers: the
     // cells that touch this rank's rows)
     const double *__restrict__ dbcvals = tab_row(dbctab);
@@ -144,30 +162,15 @@ conv_cells_block(int bid, int ncells, const int *__restrict__ cellmap,   // [12]
     double gl[3][2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) gl[k >> 1][k & 1] = __shfl(gl_q, lane0 + k, 64);
-    double uq[2] = {0.0, 0.0};
-    double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // g[i][d] = d_d u_i
     double ph[6];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        ph[a] = c_conv.phi[qq][a];
-        const double d0 = c_conv.dphi[qq][a][0], d1 = c_conv.dphi[qq][a][1],
-                     d2 = c_conv.dphi[qq][a][2];
-        const double gx = d0 * gl[0][0] + d1 * gl[1][0] + d2 * gl[2][0];
-        const double gy = d0 * gl[0][1] + d1 * gl[1][1] + d2 * gl[2][1];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            uq[i] = fma(ph[a], ul[a][i], uq[i]);
-            g[i][0] = fma(gx, ul[a][i], g[i][0]);
-            g[i][1] = fma(gy, ul[a][i], g[i][1]);
-        }
-    }
-    const double wq = (q < 7 && live) ? c_conv.qw[qq] * area[cc] : 0.0;
-    const double cv0 = wq * (g[0][0] * uq[0] + g[0][1] * uq[1]);
-    const double cv1 = wq * (g[1][0] * uq[0] + g[1][1] * uq[1]);
+    const double wq =
+        (q < 7 && live) ? __dmul_rn(c_conv.qw[qq], area[cc]) : 0.0;
+    double cv0, cv1;
+    conv_point(qq, gl, ul, wq, ph, cv0, cv1);
     double mine = 0.0, mine8 = 0.0;     // slots q and q + 8 after the reduction
 #pragma unroll
     for (int sl = 0; sl < 12; ++sl) {
-        double v = ph[sl >> 1] * ((sl & 1) ? cv1 : cv0);
+        double v = __dmul_rn(ph[sl >> 1], (sl & 1) ? cv1 : cv0);
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
@@ -191,6 +194,65 @@ k_conv_cells(int ncells, const int *__restrict__ cellmap,
              int nsel) {
     conv_cells_block(blockIdx.x, ncells, cellmap, glam, area,
                      ConvFromVec{v_inner}, dbctab, cellvals, sel, nsel);
+}
+
+// The same cell values with ONE LANE PER CELL (streaming regime, >= kConvLaneMin
+// cells): every load and store instruction of a wave covers 64 consecutive
+// cells of a slot-major array -- 256 / 512 contiguous bytes instead of eight
+// 32 / 64-byte pieces --, 31 independent loads per lane are in flight, and the
+// seven quadrature points are walked in registers.  The sums over the points
+// follow the tree of the eight-lane kernel's shuffles, ((0+1)+(2+3)) +
+// ((4+5)+(6+0)): the values are the same bit for bit.
+constexpr int kConvLaneMin = 200000;
+
+__global__ void __launch_bounds__(kBlock)
+k_conv_cells_lane(int ncells, const int *__restrict__ cellmap,
+                  const double *__restrict__ glam,
+                  const double *__restrict__ area,
+                  const double *__restrict__ v_inner, TabRef dbctab,
+                  double *__restrict__ cellvals, const int *__restrict__ sel,
+                  int nsel) {
+#pragma clang fp contract(off)
+    const double *__restrict__ dbcvals = tab_row(dbctab);
+    const int slot = blockIdx.x * kBlock + threadIdx.x;
+    const bool live = sel ? slot < nsel : slot < ncells;
+    if (!live) return;
+    const int c = sel ? sel[slot] : slot;
+    int m[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) m[k] = cellmap[(size_t)k * ncells + c];
+    double gl[3][2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gl[k >> 1][k & 1] = glam[(size_t)k * ncells + c];
+    const double ar = area[c];
+    double ul[6][2];
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+        ul[k >> 1][k & 1] = (m[k] >= 0) ? v_inner[m[k]] : dbcvals[-m[k] - 1];
+    double part[12][4];                 // tree of the sums over the points
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        double ph[6];
+        double cv0, cv1;
+        conv_point(q, gl, ul, __dmul_rn(c_conv.qw[q], ar), ph, cv0, cv1);
+#pragma unroll
+        for (int sl = 0; sl < 12; ++sl) {
+            // (a product of its own, as in the eight-lane kernel: not to be
+            // contracted into the sum behind it)
+            const double v = __dmul_rn(ph[sl >> 1], (sl & 1) ? cv1 : cv0);
+            // pairs (0,1) (2,3) (4,5) (6,7): v_q + v_{q^1}, the eighth lane's
+            // value is zero
+            if (q & 1) part[sl][q >> 1] += v;
+            else part[sl][q >> 1] = v;
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 12; ++sl) {
+        part[sl][3] += 0.0;             // v_6 + v_7, v_7 = 0
+        const double s = (part[sl][0] + part[sl][1]) +
+                         (part[sl][2] + part[sl][3]);
+        cellvals[(size_t)sl * ncells + c] = s;
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -227,6 +289,7 @@ struct dns_conv {
         const int r = std::min(std::max(dbc_row + row_shift, 0), dbc_rows - 1);
         return {dbc_tab.p + (size_t)r * std::max(1, ndbc), nullptr, 0, 1};
     }
+    int lane_min = dns::kConvLaneMin;      // DNS_CONV_LANE_MIN (read at create)
     std::vector<int> cmap_host;            // [12][ncells], as on the device
     std::vector<int> gptr_host, gidx_host; // the inverted index, as on the device
     struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
@@ -251,6 +314,15 @@ struct dns_conv {
                       const int *sel = nullptr, int nsel = 0) {
         const int live = sel ? nsel : ncells;
         if (live <= 0) return DNS_OK;
+        if (live >= lane_min) {
+            // streaming regime: one lane per cell (same values, bit for bit)
+            hipLaunchKernelGGL(dns::k_conv_cells_lane,
+                               (live + dns::kBlock - 1) / dns::kBlock,
+                               dns::kBlock, 0, s, ncells, cellmap.p, glam.p,
+                               area.p, v_dev, dbc_ref(), cellvals.p, sel, nsel);
+            DNS_HIP(hipGetLastError());
+            return DNS_OK;
+        }
         const int g1 = (8 * live + dns::kBlock - 1) / dns::kBlock;
         hipLaunchKernelGGL(dns::k_conv_cells, g1, dns::kBlock, 0, s, ncells,
                            cellmap.p, glam.p, area.p, v_dev, dbc_ref(),

@@ -60,6 +60,23 @@ def test_full_size_convection_and_bad_maps(conv_setup):
     full[femp['dbcinds'], 0] = femp['dbcvals']
     ref = th.convection_vec(full)[inv, :]
     assert np.abs(cv.apply(v) - ref).max() <= 1e-13*np.abs(ref).max()
+    # the one-lane-per-cell kernel of the streaming regime (DNS_CONV_LANE_MIN,
+    # read when the operator is created): the same values, bit for bit
+    import os
+    got8 = cv.apply(v)
+    old = os.environ.get('DNS_CONV_LANE_MIN')
+    os.environ['DNS_CONV_LANE_MIN'] = '1'
+    try:
+        cvl = convection.ConvectionP2.from_taylor_hood(
+            th, inv, femp['dbcinds'], femp['dbcvals'])
+    finally:
+        if old is None:
+            del os.environ['DNS_CONV_LANE_MIN']
+        else:
+            os.environ['DNS_CONV_LANE_MIN'] = old
+    got1 = cvl.apply(v)
+    assert np.array_equal(got1, got8)
+    cvl.close()
     cv.close()
     # a dof that is neither inner nor Dirichlet is rejected on the host
     with pytest.raises(_capi.DnsError):
