@@ -203,7 +203,7 @@ k_conv_cells(int ncells, const int *__restrict__ cellmap,
 // seven quadrature points are walked in registers.  The sums over the points
 // follow the tree of the eight-lane kernel's shuffles, ((0+1)+(2+3)) +
 // ((4+5)+(6+0)): the values are the same bit for bit.
-constexpr int kConvLaneMin = 200000;
+constexpr int kConvLaneMin = 100000;   // (refine 3, 1.5e5 cells: 1402 -> 1434 steps/s; refine 2, 3.8e4: no difference)
 
 __global__ void __launch_bounds__(kBlock)
 k_conv_cells_lane(int ncells, const int *__restrict__ cellmap,
