@@ -1713,6 +1713,13 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     int c = (last_iters >= 0) ? last_iters + 1 : std::min(m, 16);
     c = std::min(m, std::max(gran, (c + gran - 1) / gran * gran));
     if (cycle_first > 0) c = std::min(m, cycle_first);
+    // a host-callback communicator cannot pipeline (its collectives wait for
+    // the stream): a solve the previous one predicts as a single step starts
+    // with the ONE-step cycle the pipelined RCCL path runs (k_arn_tail_lazy1:
+    // norms with the dots, the step always taken) -- the two-ranks-on-one-GPU
+    // rehearsal runs the algorithm the ranks of a node run
+    else if (dist() && !graph_capable() && last_iters >= 0 && last_iters <= 1)
+        c = 1;
     if (pipeline_c > 0) c = std::min(m, pipeline_c);
     // dots fused into the K apply while the system is launch-latency bound
     fuse_dots = n <= 400000;
