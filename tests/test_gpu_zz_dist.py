@@ -171,6 +171,17 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
         info['precond'] = system.precond_info()
     x = system.solve(pr['rhsv'], pr['rhsp'], rtol=1e-12, reorth=reorth)
     stats = dict(system.last_stats)
+    if info is not None and info.get('revalue'):
+        # new values of F (the same ones) through `dns_saddle_update_values` --
+        # the values of the own rows on a handle created from rows -- and the
+        # set-up once more: the same answer
+        system.update_values(system._f.data.copy())
+        system.setup_precond(cheb_degree=6 if cyl3 else 4,
+                             schur='mg' if mgs else 'dense', fhat=fhat,
+                             factorization=fact,
+                             drop_tol=1e-3 if cyl3 else None)
+        x2 = system.solve(pr['rhsv'], pr['rhsp'], rtol=1e-12, reorth=reorth)
+        assert np.array_equal(x, x2)
     # a few device-resident CNAB steps through the same communicator
     stepper = sad.ImexStepper(system, pr['R1'])
     dt = pr['dt']
@@ -429,7 +440,7 @@ def _worker_rows(rank, world, port, outdir):
     cm = dcomm.Comm.gloo(0)
     out = {}
     for fhat in ('full', 'full_loc', 'mg3part', 'mg3part_loc', 'mg3part_rep'):
-        info = {}
+        info = {'revalue': True}
         x, st, v, p = _solve_and_step(saddle, cm, fhat, False, info=info)
         out[fhat] = (x, v, p, st['iters'], st['true_relres'])
     np.savez(os.path.join(outdir, 'rank{0}.npz'.format(rank)),
