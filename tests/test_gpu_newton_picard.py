@@ -205,6 +205,58 @@ def test_conv_kat_at_full_size():
     cv.close()
 
 
+def test_conv_split_into_inner_and_boundary_parts():
+    """The reference's second known-answer test of the convection matrices
+    (`tests/test_units_fenicsci.py:132-188`, `test_conv_asquad`): on the driven
+    cavity (N = 15) with the field u = ((1-x)x(1-y)y x + 2, (1-x)x(1-y)y y + 1),
+    split into its inner part u_i and its boundary part u_gamma,
+
+        N(u)[inner, :] u  ==  H (u_i x u_i) + ((N1 + N2)(u_gamma) u_i)[inner]
+                                + fv(u_gamma)[inner]
+
+    with `N1, N2, fv = get_convmats(u0 = u_gamma)` -- the linearisation about a
+    field that lives on the boundary only is exactly what `get_v_conv_conts`
+    feeds the Newton/Picard systems with (snu:109-133).  Mirrored on the DEVICE
+    assembly: the matrices by `dns_conv_assemble` about u_gamma, the vectors by
+    the device convection kernel.  `H` (`ass_convmat_asmatquad`, the quadratic
+    tensor of the reduced-order models: out of scope) enters
+    the identity only through `H (u_i x u_i) = N(u_i) u_i`, which the device
+    kernel evaluates directly."""
+    from dolfin_navier_scipy_amd import convection, newton_picard as dnp
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='drivencavity', N=15, nu=1e-2)
+    th, inv = femp['V'], femp['invinds']
+    dbcinds = np.asarray(femp['dbcinds'])
+    xy = th.nodecoords
+    bub = (1 - xy[:, 0])*xy[:, 0]*(1 - xy[:, 1])*xy[:, 1]
+    uvec = np.zeros((th.vdim, 1))
+    uvec[0::2, 0] = bub*xy[:, 0] + 2
+    uvec[1::2, 0] = bub*xy[:, 1] + 1
+    u_i = uvec[inv]
+    gam = uvec[dbcinds, 0]
+    # (the split is a split: test_units_fenicsci.py:186-188)
+    uvec_i, uvec_g = 0*uvec, uvec.copy()
+    uvec_i[inv] = uvec[inv]
+    uvec_g[inv] = 0
+    assert np.linalg.norm(uvec - uvec_g - uvec_i) < 1e-14
+    cv = convection.ConvectionP2.from_taylor_hood(th, inv, dbcinds, gam)
+    cv.bind_pattern(dnp.union_pattern(cv.connectivity()))
+    # N(u)[inner, :] u with u's own boundary values
+    classicalconv = cv.apply(u_i, scale=1.0)
+    assert np.abs(classicalconv - th.convection_vec(uvec)[inv]).max() <= \
+        1e-12*np.abs(classicalconv).max()
+    # (N1 + N2)(u_gamma) on the inner dofs and fv(u_gamma) = N(u_gamma) u_gamma
+    N12, _, fv_gamma = cv.assemble(0*u_i, newton=True)
+    # H (u_i x u_i) = N(u_i) u_i: homogeneous boundary values
+    cv.set_dbcvals(0*gam)
+    inner_inner = cv.apply(u_i, scale=1.0)
+    quadconv = inner_inner + N12 @ u_i + fv_gamma.reshape((-1, 1))
+    scale = np.abs(classicalconv).max()
+    assert np.allclose(classicalconv, quadconv)          # (:184)
+    assert np.abs(classicalconv - quadconv).max() <= 1e-12*scale
+    cv.close()
+
+
 def test_device_newton_picard_driver_matches_oracle(setup, cvop):
     from dolfin_navier_scipy_amd import newton_picard as dnp, saddle
     s = setup

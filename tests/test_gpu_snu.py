@@ -217,6 +217,69 @@ def test_solve_nse_explicit_static_bcs(snu, toy_prob, scheme):
     assert _rel(ylist[-1][toy_prob['invinds']], vo) <= VTOL
 
 
+def test_time_integration_residuals_of_solve_nse(snu):
+    """The reference's own known-answer test of `solve_nse`
+    (`tests/test_units_residuals.py:32-134`): `gen_bccont` set-up with
+    nu = 1e-3, charvel = 0.2, `treat_nonl_explicit=True`, `start_ssstokes=True`,
+    `return_vp_dict=True`, `t0 = 0, tE = 0.1, Nts = 2` -- the Heun start and one
+    AB2 step -- and then the SciPy residual of the AB2 step, written with the
+    ASSEMBLED quantities (M, A, JT, fv, `dts.get_convvec` of the saved
+    velocities), vanishes: `np.allclose(abscres, 0.)`
+    (test_units_residuals.py:121-134).  Mirrored with the formulas of that file
+    on the outputs of THIS `solve_nse` (device path): it holds only if the
+    closures `solve_nse` hands to the integrator -- convection with boundary
+    values and its sign, merged right-hand sides, pressure scaling, appended
+    boundary values -- compose as the reference's do.
+    What is NOT mirrored, and why: (i) the reference runs it on
+    `karman2D-rotcyl_lvl1`, whose geometry description this repository's
+    assembler does not read -- the property does not depend on the mesh, the
+    `2D-double-rotcyl_lvl1` set-up of config 5 stands in; (ii) the two Heun
+    assertions of that file (:100-118) describe an integrator the reference no
+    longer has: at this commit `_onestepheun` predicts with implicit Euler
+    (`scheme='IMEX-Euler'`, tiu:368,398-403), corrects with `amat=M`
+    (tiu:459-466) and does not store the `(tm, 'heunpred')` entry the test
+    reads (tiu:448 is commented out) -- the Heun start is pinned by the fixtures
+    generated from the reference's `time_int_utils` instead
+    (`tests/golden/`, `tests/test_gpu_imex.py`)."""
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='gen_bccont', nu=1e-3, charvel=0.2,
+                                 bccontrol=False)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    JT = J.T.tocsr()
+    fv = rhsd['fv']
+    th, inv = femp['V'], femp['invinds']
+    t0, tE, Nts = 0.0, 0.1, 2
+    vpdct = snu.solve_nse(
+        A=A, M=M, J=J, fv=fv, fp=rhsd['fp'], V=th, invinds=inv,
+        dbcinds=femp['dbcinds'].tolist(), dbcvals=femp['dbcvals'].tolist(),
+        t0=t0, tE=tE, Nts=Nts, treat_nonl_explicit=True, return_vp_dict=True,
+        start_ssstokes=True, solver=dict(rtol=1e-13))
+    dt = (tE - t0)/Nts
+    tm = (tE - t0)/2
+    assert sorted(vpdct.keys()) == [t0, tm, tE]
+
+    def convvec(vfull):
+        # `dts.get_convvec(V=V, u0_vec=vfull, invinds=invinds)`
+        return th.convection_vec(vfull)[inv, :]
+    iniconvvec = convvec(vpdct[t0]['v'])
+    cnhevw = vpdct[tm]['v']
+    cnhev = cnhevw[inv]
+    cnabv, cnabp = vpdct[tE]['v'][inv], vpdct[tE]['p']
+    hcconvvec = convvec(cnhevw)
+    # the AB2 step (test_units_residuals.py:121-125)
+    abtrhs = M @ cnhev - .5*dt*(A @ cnhev - iniconvvec + 3.*hcconvvec) \
+        + dt*fv
+    matvp = M @ cnabv + .5*dt*(A @ cnabv) - dt*(JT @ cnabp)
+    abscres = np.linalg.norm(matvp - abtrhs)
+    print('AB2 step, SciPy residual:', abscres, 'of', np.linalg.norm(abtrhs))
+    assert np.allclose(abscres, 0.), abscres           # (:134)
+    assert abscres <= 1e-9*np.linalg.norm(abtrhs)
+    # (and the velocities are discretely divergence free up to the data)
+    for v in (cnhev, cnabv):
+        assert np.linalg.norm(J @ v - rhsd['fp']) <= 1e-9*max(
+            1., np.linalg.norm(rhsd['fp']))
+
+
 def _controlled_setup(prob, amplitude):
     from dolfin_navier_scipy_amd.fem import condense_sysmatsbybcs
     th, stms = prob['th'], prob['stms']

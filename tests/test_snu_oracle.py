@@ -149,3 +149,80 @@ def test_solve_nse_controlled_boundary_restriction(toy_prob):
     assert v1.shape == v2.shape
     assert np.linalg.norm(v1 - v2) <= 1e-10*np.linalg.norm(v2)
     assert np.linalg.norm(p1 - p2) <= 1e-8*np.linalg.norm(p2)
+
+
+# ---- the reference's own known-answer tests, on the ORACLE -------------------
+def test_oracle_solve_nse_ab2_residual_as_the_reference_tests_it(toy_prob):
+    """`tests/test_units_residuals.py:32-134` on `oracle/snu_oracle.solve_nse`:
+    Stokes start, `Nts = 2` (Heun start, one AB2 step), and the SciPy residual
+    of the AB2 step written with the ASSEMBLED quantities vanishes
+    (`np.allclose(abscres, 0.)`, :121-134).  (The two Heun assertions of that
+    file describe an integrator the reference no longer has at this commit --
+    `_onestepheun` predicts with implicit Euler and corrects with `amat=M`,
+    tiu:368,398-403,459-466, and the `(tm, 'heunpred')` entry the test reads is
+    not stored, tiu:448 -- the Heun start is pinned by the fixtures generated
+    from the reference's `time_int_utils`, tests/test_oracle_golden.py.)"""
+    th, smc, rhsd = toy_prob['th'], toy_prob['smc'], toy_prob['rhsd']
+    inv = toy_prob['invinds']
+    M, A, J = smc['M'], smc['A'], smc['J']
+    JT = sps.csr_matrix(J.T)
+    fv = rhsd['fv']
+    t0, tE, Nts = 0.0, 0.1, 2
+    trange = np.linspace(t0, tE, Nts + 1)
+    got = {}
+
+    def savevp(vfull, pvec, time=None):
+        got[time] = dict(v=np.array(vfull), p=np.array(pvec))
+    so.solve_nse(A=A, M=M, J=J, fv=fv, fp=rhsd['fp'], V=th, invinds=inv,
+                 dbcinds=toy_prob['dbcinds'].tolist(),
+                 dbcvals=toy_prob['dbcvals'].tolist(), trange=trange,
+                 start_ssstokes=True, savevp=savevp)
+    dt = (tE - t0)/Nts
+    tm = trange[1]
+    assert sorted(got.keys()) == sorted(trange.tolist())
+
+    def convvec(vfull):
+        return th.convection_vec(vfull)[inv, :]
+    iniconvvec = convvec(got[t0]['v'])
+    cnhev = got[tm]['v'][inv]
+    hcconvvec = convvec(got[tm]['v'])
+    cnabv, cnabp = got[tE]['v'][inv], got[tE]['p']
+    abtrhs = M @ cnhev - .5*dt*(A @ cnhev - iniconvvec + 3.*hcconvvec) \
+        + dt*fv
+    matvp = M @ cnabv + .5*dt*(A @ cnabv) - dt*(JT @ cnabp)
+    abscres = np.linalg.norm(matvp - abtrhs)
+    assert np.allclose(abscres, 0.), abscres
+    assert abscres <= 1e-10*np.linalg.norm(abtrhs)
+
+
+def test_host_convection_matrices_split_as_the_reference_tests_it():
+    """`tests/test_units_fenicsci.py:132-188` (`test_conv_asquad`) on the HOST
+    assembly the oracle's `get_v_conv_conts` is made of: driven cavity N = 15,
+    u = ((1-x)x(1-y)y x + 2, (1-x)x(1-y)y y + 1) split into inner and boundary
+    part,  N(u)[inner, :] u == N(u_i) u_i + ((N1 + N2)(u_gamma) u_i)[inner]
+    + (N(u_gamma) u_gamma)[inner]   (`H (u_i x u_i) = N(u_i) u_i`: the quadratic
+    tensor itself is out of scope), and `N(u)u == N1(u) u == N2(u) u`
+    (:84-85) for the same field."""
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='drivencavity', N=15, nu=1e-2)
+    th, inv = femp['V'], femp['invinds']
+    xy = th.nodecoords
+    bub = (1 - xy[:, 0])*xy[:, 0]*(1 - xy[:, 1])*xy[:, 1]
+    uvec = np.zeros((th.vdim, 1))
+    uvec[0::2, 0] = bub*xy[:, 0] + 2
+    uvec[1::2, 0] = bub*xy[:, 1] + 1
+    uvec_i, uvec_g = 0*uvec, uvec.copy()
+    uvec_i[inv] = uvec[inv]
+    uvec_g[inv] = 0
+    assert np.linalg.norm(uvec - uvec_g - uvec_i) < 1e-14
+    conv = th.convection_vec(uvec)
+    N1, N2 = th.convection_mats(uvec)[:2]
+    assert np.allclose(conv, N1 @ uvec) and np.allclose(conv, N2 @ uvec)
+    N1g, N2g = th.convection_mats(uvec_g)[:2]
+    fvg = th.convection_vec(uvec_g)
+    classicalconv = (N1 @ uvec)[inv]
+    quadconv = th.convection_vec(uvec_i)[inv] + \
+        ((N1g + N2g) @ uvec_i)[inv] + fvg[inv]
+    assert np.allclose(classicalconv, quadconv)
+    assert np.abs(classicalconv - quadconv).max() <= \
+        1e-12*np.abs(classicalconv).max()
