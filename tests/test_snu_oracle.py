@@ -226,3 +226,32 @@ def test_host_convection_matrices_split_as_the_reference_tests_it():
     assert np.allclose(classicalconv, quadconv)
     assert np.abs(classicalconv - quadconv).max() <= \
         1e-12*np.abs(classicalconv).max()
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('scheme', ['cnab', 'sbdf2'])
+def test_oracle_solve_nse_converges_with_second_order_in_time(toy_prob, scheme):
+    """`tests/tdp_convcheck.py:82-137` ("Check for 2nd order convergence") on the
+    oracle: Stokes start, explicit treatment of the convection, the final
+    velocity for `Nts`, `2 Nts`, `4 Nts` steps against `8 Nts` steps in the
+    M-norm falls like `Nts**-2` for both schemes of the script"""
+    th, smc, rhsd = toy_prob['th'], toy_prob['smc'], toy_prob['rhsd']
+    M = smc['M']
+    kw = dict(A=smc['A'], M=M, J=smc['J'], fv=rhsd['fv'], fp=rhsd['fp'], V=th,
+              invinds=toy_prob['invinds'],
+              dbcinds=toy_prob['dbcinds'].tolist(),
+              dbcvals=toy_prob['dbcvals'].tolist(), start_ssstokes=True,
+              time_int_scheme=scheme)
+    Nts, dblng, tE = 10, 3, 0.1
+
+    def final(nts):
+        return so.solve_nse(trange=np.linspace(0., tE, nts + 1), **kw)[0]
+    vfref = final(Nts*2**dblng)
+    errs = []
+    for k in range(dblng):
+        difv = final(Nts*2**k) - vfref
+        errs.append(float(np.sqrt((difv.T @ (M @ difv)).item())))
+    orders = [np.log2(errs[k]/errs[k + 1]) for k in range(dblng - 1)]
+    assert orders[0] >= 1.8 and all(o >= 1.6 for o in orders), (errs, orders)
