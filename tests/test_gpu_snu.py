@@ -434,6 +434,55 @@ def test_solve_nse_newton_picard_branch(snu, toy_prob):
                            toy_prob['dbcvals'])
 
 
+def test_newton_sweeps_at_once_and_resumed_as_the_reference_driver(snu):
+    """`tests/time_dep_nse_linearizations.py:10-61` (cylinder wake N = 1, Re = 40,
+    `vel_nwtn_tol = 1e-14`, Stokes start; the driver's dt = 0.01 is beyond the
+    stability limit of the explicit run that seeds the sweeps on this mesh --
+    the blow-up guard of tiu:99-103 stops it at t = 0.22 -- so dt = 0.0025 here:
+    Nts = 100, tE = 0.25): eight sweeps at once (the first four Picard), then one sweep
+    whose velocities are handed back as `lin_vel_point` to seven Newton sweeps
+    (`vel_pcrd_stps=0`) -- "1, 2, check, check" (:45).  Both runs end at the
+    solution of the same nonlinear trapezoidal equations: they agree, and the
+    nonlinear residual of every step, written with the assembled quantities,
+    vanishes.  (The driver asserts nothing; what it exercises is that a sweep
+    resumes from a stored linearisation trajectory.)"""
+    from dolfin_navier_scipy_amd.fem import get_sysmats
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=1, Re=40)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    th, inv = femp['V'], femp['invinds']
+    kw = dict(A=A, M=M, J=J, fv=rhsd['fv'], fp=rhsd['fp'], V=th, invinds=inv,
+              dbcinds=femp['dbcinds'].tolist(),
+              dbcvals=femp['dbcvals'].tolist(), t0=0.0, tE=0.25, Nts=100,
+              vel_nwtn_tol=1e-14, start_ssstokes=True,
+              treat_nonl_explicit=False, return_dictofvelstrs=True,
+              return_dictofpstrs=True, solver=dict(rtol=1e-13))
+    v8, p8 = snu.solve_nse(vel_nwtn_stps=8, **kw)
+    csd, _ = snu.solve_nse(vel_nwtn_stps=1, **kw)
+    v7, p7 = snu.solve_nse(vel_nwtn_stps=7, lin_vel_point=csd,
+                           vel_pcrd_stps=0, **kw)
+    trange = np.linspace(0., 0.25, 101)
+    dt = trange[1] - trange[0]
+    JT = J.T.tocsr()
+    worst, wres = 0., 0.
+
+    def cfull(t):
+        return th.convection_vec(v7[t])[inv, :]
+    for k in range(1, trange.size):
+        tc, tn = trange[k - 1], trange[k]
+        worst = max(worst, _rel(v7[tn][inv], v8[tn][inv]))
+        vc, vn = v7[tc][inv], v7[tn][inv]
+        res = M @ (vn - vc) + .5*dt*(A @ (vn + vc) + cfull(tn) + cfull(tc)) \
+            - dt*(JT @ p7[tn]) - dt*rhsd['fv']
+        wres = max(wres, np.linalg.norm(res)/np.linalg.norm(M @ vn))
+    print('8 sweeps at once vs 1 + 7 resumed: worst relative difference',
+          worst, '; worst nonlinear residual', wres)
+    # (eight sweeps of which four are Picard have not converged as far as
+    # one Picard + seven Newton sweeps: 2.2e-8 apart, the resumed run solves
+    # the nonlinear equations to 6e-11)
+    assert worst <= 1e-6
+    assert wres <= 1e-9
+
+
 def test_solve_nse_newton_picard_sections_and_full_sweep(snu, toy_prob):
     """`nsects`, `addfullsweep`, `loc_pcrd_stps` (snu:1076-1091, 1576-1587)
     through the product `solve_nse` against the oracle"""
