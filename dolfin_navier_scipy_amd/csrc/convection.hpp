@@ -295,7 +295,12 @@ struct dns_conv {
     struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
     ~dns_conv();
     // local matrices of N1(u) (+ N2(u)) -> mat->L
-    int enqueue_mat_cells(const double *v_dev, int newton, hipStream_t s);
+    int enqueue_mat_cells(const double *v_dev, int newton, hipStream_t s,
+                          const int *sel = nullptr, int nsel = 0);
+    // non-zeros [z0, z1) / rows [r0, r1) of the bound pattern (one rank's)
+    struct RowRange {
+        int z0, z1, r0, r1;
+    };
     // nvals (and F = M + tdt (A + N) if fvals) in the bound pattern
     int enqueue_mat_gather(double *nvals, const double *mvals,
                            const double *avals, double tdt, double *fvals,
@@ -308,7 +313,8 @@ struct dns_conv {
                               const double *rhscon, double *fvn,
                               hipStream_t s, const int *kpos = nullptr,
                               double *kvals = nullptr,
-                              bool rhscon_from_cells = false);
+                              bool rhscon_from_cells = false,
+                              const RowRange *rr = nullptr);
     // element kernel alone (the gather is fused into the step prologue)
     int enqueue_cells(const double *v_dev, hipStream_t s,
                       const int *sel = nullptr, int nsel = 0) {
@@ -380,12 +386,16 @@ k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
                  const double *__restrict__ glam,
                  const double *__restrict__ area,
                  const double *__restrict__ v_inner, TabRef dbctab,
-                 int newton, double *__restrict__ L) {      // [144][ncells]
+                 int newton, double *__restrict__ L,        // [144][ncells]
+                 const int *__restrict__ sel = nullptr, int nsel = 0) {
+    // sel: only the cells sel[0..nsel) (row-partitioned trapezoidal stepper:
+    // the cells that touch this rank's rows)
     const double *__restrict__ dbcvals = tab_row(dbctab);
     const int t = blockIdx.x * kBlock + threadIdx.x;
-    const int c = t >> 3;
+    const int slot = t >> 3;
     const int a = t & 7;
-    if (c >= ncells || a >= 6) return;
+    if (slot >= (sel ? nsel : ncells) || a >= 6) return;
+    const int c = sel ? sel[slot] : slot;
     double ul[6][2];
 #pragma unroll
     for (int b = 0; b < 6; ++b)
@@ -508,12 +518,15 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
                      double *__restrict__ kvals = nullptr,
                      const int *__restrict__ gptr = nullptr,
                      const int *__restrict__ gidx = nullptr,
-                     const double *__restrict__ cellvals = nullptr) {
+                     const double *__restrict__ cellvals = nullptr,
+                     int z0 = 0, int r0 = 0) {
+    // (z0, r0: first non-zero / first row of a range that ends at nnz /
+    // nrows -- the rows of one rank)
     // kpos / kvals: the new value of F goes straight into its place in the
     // assembled K = [[F, JT], [J, 0]] as well (a scatter kernel of its own
     // before)
     if ((int)blockIdx.x < gm) {
-        for (int z = blockIdx.x * kBlock + threadIdx.x; z < nnz;
+        for (int z = z0 + blockIdx.x * kBlock + threadIdx.x; z < nnz;
              z += gm * kBlock) {
             double s = 0.0;
             for (int k = mptr[z]; k < mptr[z + 1]; ++k) s += L[midx[k]];
@@ -528,7 +541,7 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
     }
     const double *__restrict__ dbcvals = tab_row(dbctab);
     const int rb = blockIdx.x - gm, nrb = gridDim.x - gm;
-    for (int r = rb * kBlock + threadIdx.x; r < nrows; r += nrb * kBlock) {
+    for (int r = r0 + rb * kBlock + threadIdx.x; r < nrows; r += nrb * kBlock) {
         double s = 0.0;
         for (int k = bptr[r]; k < bptr[r + 1]; ++k)
             s = fma(L[bidx[k]], dbcvals[bbc[k]], s);
@@ -557,11 +570,14 @@ struct dns_conv_mat {
 inline dns_conv::~dns_conv() { delete mat; }
 
 inline int dns_conv::enqueue_mat_cells(const double *v_dev, int newton,
-                                       hipStream_t s) {
-    const int g = (8 * ncells + dns::kBlock - 1) / dns::kBlock;
+                                       hipStream_t s, const int *sel,
+                                       int nsel) {
+    const int live = sel ? nsel : ncells;
+    if (live <= 0) return DNS_OK;
+    const int g = (8 * live + dns::kBlock - 1) / dns::kBlock;
     hipLaunchKernelGGL(dns::k_conv_mat_cells, g, dns::kBlock, 0, s, ncells,
                        cellmap.p, glam.p, area.p, v_dev, dbc_ref(), newton,
-                       mat->L.p);
+                       mat->L.p, sel, nsel);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }
@@ -585,19 +601,24 @@ inline int dns_conv::enqueue_mat_bc_gather(double *nvals, const double *mvals,
                                            const double *rhscon, double *fvn,
                                            hipStream_t s, const int *kpos,
                                            double *kvals,
-                                           bool rhscon_from_cells) {
-    const int gm = std::max(1, std::min((mat->nnz + dns::kBlock - 1) /
+                                           bool rhscon_from_cells,
+                                           const RowRange *rr) {
+    // rr: the non-zeros [z0, z1) and rows [r0, r1) of one rank only
+    const int z0 = rr ? rr->z0 : 0, z1 = rr ? rr->z1 : mat->nnz;
+    const int r0 = rr ? rr->r0 : 0, r1 = rr ? rr->r1 : nv_inner;
+    const int gm = std::max(1, std::min((z1 - z0 + dns::kBlock - 1) /
                                             dns::kBlock, 4096));
-    const int gb = std::max(1, std::min((nv_inner + dns::kBlock - 1) /
+    const int gb = std::max(1, std::min((r1 - r0 + dns::kBlock - 1) /
                                             dns::kBlock, 2048));
     hipLaunchKernelGGL(dns::k_conv_mat_bc_gather, gm + gb, dns::kBlock, 0, s,
-                       gm, mat->nnz, mat->mptr.p, mat->midx.p, mat->L.p, nvals,
-                       mvals, avals, tdt, fvals, nv_inner, mat->bptr.p,
+                       gm, z1, mat->mptr.p, mat->midx.p, mat->L.p, nvals,
+                       mvals, avals, tdt, fvals, r1, mat->bptr.p,
                        mat->bidx.p, mat->bbc.p, dbc_ref(), rhsbc, fv, rhscon,
                        fvn, kpos, kvals,
                        rhscon_from_cells ? gptr.p : (const int *)nullptr,
                        rhscon_from_cells ? gidx.p : (const int *)nullptr,
-                       rhscon_from_cells ? cellvals.p : (const double *)nullptr);
+                       rhscon_from_cells ? cellvals.p : (const double *)nullptr,
+                       z0, r0);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

@@ -13,6 +13,7 @@
 #pragma once
 #include <mutex>
 #include "convection.hpp"
+#include "halo.hpp"
 #include "solver.hpp"
 
 namespace dns {
@@ -36,13 +37,16 @@ k_trap_rhs(int nv, int np, const int *__restrict__ rowptr,
            const double *__restrict__ avals, const double *__restrict__ ncvals,
            const double *__restrict__ v_c, double hdt,
            const double *__restrict__ fvn_n, const double *__restrict__ fvn_c,
-           const double *__restrict__ fp, double *__restrict__ b) {
+           const double *__restrict__ fp, double *__restrict__ b,
+           int r0 = 0, int r1 = -1) {
+    // rows [r0, r1) only (a rank's rows; r1 < 0: all)
+    if (r1 < 0) r1 = nv;
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
     // ncvals == nullptr: the convection part of C_c v_c has gone into fvn_c
     // as the convection VECTOR (dns_trap::assemble_current)
-    for (int row = sub; row < nv; row += nsub) {
+    for (int row = r0 + sub; row < r1; row += nsub) {
         double s = 0.0;
         const int k1 = rowptr[row + 1];
         if (ncvals) {
@@ -83,13 +87,23 @@ __global__ void __launch_bounds__(kBlock)
 k_trap_updnorm(int nv, const int *__restrict__ rowptr,
                const int *__restrict__ colidx, const double *__restrict__ mvals,
                const double *__restrict__ x, const double *__restrict__ y,
-               double *__restrict__ part, double *__restrict__ copy_out) {
+               double *__restrict__ part, double *__restrict__ copy_out,
+               int r0 = 0, int r1 = -1, const int *__restrict__ halo = nullptr,
+               int nhalo = 0) {
+    // rows [r0, r1) only (a rank's share of the norm; r1 < 0: all); halo:
+    // entries of x that are stored as well (what the rank's cells and rows
+    // will read of this velocity as a linearisation point)
+    if (r1 < 0) r1 = nv;
     __shared__ double red[4];
     const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
     const int sublane = threadIdx.x % LPR;
     const int nsub = gridDim.x * (kBlock / LPR);
     double acc = 0.0;
-    for (int row = sub; row < nv; row += nsub) {
+    if (copy_out)
+        for (int i = blockIdx.x * kBlock + threadIdx.x; i < nhalo;
+             i += gridDim.x * kBlock)
+            copy_out[halo[i]] = x[halo[i]];
+    for (int row = r0 + sub; row < r1; row += nsub) {
         double s = 0.0;
         const int k1 = rowptr[row + 1];
         for (int k = rowptr[row] + sublane; k < k1; k += LPR) {
@@ -112,8 +126,9 @@ k_trap_updnorm(int nv, const int *__restrict__ rowptr,
 __global__ void __launch_bounds__(kBlock)
 k_trap_fc(int nv, const int *__restrict__ gptr, const int *__restrict__ gidx,
           const double *__restrict__ cellvals, const double *__restrict__ fv,
-          double *__restrict__ fvn_c) {
-    for (int r = blockIdx.x * kBlock + threadIdx.x; r < nv;
+          double *__restrict__ fvn_c, int r0 = 0) {
+    // (rows [r0, nv): a rank passes the end of its rows as nv)
+    for (int r = r0 + blockIdx.x * kBlock + threadIdx.x; r < nv;
          r += gridDim.x * kBlock) {
         double s = 0.0;
         for (int k = gptr[r]; k < gptr[r + 1]; ++k) s += cellvals[gidx[k]];
@@ -204,6 +219,23 @@ struct dns_trap {
         const double *vmat_n;    // r x NV, row major
     };
     dns::DevBuf<double> fb_u, fb_vc, fb_vn, fb_y;
+    // Row-partitioned system: the ASSEMBLY is partitioned like the solve --
+    // a rank evaluates the cells that touch its rows, gathers the non-zeros
+    // and right-hand sides of its rows, takes its share of the update norm
+    // (all-reduced when the host asks) -- and no solution is gathered: the
+    // preconditioned vectors of the solve are exchanged over `planX` (rows of
+    // K + the dofs of those cells), which leaves the new iterate valid
+    // wherever this rank reads it.  Trajectory slots hold the own rows and
+    // that halo; reading one to the host gathers it first.
+    struct Part {
+        bool on = false;
+        uint64_t gen = ~0ull;
+        int v0 = 0, v1 = 0, z0 = 0, z1 = 0, nsel = 0, nhalo = 0;
+        dns::DevBuf<int> sel, halo;
+        dns_halo_plan planX;
+    } part;
+    int ensure_partition();
+    int gather_slot(int which, int slot);  // collective: whole slot everywhere
     int step_impl(double dt, int lin_which, int lin_slot, int out_slot,
                   int newton, int extrapolate_x0, const dns_solve_opts *opts,
                   dns_solve_stats *stats, const Feedback *fb);

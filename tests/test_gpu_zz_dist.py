@@ -666,9 +666,16 @@ def _trap_sweeps(comm):
                                               factorization='full'))
     stp.set_rhs(s['fv'], s['fp'])
     opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True)
+    c0 = comm.stats() if comm is not None else None
     vd, pd, hist = dnp.newton_picard(stp, tr, s['iniv'], s['lin0'],
                                      vel_pcrd_stps=1, vel_nwtn_stps=2,
                                      opts=opts)
+    if comm is not None:
+        c1 = comm.stats()
+        # all-gathers of the three sweeps and how many time steps they made
+        s['sweep_gathers'] = c1['allgatherv'] - c0['allgatherv']
+        s['sweep_steps'] = 3*(tr.size - 1)
+        s['nslots'] = tr.size
     # ... and three steps with the low-rank feedback terms of
     # `_get_mats_rhs_ts` (snu:1036-1042: `F - dt/2 U V_n` by Sherman-Morrison-
     # Woodbury; every Woodbury column is one more partitioned solve)
@@ -713,16 +720,19 @@ def _worker_trap(rank, world, port, outdir):
     np.savez(os.path.join(outdir, 'trap_rank{0}.npz'.format(rank)), v=v, p=p,
              fbv=sw['fb_state'][0], fbp=sw['fb_state'][1],
              hist=hist, halo=after['halo_exchange'] - before['halo_exchange'],
-             gathers=after['allgatherv'] - before['allgatherv'])
+             gathers=after['allgatherv'] - before['allgatherv'],
+             sweep_gathers=sw['sweep_gathers'], sweep_steps=sw['sweep_steps'],
+             nslots=sw['nslots'])
     cm.close()
     dist.destroy_process_group()
 
 
 def test_newton_picard_sweeps_on_a_partitioned_handle(tmp_path):
-    """the trapezoidal Newton/Picard stepper with its saddle solves
-    row-partitioned over two ranks (assembly replicated, solution gathered per
-    step): same sweeps, update norms and iterates as on one GPU and as the
-    oracle's restatement"""
+    """the trapezoidal Newton/Picard stepper row-partitioned over two ranks,
+    ASSEMBLY included (a rank evaluates the cells that touch its rows, gathers
+    the non-zeros and right-hand sides of its rows, takes its share of the
+    update norm; no solution is gathered per step): same sweeps, update norms
+    and iterates as on one GPU and as the oracle's restatement"""
     from oracle import newton_picard_oracle as npo
     from spawn_util import spawn_ranks
     spawn_ranks(_worker_trap, 2, str(tmp_path))
@@ -748,6 +758,13 @@ def test_newton_picard_sweeps_on_a_partitioned_handle(tmp_path):
     assert np.linalg.norm(r0['v'] - vo[tl]) <= 1e-8*np.linalg.norm(vo[tl])
     assert np.linalg.norm(r0['p'] - po[tl]) <= 1e-8*np.linalg.norm(po[tl])
     assert int(r0['halo']) > 0 and int(r0['gathers']) > 0
+    # no all-gather inside the time steps of a sweep: what is left are the
+    # whole trajectories (and final states) handed to the host between the
+    # sweeps -- at most a few per trajectory slot, not two per time step
+    print('all-gathers of three sweeps:', int(r0['sweep_gathers']), 'for',
+          int(r0['sweep_steps']), 'time steps,', int(r0['nslots']), 'slots')
+    assert int(r0['sweep_gathers']) <= 3*(int(r0['nslots']) + 2)
+    assert int(r0['sweep_gathers']) < 2*int(r0['sweep_steps'])
 
 
 def test_newton_picard_sweeps_on_one_rccl_rank():
