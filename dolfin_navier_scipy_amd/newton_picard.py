@@ -71,9 +71,11 @@ class TrapezoidalStepper(object):
                  JT=None, comm=None, precond_linpoint=None, refresh_iters=3.0,
                  batch=64):
         """`comm` (a `comm.Comm`): the saddle solves of the sweeps run
-        row-partitioned over its ranks; the assembly of
-        `N(v_lin)`, `F` and the right-hand side is replicated on every rank,
-        the solution is gathered after every step.
+        row-partitioned over its ranks, and so does the
+        assembly: a rank evaluates the cells that touch its rows and forms
+        its rows of `N(v_lin)`, `F` and the right-hand side; no solution is
+        gathered per step.  `read_traj`, the trajectory exports, `state()`
+        and `update_norm()` are collective then (all ranks call them).
         `precond_linpoint` (inner velocity, NV): the preconditioner -- set up
         ONCE, the system matrix is re-valued every step -- is built for
         `M + dt/2 (A + N1(v))` at this velocity instead of `M + dt/2 A`: the

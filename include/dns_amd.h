@@ -579,6 +579,11 @@ int dns_trap_step(dns_trap *t, double dt, int32_t lin_which, int32_t lin_slot,
                   const dns_solve_opts *opts, dns_solve_stats *stats);
 int dns_trap_get_state(dns_trap *t, double *v, double *p);
 int dns_trap_update_norm(dns_trap *t, double *out);
+/* On a row-partitioned system (dns_saddle_set_comm) the stepper's assembly is
+ * partitioned like the solve and no solution is gathered per step: trajectory
+ * slots and states hold a rank's rows and its halo.  dns_trap_traj_read,
+ * dns_trap_traj_export_async, dns_trap_get_state and dns_trap_update_norm are
+ * COLLECTIVE then (they gather / all-reduce first): every rank calls them. */
 /* time-dependent data of the sweeps, one row per trajectory slot (= time
  * instance; nslots rows each, NULL = not time dependent): `fv_tab` replaces fv
  * (forcing `fvtd(t)` and the stiffness contribution of controlled boundary
