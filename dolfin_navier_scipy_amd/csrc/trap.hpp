@@ -89,7 +89,16 @@ k_trap_updnorm(int nv, const int *__restrict__ rowptr,
                const double *__restrict__ x, const double *__restrict__ y,
                double *__restrict__ part, double *__restrict__ copy_out,
                int r0 = 0, int r1 = -1, const int *__restrict__ halo = nullptr,
-               int nhalo = 0) {
+               int nhalo = 0, double scale = 1.0,
+               const int *__restrict__ gptr = nullptr,
+               const int *__restrict__ gidx = nullptr,
+               const double *__restrict__ cellvals = nullptr,
+               const double *__restrict__ fv = nullptr,
+               double *__restrict__ fvn_c = nullptr) {
+    // scale: the partials are stored times this factor (dt: a pipelined sweep
+    // keeps the partials of a whole batch and sums them once).  gptr ...:
+    // f_c - N_c v_c rides along (k_trap_fc: fvn_c = fv - gather of the cell
+    // values of the new velocity), the rows are walked anyway
     // rows [r0, r1) only (a rank's share of the norm; r1 < 0: all); halo:
     // entries of x that are stored as well (what the rank's cells and rows
     // will read of this velocity as a linearisation point)
@@ -111,14 +120,22 @@ k_trap_updnorm(int nv, const int *__restrict__ rowptr,
             s = fma(mvals[k], x[c] - y[c], s);
         }
         s = subwave_sum<LPR>(s);
+        double cvs = 0.0;
+        if (gptr) {
+            const int g1 = gptr[row + 1];
+            for (int k = gptr[row] + sublane; k < g1; k += LPR)
+                cvs += cellvals[gidx[k]];
+            cvs = subwave_sum<LPR>(cvs);
+        }
         if (sublane == 0) {
             const double xr = x[row];
             acc = fma(xr - y[row], s, acc);
             if (copy_out) copy_out[row] = xr;
+            if (gptr) fvn_c[row] = fv[row] - cvs;
         }
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+    if (threadIdx.x == 0) part[blockIdx.x] = scale * acc;
 }
 
 // f_c - N_c v_c without the matrix: fvn_c = fv - N(v_c) v_c, the gather of the
@@ -185,6 +202,13 @@ struct dns_trap {
     int export_fence(int which);   // solver stream waits for a pending export
     double updnorm = 0.0;                      // sum dt ||v_n - v_lin||_M^2
     dns::DevBuf<double> updnorm_dev;           // ... its part still on the device
+    // pipelined sweep: the partials of every step of a batch (times dt) side
+    // by side, summed ONCE when the host polls (a one-workgroup launch per
+    // step before)
+    dns::DevBuf<double> upd_ring;
+    int upd_slot = 0, upd_stride = 0;
+    static constexpr int kUpdSlots = 128;
+    int flush_updnorm();
     int pipeline_c = 0;                        // > 0: steps do not synchronise
     double last_dt = 0.0;
     // time-dependent data of the sweeps, one row per trajectory slot (= time
@@ -240,7 +264,9 @@ struct dns_trap {
                   int newton, int extrapolate_x0, const dns_solve_opts *opts,
                   dns_solve_stats *stats, const Feedback *fb);
     // N_c, f_c at the current velocity
-    int assemble_current(int newton);
+    // (cells_only: the row gather f_c - N_c v_c is left to the update-norm
+    // kernel behind, which walks the same rows)
+    int assemble_current(int newton, bool cells_only = false);
     // checkpoint of the ring (a pipelined batch that did not converge within
     // its cycle length is repeated from here): the three solutions behind
     // `cur`, the host's bookkeeping; N_c / f_c are re-assembled on restore
