@@ -284,6 +284,10 @@ struct TrapRhs {
     const double *v_c, *fvn_c, *fp;
     double *b;
     int nv, np;
+    // cells_c != nullptr: fvn_c = fv_c - gather of the cell values of the
+    // current velocity (k_conv_step_cells), formed here instead of being read
+    const int *cgptr, *cgidx;
+    const double *cells_c, *fv_c;
 };
 
 }  // namespace dns
@@ -308,6 +312,11 @@ struct dns_conv {
         return {dbc_tab.p + (size_t)r * std::max(1, ndbc), nullptr, 0, 1};
     }
     int lane_min = dns::kConvLaneMin;      // DNS_CONV_LANE_MIN (read at create)
+    dns::DevBuf<double> cellvals_c;        // cell values of a second velocity
+                                           // (trapezoidal step: the current one)
+    int enqueue_step_cells(const double *v_lin, int newton, const double *x_c,
+                           int row_shift_c, hipStream_t s, const int *sel,
+                           int nsel);
     std::vector<int> cmap_host;            // [12][ncells], as on the device
     std::vector<int> gptr_host, gidx_host; // the inverted index, as on the device
     struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
@@ -400,17 +409,17 @@ struct dns_conv {
 // ---------------------------------------------------------------------------
 namespace dns {
 
-__global__ void __launch_bounds__(kBlock)
-k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
-                 const double *__restrict__ glam,
-                 const double *__restrict__ area,
-                 const double *__restrict__ v_inner, TabRef dbctab,
-                 int newton, double *__restrict__ L,        // [144][ncells]
-                 const int *__restrict__ sel = nullptr, int nsel = 0) {
+__device__ __forceinline__ void
+conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
+                     const double *__restrict__ glam,
+                     const double *__restrict__ area,
+                     const double *__restrict__ v_inner, TabRef dbctab,
+                     int newton, double *__restrict__ L,    // [144][ncells]
+                     const int *__restrict__ sel, int nsel) {
     // sel: only the cells sel[0..nsel) (row-partitioned trapezoidal stepper:
     // the cells that touch this rank's rows)
     const double *__restrict__ dbcvals = tab_row(dbctab);
-    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int t = bid * kBlock + threadIdx.x;
     const int slot = t >> 3;
     const int a = t & 7;
     if (slot >= (sel ? nsel : ncells) || a >= 6) return;
@@ -481,6 +490,46 @@ k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
                     ((i == k) ? n1[b] : 0.0) + (newton ? n2[b][i][k] : 0.0);
                 L[(size_t)slot * ncells + c] = v;
             }
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
+                 const double *__restrict__ glam,
+                 const double *__restrict__ area,
+                 const double *__restrict__ v_inner, TabRef dbctab,
+                 int newton, double *__restrict__ L,
+                 const int *__restrict__ sel = nullptr, int nsel = 0) {
+    conv_mat_cells_block(blockIdx.x, ncells, cellmap, glam, area, v_inner,
+                         dbctab, newton, L, sel, nsel);
+}
+
+// The element work of a trapezoidal step in ONE launch, three independent
+// families of workgroups: [0, ga) the local matrices of N1 (+ N2) about the
+// linearisation point, [ga, ga + gb) the cell values of N(x_c) x_c for the
+// CURRENT velocity (f_c - N_c v_c of the right-hand side; its own boundary
+// values and output array), the rest -- Newton -- the cell values of
+// N(v_lin) v_lin.  (Three launches before, two of them at the end of the
+// step before.)
+__global__ void __launch_bounds__(kBlock)
+k_conv_step_cells(int ga, int gb, int ncells, const int *__restrict__ cellmap,
+                  const double *__restrict__ glam,
+                  const double *__restrict__ area,
+                  const double *__restrict__ v_lin, TabRef dbc_lin, int newton,
+                  double *__restrict__ L, const double *__restrict__ x_c,
+                  TabRef dbc_c, double *__restrict__ cells_c,
+                  double *__restrict__ cells_lin,
+                  const int *__restrict__ sel, int nsel) {
+    const int bid = blockIdx.x;
+    if (bid < ga) {
+        conv_mat_cells_block(bid, ncells, cellmap, glam, area, v_lin, dbc_lin,
+                             newton, L, sel, nsel);
+    } else if (bid < ga + gb) {
+        conv_cells_block(bid - ga, ncells, cellmap, glam, area,
+                         ConvFromVec{x_c}, dbc_c, cells_c, sel, nsel);
+    } else {
+        conv_cells_block(bid - ga - gb, ncells, cellmap, glam, area,
+                         ConvFromVec{v_lin}, dbc_lin, cells_lin, sel, nsel);
+    }
 }
 
 // nvals[z] = sum of the local contributions of non-zero z;  if fvals:
@@ -574,15 +623,22 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
             for (int k = rhs.rowptr[r] + sl; k < rhs.rowptr[r + 1]; k += LR)
                 acc = fma(mvals[k] - tdt * avals[k], rhs.v_c[rhs.colidx[k]],
                           acc);
+            double cc = 0.0;
+            if (rhs.cells_c)
+                for (int k = rhs.cgptr[r] + sl; k < rhs.cgptr[r + 1]; k += LR)
+                    cc += rhs.cells_c[rhs.cgidx[k]];
             s = subwave_sum<LR>(s);
             rc = subwave_sum<LR>(rc);
             acc = subwave_sum<LR>(acc);
+            cc = subwave_sum<LR>(cc);
             if (sl == 0) {
                 if (!gptr && rhscon) rc = rhscon[r];
                 rhsbc[r] = -s;
                 const double fn = fv[r] - s + rc;
                 if (fvn) fvn[r] = fn;
-                rhs.b[r] = acc + tdt * (fn + rhs.fvn_c[r]);
+                const double fc = rhs.cells_c ? rhs.fv_c[r] - cc
+                                             : rhs.fvn_c[r];
+                rhs.b[r] = acc + tdt * (fn + fc);
             }
         }
         for (int i = rb * kBlock + threadIdx.x; i < rhs.np; i += nrb * kBlock)
@@ -626,6 +682,24 @@ inline int dns_conv::enqueue_mat_cells(const double *v_dev, int newton,
     hipLaunchKernelGGL(dns::k_conv_mat_cells, g, dns::kBlock, 0, s, ncells,
                        cellmap.p, glam.p, area.p, v_dev, dbc_ref(), newton,
                        mat->L.p, sel, nsel);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+inline int dns_conv::enqueue_step_cells(const double *v_lin, int newton,
+                                        const double *x_c, int row_shift_c,
+                                        hipStream_t s, const int *sel,
+                                        int nsel) {
+    const int live = sel ? nsel : ncells;
+    if (live <= 0) return DNS_OK;
+    if (cellvals_c.n < (size_t)12 * ncells)
+        DNS_TRY(cellvals_c.alloc((size_t)12 * ncells));
+    const int g = (8 * live + dns::kBlock - 1) / dns::kBlock;
+    hipLaunchKernelGGL(dns::k_conv_step_cells, g * (newton ? 3 : 2),
+                       dns::kBlock, 0, s, g, g, ncells, cellmap.p, glam.p,
+                       area.p, v_lin, dbc_ref(), newton, mat->L.p, x_c,
+                       dbc_ref(row_shift_c), cellvals_c.p, cellvals.p, sel,
+                       nsel);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }
