@@ -6,7 +6,9 @@
 //   F   = M + dt/2 (A + N_n)                 fused into the gather; K, D^-1
 //   rhs = M v_c + dt/2 (f_n + f_c - (A + N_c) v_c)
 //   K [v_n; p~] = [rhs; fp]                  preconditioned GMRES, warm start
-//   N_c = N(v_n), f_c;  update norm dt ||v_n - v_lin||_M^2;  p = -p~/dt
+//   update norm dt ||v_n - v_lin||_M^2;  p = -p~/dt   (N_c v_c, f_c of the
+//   right-hand side: cell values of the current velocity, taken in the same
+//   launch as the element matrices of the next step)
 // The linearisation points of a sweep and the velocities it produces live in
 // two trajectory buffers (nslots x NV each) in HBM -- they replace the
 // per-time-step .npy files of the reference (snu:1012-1014, 1424-1431).
@@ -26,43 +28,6 @@ k_trap_fvn(int nv, const double *__restrict__ fv,
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < nv;
          i += gridDim.x * kBlock)
         out[i] = fv[i] + rhsbc[i] + (rhscon ? rhscon[i] : 0.0);
-}
-
-// b_v = (M - hdt (A + N_c)) v_c + hdt (f_n + f_c);  b_p = fp.  The three value
-// arrays share ONE pattern (that of F), so the row is walked once.
-template <int LPR>
-__global__ void __launch_bounds__(kBlock)
-k_trap_rhs(int nv, int np, const int *__restrict__ rowptr,
-           const int *__restrict__ colidx, const double *__restrict__ mvals,
-           const double *__restrict__ avals, const double *__restrict__ ncvals,
-           const double *__restrict__ v_c, double hdt,
-           const double *__restrict__ fvn_n, const double *__restrict__ fvn_c,
-           const double *__restrict__ fp, double *__restrict__ b,
-           int r0 = 0, int r1 = -1) {
-    // rows [r0, r1) only (a rank's rows; r1 < 0: all)
-    if (r1 < 0) r1 = nv;
-    const int sub = (blockIdx.x * kBlock + threadIdx.x) / LPR;
-    const int sublane = threadIdx.x % LPR;
-    const int nsub = gridDim.x * (kBlock / LPR);
-    // ncvals == nullptr: the convection part of C_c v_c has gone into fvn_c
-    // as the convection VECTOR (dns_trap::assemble_current)
-    for (int row = r0 + sub; row < r1; row += nsub) {
-        double s = 0.0;
-        const int k1 = rowptr[row + 1];
-        if (ncvals) {
-            for (int k = rowptr[row] + sublane; k < k1; k += LPR)
-                s = fma(mvals[k] - hdt * (avals[k] + ncvals[k]),
-                        v_c[colidx[k]], s);
-        } else {
-            for (int k = rowptr[row] + sublane; k < k1; k += LPR)
-                s = fma(mvals[k] - hdt * avals[k], v_c[colidx[k]], s);
-        }
-        s = subwave_sum<LPR>(s);
-        if (sublane == 0) b[row] = s + hdt * (fvn_n[row] + fvn_c[row]);
-    }
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < np;
-         i += gridDim.x * kBlock)
-        b[nv + i] = fp[i];
 }
 
 // acc[0] += scale * sum(partials)   (one workgroup; the update norm of a
@@ -89,16 +54,9 @@ k_trap_updnorm(int nv, const int *__restrict__ rowptr,
                const double *__restrict__ x, const double *__restrict__ y,
                double *__restrict__ part, double *__restrict__ copy_out,
                int r0 = 0, int r1 = -1, const int *__restrict__ halo = nullptr,
-               int nhalo = 0, double scale = 1.0,
-               const int *__restrict__ gptr = nullptr,
-               const int *__restrict__ gidx = nullptr,
-               const double *__restrict__ cellvals = nullptr,
-               const double *__restrict__ fv = nullptr,
-               double *__restrict__ fvn_c = nullptr) {
+               int nhalo = 0, double scale = 1.0) {
     // scale: the partials are stored times this factor (dt: a pipelined sweep
-    // keeps the partials of a whole batch and sums them once).  gptr ...:
-    // f_c - N_c v_c rides along (k_trap_fc: fvn_c = fv - gather of the cell
-    // values of the new velocity), the rows are walked anyway
+    // keeps the partials of a whole batch and sums them once)
     // rows [r0, r1) only (a rank's share of the norm; r1 < 0: all); halo:
     // entries of x that are stored as well (what the rank's cells and rows
     // will read of this velocity as a linearisation point)
@@ -120,37 +78,14 @@ k_trap_updnorm(int nv, const int *__restrict__ rowptr,
             s = fma(mvals[k], x[c] - y[c], s);
         }
         s = subwave_sum<LPR>(s);
-        double cvs = 0.0;
-        if (gptr) {
-            const int g1 = gptr[row + 1];
-            for (int k = gptr[row] + sublane; k < g1; k += LPR)
-                cvs += cellvals[gidx[k]];
-            cvs = subwave_sum<LPR>(cvs);
-        }
         if (sublane == 0) {
             const double xr = x[row];
             acc = fma(xr - y[row], s, acc);
             if (copy_out) copy_out[row] = xr;
-            if (gptr) fvn_c[row] = fv[row] - cvs;
         }
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) part[blockIdx.x] = scale * acc;
-}
-
-// f_c - N_c v_c without the matrix: fvn_c = fv - N(v_c) v_c, the gather of the
-// convection cell values along the rows (inverted index of dns_conv)
-__global__ void __launch_bounds__(kBlock)
-k_trap_fc(int nv, const int *__restrict__ gptr, const int *__restrict__ gidx,
-          const double *__restrict__ cellvals, const double *__restrict__ fv,
-          double *__restrict__ fvn_c, int r0 = 0) {
-    // (rows [r0, nv): a rank passes the end of its rows as nv)
-    for (int r = r0 + blockIdx.x * kBlock + threadIdx.x; r < nv;
-         r += gridDim.x * kBlock) {
-        double s = 0.0;
-        for (int k = gptr[r]; k < gptr[r + 1]; ++k) s += cellvals[gidx[k]];
-        fvn_c[r] = fv[r] - s;
-    }
 }
 
 // kpos[z] = where the z-th non-zero of F sits in the assembled K (velocity
@@ -187,7 +122,7 @@ struct dns_trap {
     dns::DevBuf<double> xs[6];                 // ring of [v; p~] solutions
     int cur = 0, prev = 1, pprev = 2, p3 = 3, p4 = 4, work = 5;
     int nsol = 0;
-    dns::DevBuf<double> fv, fp, fvn_c, fvn_n, rhsbc, rhscon, b, dtmp, mtmp;
+    dns::DevBuf<double> fv, fp, fvn_n, rhsbc, rhscon, b, dtmp, mtmp;
     dns::DevBuf<double> traj[2];
     // asynchronous export of trajectory slots to the host (the "async writer"
     // of SURVEY 8f4): a copy stream of its own; the solver's stream only
@@ -263,10 +198,6 @@ struct dns_trap {
     int step_impl(double dt, int lin_which, int lin_slot, int out_slot,
                   int newton, int extrapolate_x0, const dns_solve_opts *opts,
                   dns_solve_stats *stats, const Feedback *fb);
-    // N_c, f_c at the current velocity
-    // (cells_only: the row gather f_c - N_c v_c is left to the update-norm
-    // kernel behind, which walks the same rows)
-    int assemble_current(int newton, bool cells_only = false);
     // checkpoint of the ring (a pipelined batch that did not converge within
     // its cycle length is repeated from here): the three solutions behind
     // `cur`, the host's bookkeeping; N_c / f_c are re-assembled on restore
