@@ -6,7 +6,8 @@ Run once in the build container (the reference tree does not exist on the GPU
 box):  python scripts/convert_meshes.py
 
 Source data: `/root/reference/tests/mesh/cylinder_{0,1,2,3}.xml`,
-`2D-double-rotcyl_lvl{1,2}.xml.gz` and `2D-double-rotcyl_geo_cntrlbc*.json`
+`2D-double-rotcyl_lvl{1,2}.xml.gz`, `karman2D-{rotcyl,outlets}_lvl1.xml.gz` and the
+`*_geo_cntrlbc*.json` geometry descriptions next to them
 (data files the reference's own drivers load, `problem_setups.py:476-478`,
 `tests/time_dep_nse_double_rotcyl_bcrob.py:7,16-18`).  Output: vertex
 coordinates + triangle connectivity only; the `*_facet_region` files are NOT
@@ -39,7 +40,16 @@ if __name__ == '__main__':
         out = os.path.join(DATA, 'mesh_2D-double-rotcyl_lvl{0}.npz'.format(lvl))
         save_npz_mesh(out, mesh)
         print(out, mesh.nverts, mesh.ncells)
+    # the meshes of the reference's known-answer tests (test_units_residuals.py:
+    # 17-26, tdp_convcheck.py:85-95)
+    for name in ('karman2D-rotcyl_lvl1', 'karman2D-outlets_lvl1'):
+        mesh = read_dolfin_xml(os.path.join(REFMESH, name + '.xml.gz'))
+        out = os.path.join(DATA, 'mesh_{0}.npz'.format(name))
+        save_npz_mesh(out, mesh)
+        print(out, mesh.nverts, mesh.ncells)
     for name in ('2D-double-rotcyl_geo_cntrlbc.json',
-                 '2D-double-rotcyl_geo_cntrlbc_rotcntrl.json'):
+                 '2D-double-rotcyl_geo_cntrlbc_rotcntrl.json',
+                 'karman2D-rotcyl-bm_geo_cntrlbc.json',
+                 'karman2D-outlets_geo_cntrlbc.json'):
         shutil.copy(os.path.join(REFMESH, name), os.path.join(DATA, name))
         print(name)

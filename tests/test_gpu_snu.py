@@ -230,10 +230,10 @@ def test_time_integration_residuals_of_solve_nse(snu):
     closures `solve_nse` hands to the integrator -- convection with boundary
     values and its sign, merged right-hand sides, pressure scaling, appended
     boundary values -- compose as the reference's do.
-    What is NOT mirrored, and why: (i) the reference runs it on
-    `karman2D-rotcyl_lvl1`, whose geometry description this repository's
-    assembler does not read -- the property does not depend on the mesh, the
-    `2D-double-rotcyl_lvl1` set-up of config 5 stands in; (ii) the two Heun
+    Same mesh (`karman2D-rotcyl_lvl1`, converted to arrays by
+    `scripts/convert_meshes.py`; its boundary parts classified from the
+    geometry in `karman2D-rotcyl-bm_geo_cntrlbc.json`), same parameters.
+    What is NOT mirrored, and why: the two Heun
     assertions of that file (:100-118) describe an integrator the reference no
     longer has: at this commit `_onestepheun` predicts with implicit Euler
     (`scheme='IMEX-Euler'`, tiu:368,398-403), corrects with `amat=M`
@@ -242,8 +242,10 @@ def test_time_integration_residuals_of_solve_nse(snu):
     generated from the reference's `time_int_utils` instead
     (`tests/golden/`, `tests/test_gpu_imex.py`)."""
     from dolfin_navier_scipy_amd.fem import get_sysmats
-    femp, sm, rhsd = get_sysmats(problem='gen_bccont', nu=1e-3, charvel=0.2,
-                                 bccontrol=False)
+    femp, sm, rhsd = get_sysmats(
+        problem='gen_bccont', nu=1e-3, charvel=0.2, bccontrol=False,
+        meshparams=dict(meshname='karman2D-rotcyl_lvl1',
+                        geodata='karman2D-rotcyl-bm_geo_cntrlbc'))
     M, A, J = sm['M'], sm['A'], sm['J']
     JT = J.T.tocsr()
     fv = rhsd['fv']
@@ -288,13 +290,16 @@ def test_second_order_convergence_in_time_of_solve_nse(snu, scheme):
     the final velocity for `Nts`, `2 Nts`, `4 Nts` steps against the one for
     `2**dblng Nts` steps in the M-norm -- the error falls like `Nts**-2` (the
     fit line the script draws).  Mirrored on the device path for both schemes
-    of the script (`--tis cnab|sbdf2`), `tE = 0.1` as its default, on the
-    `2D-double-rotcyl_lvl1` mesh (the script's `karman2D-outlets` geometry
-    description is not read by this repository's assembler; the order of the
-    scheme does not depend on the mesh)."""
+    of the script (`--tis cnab|sbdf2`) with its defaults: mesh
+    `karman2D-outlets_lvl1` (converted to arrays, boundary parts from the
+    geometry in `karman2D-outlets_geo_cntrlbc.json`; the control segments
+    are walls with `bccontrol=False`), Re = 100, `tE = 0.1`, `Nts = 100`.
+    (Three doublings here, four in the script.)"""
     from dolfin_navier_scipy_amd.fem import get_sysmats
-    femp, sm, rhsd = get_sysmats(problem='gen_bccont', Re=100,
-                                 bccontrol=False)
+    femp, sm, rhsd = get_sysmats(
+        problem='gen_bccont', Re=100, bccontrol=False,
+        meshparams=dict(meshname='karman2D-outlets_lvl1',
+                        geodata='karman2D-outlets_geo_cntrlbc'))
     M = sm['M']
     kw = dict(A=sm['A'], M=M, J=sm['J'], fv=rhsd['fv'], fp=rhsd['fp'],
               V=femp['V'], invinds=femp['invinds'],
@@ -303,7 +308,7 @@ def test_second_order_convergence_in_time_of_solve_nse(snu, scheme):
               start_ssstokes=True, treat_nonl_explicit=True,
               time_int_scheme=scheme, t0=0.0, tE=0.1,
               solver=dict(rtol=1e-13))
-    Nts, dblng = 25, 3
+    Nts, dblng = 100, 3
     vfref, _ = snu.solve_nse(Nts=Nts*2**dblng, **kw)
     errs = []
     for k in range(dblng):
