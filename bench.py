@@ -617,7 +617,9 @@ def partitioned_run(args, world, rank, device, dist, one_gpu, start=None,
         th, inv, femp['dbcinds'], femp['dbcvals'], device=device)
     nfc = cvop.apply(v0, scale=-1.0)
     cf = saddle.ImexStepper.coeffs(a_c=1., a_p=0., cn_c=1.5*dt, cn_o=-.5*dt,
-                                   pscale=-1./dt, extrapolate=args.extrap,
+                                   pscale=-1./dt,
+                                   extrapolate=(tuned['extrapolate'] if big
+                                                else args.extrap),
                                    carry_residual=bool(args.carry))
 
     def options(graph):
@@ -883,9 +885,19 @@ def run_child(cmd, env, timeout, want_result):
             cout, _ = child.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             os.killpg(child.pid, 9)         # exactly the group started above
-            child.communicate()
-            return dict(error='no result within {0:g} s (killed)'
-                        .format(timeout))
+            cout, _ = child.communicate()
+            res = dict(error='no result within {0:g} s (killed)'
+                       .format(timeout))
+            # what it had reported before it stopped (the self-test prints a
+            # line per primitive: the last one names the primitive that hung)
+            part = [ln for ln in (cout or b'').decode(errors='replace')
+                    .splitlines() if ln.startswith('{')]
+            if part:
+                try:
+                    res['partial'] = json.loads(part[-1])
+                except ValueError:
+                    pass
+            return res
         lines = [ln for ln in cout.decode(errors='replace').splitlines()
                  if ln.startswith('{')]
         if lines:
@@ -897,6 +909,187 @@ def run_child(cmd, env, timeout, want_result):
                         child.returncode))
     except Exception as exc:
         return dict(error=str(exc))
+
+
+SELFTEST_LEGS = [(name, graph)
+                 for name in ('allreduce', 'sendrecv_ring',
+                              'allgather_unequal', 'allgather_equal')
+                 for graph in (False, True)]
+
+
+def selftest_child(args, world, rank, local_rank):
+    """`--selftest-only`: first contact of the ranks over RCCL, `dns_comm_*`
+    only -- no matrix, no solver.  Rendezvous over gloo (CPU), then
+    ncclCommInitRank, then every primitive of the partitioned path once as
+    plain launches and once captured in a hipGraph.  Rank 0 prints the record
+    again after every step (the parent keeps the last line of a child it had
+    to kill: the first primitive that is missing is the one that hung);
+    every rank says on stderr where it is."""
+    rec = dict(world=world, primitives={}, complete=False, stage='start')
+
+    def report(stage):
+        rec['stage'] = stage
+        sys.stderr.write('[rccl self-test] rank {0}: {1}\n'.format(rank, stage))
+        sys.stderr.flush()
+        if rank == 0:
+            print(json.dumps(rec))
+            sys.stdout.flush()
+    import faulthandler
+    faulthandler.dump_traceback_later(max(10., args.selftest_timeout - 5.),
+                                      exit=True)
+    if args.dry_run:
+        import torch.distributed as dist
+        with stdout_to_stderr():
+            dist.init_process_group('gloo')
+            dist.barrier()
+        for name, graph in SELFTEST_LEGS:
+            rec['primitives'][name + ('_graph' if graph else '_eager')] = \
+                dict(ok=True, us_per_call=1.0)
+        rec.update(complete=True, dry_run=True)
+        report('done')
+        dist.destroy_process_group()
+        return rec
+    t0 = time.time()
+    import torch.distributed as dist
+    one_gpu = os.environ.get('DNS_BENCH_REHEARSE_ONE_GPU') == '1'
+    if world > 1 or 'MASTER_PORT' in os.environ:
+        with stdout_to_stderr():
+            dist.init_process_group('gloo')
+            dist.barrier()
+    else:
+        dist = None
+    rec['rendezvous_s'] = round(time.time() - t0, 3)
+    report('rendezvous (gloo) done')
+    from dolfin_navier_scipy_amd import _capi, comm as dcomm
+    device = 0 if one_gpu else local_rank
+    if _capi.device_count() <= device:
+        raise SystemExit('bench.py needs a HIP device (no CPU fallback)')
+    t0 = time.time()
+    with stdout_to_stderr():
+        if one_gpu and world > 1:
+            comm_obj = dcomm.Comm.gloo(device)
+            rec['backend'] = 'gloo-staged callbacks (one-GPU rehearsal)'
+        elif dist is not None:
+            comm_obj = dcomm.Comm.rccl_from_torch(device)
+            rec['backend'] = 'rccl'
+        else:
+            comm_obj = dcomm.Comm.rccl(device, 1, 0, dcomm.rccl_unique_id())
+            rec['backend'] = 'rccl'
+    rec['comm_init_s'] = round(time.time() - t0, 3)
+    report('communicator created')
+    allok = True
+    for name, graph in SELFTEST_LEGS:
+        key = name + ('_graph' if graph else '_eager')
+        if graph and rec['backend'] != 'rccl':
+            rec['primitives'][key] = dict(skipped='host-callback communicator')
+            continue
+        report('entering ' + key)
+        try:
+            with stdout_to_stderr():
+                one = comm_obj.selftest(name, graph=graph, count=4, reps=20)
+        except Exception as exc:
+            one = dict(ok=False, error=str(exc))
+        one['us_per_call'] = (round(one['us_per_call'], 2)
+                              if 'us_per_call' in one else None)
+        rec['primitives'][key] = one
+        allok = allok and bool(one.get('ok'))
+    rec['gather_forms'] = comm_obj.gather_forms()
+    rec['complete'] = True
+    rec['ok'] = allok
+    report('done')
+    comm_obj.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return rec
+
+
+def visible_gpu_count():
+    """GPUs this process could open, WITHOUT a HIP call (the launcher must not
+    touch the GPU before it starts its rank processes): the KFD topology's
+    nodes with SIMDs, cut down by *_VISIBLE_DEVICES; None when unknown"""
+    import glob
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if not nodes:
+        return None
+    count = 0
+    for path in nodes:
+        try:
+            with open(path) as fh:
+                for line in fh:
+                    if line.startswith('simd_count'):
+                        count += int(line.split()[1]) > 0
+        except (OSError, ValueError):
+            return None
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES',
+                'CUDA_VISIBLE_DEVICES'):
+        val = os.environ.get(var)
+        if val is not None:
+            count = min(count, len([x for x in val.split(',') if x.strip()]))
+    return count
+
+
+def self_launch(args):
+    """`bench.py --gpus N` (N > 1) started WITHOUT a launcher: this process
+    starts the N rank processes itself -- children with RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set, spawned before anything here has touched the
+    GPU (no torch import, no HIP call: the launcher only waits) -- hands
+    rank 0's JSON line through and exits non-zero if there is none.  The
+    one-GPU line must never be printed for `--gpus N`."""
+    import socket
+    import subprocess
+    world = args.gpus
+    if not args.dry_run and os.environ.get('DNS_BENCH_REHEARSE_ONE_GPU') != '1':
+        have = visible_gpu_count()
+        if have is not None and have < world:
+            sys.stderr.write('bench.py --gpus {0}: only {1} GPU(s) visible on '
+                             'this box -- no line printed\n'.format(world, have))
+            raise SystemExit(2)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    sys.stderr.write('bench.py --gpus {0} without a launcher: starting {0} '
+                     'rank processes (rendezvous 127.0.0.1:{1})\n'
+                     .format(world, port))
+    sys.stderr.flush()
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(world):
+        env = child_env(RANK=r, LOCAL_RANK=r, WORLD_SIZE=world,
+                        LOCAL_WORLD_SIZE=world, MASTER_ADDR='127.0.0.1',
+                        MASTER_PORT=port, DNS_BENCH_SELF_LAUNCHED=1)
+        procs.append(subprocess.Popen(
+            cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr,
+            stderr=None, start_new_session=True))
+    limit = args.time_budget + 600.
+    t0, out0 = time.time(), b''
+    try:
+        out0, _ = procs[0].communicate(timeout=limit)
+        for pr in procs[1:]:
+            pr.wait(timeout=max(5., limit - (time.time() - t0)))
+    except subprocess.TimeoutExpired:
+        sys.stderr.write('bench.py: rank processes still running after {0:g} '
+                         's, killed\n'.format(limit))
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, 9)    # exactly the groups started above
+                except OSError:
+                    pass
+                pr.wait()
+    lines = [ln for ln in out0.decode(errors='replace').splitlines()
+             if ln.startswith('{')]
+    codes = [pr.returncode for pr in procs]
+    if not lines or any(codes):
+        sys.stderr.write('bench.py --gpus {0}: rank exit codes {1}, {2} JSON '
+                         'line(s)\n'.format(world, codes, len(lines)))
+    if not lines:
+        raise SystemExit(3)
+    print(lines[-1])
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(4)
+    return json.loads(lines[-1])
 
 
 def multi_gpu_main(args, world, rank, local_rank):
@@ -989,6 +1182,72 @@ def multi_gpu_main(args, world, rank, local_rank):
                 res['first_attempt_with_graphs'] = first
         return res
 
+    t_start = time.time()
+
+    def remaining():
+        """seconds of --time-budget left, the same figure on every rank"""
+        t = torch.tensor([args.time_budget - (time.time() - t_start)],
+                         dtype=torch.float64)
+        dist.broadcast(t, 0)
+        return float(t.item())
+
+    # first contact: a short child per rank that drives dns_comm_* only
+    def selftest():
+        cmd = [sys.executable, os.path.abspath(__file__), '--selftest-only',
+               '--gpus', str(world), '--selftest-timeout',
+               str(args.selftest_timeout)]
+        if args.dry_run:
+            cmd.append('--dry-run')
+        dist.barrier()
+        port, held = fresh_port(base_port + 3)
+        try:
+            res = run_child(cmd, child_env(MASTER_PORT=port,
+                                           MASTER_ADDR='127.0.0.1'),
+                            args.selftest_timeout + 10., rank == 0)
+        finally:
+            if held is not None:
+                held.close()
+        bad = torch.tensor([1 if (res is not None and 'error' in res) else 0])
+        dist.all_reduce(bad)
+        if int(bad.item()) and rank == 0 and 'error' not in res:
+            res = dict(error='the self-test child of another rank failed',
+                       partial=res)
+        # what the legs behind it may rely on, agreed by all ranks
+        flags = torch.zeros(2, dtype=torch.int64)
+        if rank == 0:
+            rec = res.get('partial', res) if isinstance(res, dict) else {}
+            prim = rec.get('primitives', {}) if isinstance(rec, dict) else {}
+            eager = [k for k in prim if k.endswith('_eager')]
+            graph = [k for k in prim if k.endswith('_graph')
+                     and 'skipped' not in prim[k]]
+            flags[0] = int(len(eager) == 4
+                           and all(prim[k].get('ok') for k in eager))
+            flags[1] = int(len(graph) == 4
+                           and all(prim[k].get('ok') for k in graph))
+        dist.broadcast(flags, 0)
+        return res, bool(flags[0].item()), bool(flags[1].item())
+
+    rccl_selftest, eager_ok, graph_ok = selftest()
+    one_gpu_rehearsal = os.environ.get('DNS_BENCH_REHEARSE_ONE_GPU') == '1'
+    if not graph_ok and not one_gpu_rehearsal and not args.eager:
+        # captured collectives did not pass first contact: plain launches for
+        # every partitioned leg (no attempt is spent on finding that out again)
+        os.environ['DNS_DIST_GRAPH'] = '0'
+        sys.stderr.write('bench: rank {0}: RCCL self-test did not pass its '
+                         'graph legs, DNS_DIST_GRAPH=0\n'.format(rank))
+
+    skipped = {}
+
+    def leg(name, expected_s, run):
+        """a secondary leg runs only while its expected cost fits the budget"""
+        left = remaining()
+        if left < expected_s:
+            skipped[name] = ('skipped: {0:.0f} s of --time-budget left, the '
+                             'leg is expected to take {1:.0f} s'
+                             .format(left, expected_s))
+            return dict(error=skipped[name])
+        return run(left)
+
     level, refine = weak_ladder(world)
     # dt follows the mesh width: halved per refinement, and once more on the
     # level-3 mesh (explicit convection: dt=1/512 at Re=100 is past its
@@ -997,25 +1256,46 @@ def multi_gpu_main(args, world, rank, local_rank):
     # latency-regime legs start from the steady Stokes state like the N=1
     # headline; the bandwidth ladder starts from rest on every N (its N=1
     # point, `refined_bench.run`, does too)
-    weak = partitioned(17, level, refine, nts_w, 'stokes')
+    if eager_ok or one_gpu_rehearsal or args.dry_run:
+        weak = partitioned(17, level, refine, nts_w, 'stokes')
+    else:
+        weak = dict(error='not started: the RCCL self-test failed '
+                    '(config.rccl_selftest)')
+    # (only rank 0 holds the children's records: its verdict for everybody)
+    ok_t = torch.tensor([1 if (isinstance(weak, dict) and 'error' not in weak)
+                         else 0])
+    dist.broadcast(ok_t, 0)
+    headline_ok = bool(ok_t.item())
     # the same loop in the bandwidth regime (>= 7e5 rows per rank)
     bandwidth = None
-    if not args.no_bandwidth:
+    if not args.no_bandwidth and headline_ok:
         blevel, brefine = bandwidth_ladder(world)
         nts_b = args.nts*2**brefine*(2 if blevel >= 3 else 1)
-        bandwidth = partitioned(41, blevel, brefine, nts_b, 'rest',
-                                timeout=1.5*args.partitioned_timeout)
+        bandwidth = leg('weak_scaling_bandwidth', 300.,
+                        lambda left: partitioned(
+                            41, blevel, brefine, nts_b, 'rest',
+                            timeout=min(1.5*args.partitioned_timeout,
+                                        max(60., left - 90.))))
+    elif not args.no_bandwidth:
+        bandwidth = dict(error='not started: the headline leg failed')
     strong = None
-    if not args.no_strong and (level, refine) != (args.level, 0):
-        strong = partitioned(29, args.level, 0, args.nts, 'stokes')
-    elif not args.no_strong:
+    if not args.no_strong and (level, refine) != (args.level, 0) \
+            and headline_ok:
+        strong = leg('strong_scaling', 90.,
+                     lambda left: partitioned(
+                         29, args.level, 0, args.nts, 'stokes',
+                         timeout=min(args.partitioned_timeout,
+                                     max(60., left - 60.))))
+    elif not args.no_strong and headline_ok:
         strong = 'identical to the headline run (same mesh)'
 
     # ensemble: every rank advances its own copy of the N=1 workload on its own
     # GPU -- a single-GPU run of this script per rank (own timed window of
     # exactly --steps steps each; the slowest rank counts)
     ensemble = None
-    if not args.no_ensemble:
+    if not args.no_ensemble and headline_ok and remaining() < 75.:
+        ensemble = dict(error='skipped: --time-budget spent', steps_per_s=None)
+    elif not args.no_ensemble:
         env = {k: v for k, v in child_env().items()
                if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR',
                             'MASTER_PORT', 'GROUP_RANK', 'LOCAL_WORLD_SIZE',
@@ -1094,7 +1374,10 @@ def multi_gpu_main(args, world, rank, local_rank):
                                      if ok else None),
                         weak_scaling=weak, strong_scaling=strong,
                         weak_scaling_bandwidth=bandwidth,
-                        ensemble=ensemble, spinup_steps=args.spinup,
+                        ensemble=ensemble, rccl_selftest=rccl_selftest,
+                        time_budget_s=args.time_budget,
+                        elapsed_s=round(time.time() - t_start, 1),
+                        spinup_steps=args.spinup,
                         method='gmres', cheb_degree=args.cheb,
                         factorization=args.fact, drop_tol=args.drop,
                         rtol=args.rtol,
@@ -1215,16 +1498,36 @@ def main():
                     help='skip the run of the N=1 workload through the '
                     'row-partitioned code path on one RCCL rank '
                     '(config.row_partitioned: the code the N > 1 lines time)')
+    ap.add_argument('--selftest-only', action='store_true',
+                    help='(internal) first contact of the ranks of this '
+                    'launch over RCCL: dns_comm_* only, a record per primitive')
+    ap.add_argument('--selftest-timeout', type=float, default=120.,
+                    help='time limit [s] of the RCCL self-test child')
+    ap.add_argument('--time-budget', type=float, default=780.,
+                    help='N > 1: wall-clock budget [s] of the whole line; the '
+                    'self-test and the headline leg always run, a secondary '
+                    'leg only while its expected cost still fits')
     ap.set_defaults(force_dist=True, window_400=True)
     args = ap.parse_args()
 
+    internal = args.partitioned_only or args.selftest_only
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1 and not internal:
+        # started without a launcher: start the rank processes here
+        return self_launch(args)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and not internal:
+        sys.stderr.write('bench.py: --gpus {0} but the launcher started {1} '
+                         'rank(s) (WORLD_SIZE): refusing to print a line for '
+                         'another N\n'.format(args.gpus, world))
+        raise SystemExit(2)
     # `kill -USR1 <pid>` (or `timeout -s USR1`): the Python stacks on stderr
     import faulthandler
     import signal
     faulthandler.register(signal.SIGUSR1, all_threads=True)
+    if args.selftest_only:
+        return selftest_child(args, world, rank, local_rank)
     if args.partitioned_only:
         return partitioned_child(args, world, rank, local_rank)
     if world > 1:

@@ -248,6 +248,11 @@ SIGNATURES = {
     'dns_comm_set_alltoallv_cb': (ct.c_int, [_VP, ALLTOALLV_CB]),
     'dns_comm_stats2': (ct.c_int, [_VP, ct.POINTER(ct.c_int64)]),
     'dns_comm_set_timing': (ct.c_int, [_VP, ct.c_int]),
+    'dns_comm_selftest': (ct.c_int, [_VP, ct.c_int32, ct.c_int32, ct.c_int32,
+                                     ct.c_int32, ct.POINTER(ct.c_int32),
+                                     ct.POINTER(ct.c_double)]),
+    'dns_comm_gather_forms': (ct.c_int, [_VP, ct.POINTER(ct.c_int64)]),
+    'dns_comm_set_gather_form': (ct.c_int, [_VP, ct.c_int32]),
     'dns_comm_timing': (ct.c_int, [_VP, ct.POINTER(ct.c_double),
                                    ct.POINTER(ct.c_int64)]),
     'dns_halo_lists': (ct.c_int, [ct.POINTER(dns_csr), ct.c_int32, ct.c_int32,

@@ -229,6 +229,34 @@ class Comm(object):
                         us_per_call=(1e3*ms[i]/calls[i] if calls[i] else None))
                 for i, k in enumerate(names)}
 
+    SELFTEST_PRIMITIVES = ('allreduce', 'sendrecv_ring', 'allgather_unequal',
+                           'allgather_equal')
+
+    def selftest(self, which, graph=False, count=4, reps=20):
+        """`dns_comm_selftest`: ONE primitive (name or index into
+        `SELFTEST_PRIMITIVES`) once checked and `reps` times timed, as plain
+        launches or captured in a hipGraph; collective"""
+        if not isinstance(which, int):
+            which = self.SELFTEST_PRIMITIVES.index(which)
+        ok, us = ct.c_int32(0), ct.c_double(0.0)
+        C.check(self.lib.dns_comm_selftest(self._h, which, int(bool(graph)),
+                                           count, reps, ct.byref(ok),
+                                           ct.byref(us)))
+        return dict(ok=bool(ok.value), us_per_call=us.value)
+
+    def set_gather_form(self, form):
+        """'auto' (in place for equal blocks, staged otherwise), 'bcast' (a
+        group of broadcasts) or 'staged' (always through the staging buffer)"""
+        C.check(self.lib.dns_comm_set_gather_form(
+            self._h, ('auto', 'bcast', 'staged').index(form)))
+
+    def gather_forms(self):
+        """how the all-gathers were issued so far"""
+        buf = (ct.c_int64*3)()
+        C.check(self.lib.dns_comm_gather_forms(self._h, buf))
+        return dict(allgather_inplace=buf[0], allgather_staged=buf[1],
+                    broadcast_group=buf[2])
+
     def close(self):
         if self._h:
             self.lib.dns_comm_destroy(self._h)

@@ -18,6 +18,28 @@
 #include "common.hpp"
 #include "halo_host.hpp"
 
+// block starts of an all-gather, by value in the kernel arguments
+constexpr int kDnsMaxGatherRanks = 64;
+struct dns_gather_starts {
+    int st[kDnsMaxGatherRanks + 1];
+};
+
+namespace dns {
+// behind a padded ncclAllGather: block q of `width` doubles in `stage` goes to
+// vec[st[q] .. st[q+1]); the own block is already where it belongs
+__global__ void __launch_bounds__(kBlock)
+k_gather_unpack(dns_gather_starts gs, int nranks, int rank, int width,
+                const double *__restrict__ stage, double *__restrict__ vec) {
+    const long long total = (long long)width * nranks;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total;
+         e += (long long)gridDim.x * kBlock) {
+        const int q = (int)(e / width), i = (int)(e - (long long)q * width);
+        if (q != rank && i < gs.st[q + 1] - gs.st[q])
+            vec[gs.st[q] + i] = stage[e];
+    }
+}
+}  // namespace dns
+
 struct dns_comm {
     int rank = 0, nranks = 1, device = 0;
     ncclComm_t nccl = nullptr;
@@ -158,23 +180,108 @@ struct dns_comm {
         return DNS_OK;
     }
 
+    // ---- all-gather of contiguous, possibly unequal blocks ---------------
+    // ONE ncclAllGather on blocks padded to the widest one.  Equal blocks are
+    // gathered in place (send pointer = receive pointer + rank * width, the
+    // in-place form of the collective); unequal ones -- the even-chunk
+    // partition of an NV that the ranks do not divide -- go through a staging
+    // buffer [own block | nranks blocks]: one device copy in front, one
+    // kernel behind.  (Until round 5 this was a group of nranks
+    // ncclBroadcasts: nranks rings instead of one.)  The staging buffer only
+    // grows outside a stream capture; a captured call that finds it too
+    // small takes the broadcast form, which needs none.
+    static constexpr int kMaxGatherRanks = kDnsMaxGatherRanks;
+    dns::DevBuf<double> ag_stage;
+    // DNS_COMM_ALLGATHER / dns_comm_set_gather_form: 0 = as described, 1 =
+    // "bcast" the old form, 2 = "staged" the staging buffer for equal blocks
+    // too (lets ONE rank exercise the pack / unpack path)
+    int ag_form = 0;
+    int64_t n_ag_inplace = 0, n_ag_staged = 0, n_ag_bcast = 0;
+
+    static bool capturing(hipStream_t s) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        return hipStreamIsCapturing(s, &cs) != hipSuccess ||
+               cs != hipStreamCaptureStatusNone;
+    }
+    // room for an all-gather of blocks up to `width` doubles (set-up time)
+    int reserve_gather(size_t width, hipStream_t s) {
+        const size_t need = width * (size_t)(nranks + 1);
+        if (!nccl || ag_stage.n >= need) return DNS_OK;
+        if (capturing(s))
+            return dns::fail(DNS_ERR_COMM, "reserve_gather inside a capture");
+        DNS_HIP(hipStreamSynchronize(s));
+        return ag_stage.alloc(need);
+    }
+
+    int allgatherv_bcast(double *dev, const std::vector<int> &starts,
+                         hipStream_t s) {
+        n_ag_bcast++;
+        ncclResult_t r = ncclGroupStart();
+        for (int q = 0; q < nranks && r == ncclSuccess; ++q) {
+            const size_t cnt = (size_t)(starts[q + 1] - starts[q]);
+            if (cnt == 0) continue;
+            r = ncclBroadcast(dev + starts[q], dev + starts[q], cnt,
+                              ncclDouble, q, nccl, s);
+        }
+        ncclResult_t e = ncclGroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess)
+            return dns::fail(DNS_ERR_COMM, "allgatherv (ncclBroadcast): %s",
+                             ncclGetErrorString(r));
+        return DNS_OK;
+    }
+
     int allgatherv(double *dev, const std::vector<int> &starts, hipStream_t s) {
         n_allgather++;
         bytes_allgather += 8 * (int64_t)(starts[rank + 1] - starts[rank]);
         Timed timed_call(this, kAllgather, s);
         if (nccl) {
-            ncclResult_t r = ncclGroupStart();
-            for (int q = 0; q < nranks && r == ncclSuccess; ++q) {
-                const size_t cnt = (size_t)(starts[q + 1] - starts[q]);
-                if (cnt == 0) continue;
-                r = ncclBroadcast(dev + starts[q], dev + starts[q], cnt,
-                                  ncclDouble, q, nccl, s);
+            int width = 0;
+            bool equal = true;
+            for (int q = 0; q < nranks; ++q) {
+                const int cnt = starts[q + 1] - starts[q];
+                width = std::max(width, cnt);
+                if (cnt != starts[1] - starts[0]) equal = false;
             }
-            ncclResult_t e = ncclGroupEnd();
-            if (r == ncclSuccess) r = e;
+            if (width == 0) return DNS_OK;
+            if (ag_form == 1 || nranks > kMaxGatherRanks)
+                return allgatherv_bcast(dev, starts, s);
+            if (equal && ag_form != 2) {
+                n_ag_inplace++;
+                ncclResult_t r = ncclAllGather(dev + starts[rank],
+                                               dev + starts[0], (size_t)width,
+                                               ncclDouble, nccl, s);
+                if (r != ncclSuccess)
+                    return dns::fail(DNS_ERR_COMM, "ncclAllGather: %s",
+                                     ncclGetErrorString(r));
+                return DNS_OK;
+            }
+            const size_t need = (size_t)width * (size_t)(nranks + 1);
+            if (ag_stage.n < need) {
+                if (capturing(s)) return allgatherv_bcast(dev, starts, s);
+                DNS_TRY(reserve_gather((size_t)width, s));
+            }
+            n_ag_staged++;
+            double *snd = ag_stage.p, *rcv = ag_stage.p + width;
+            const int mine = starts[rank + 1] - starts[rank];
+            if (mine > 0)
+                DNS_HIP(hipMemcpyAsync(snd, dev + starts[rank],
+                                       (size_t)mine * sizeof(double),
+                                       hipMemcpyDeviceToDevice, s));
+            ncclResult_t r = ncclAllGather(snd, rcv, (size_t)width, ncclDouble,
+                                           nccl, s);
             if (r != ncclSuccess)
-                return dns::fail(DNS_ERR_COMM, "allgatherv (ncclBroadcast): %s",
+                return dns::fail(DNS_ERR_COMM, "ncclAllGather: %s",
                                  ncclGetErrorString(r));
+            dns_gather_starts gs;
+            for (int q = 0; q <= nranks; ++q) gs.st[q] = starts[q];
+            const long long total = (long long)width * nranks;
+            const int grid = (int)std::max<long long>(
+                1, std::min<long long>((total + dns::kBlock - 1) / dns::kBlock,
+                                       2048));
+            hipLaunchKernelGGL(dns::k_gather_unpack, grid, dns::kBlock, 0, s, gs,
+                               nranks, rank, width, rcv, dev);
+            DNS_HIP(hipGetLastError());
             return DNS_OK;
         }
         if (!ag_cb) return dns::fail(DNS_ERR_COMM, "no allgatherv backend");

@@ -97,6 +97,13 @@ int dns_saddle::init_device(int dev) {
     if (const char *sn = getenv("DNS_STREAM_GRID"))
         sgrid = std::max(64, std::min(atoi(sn), 16384));
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
+    if (const char *sn = getenv("DNS_OVERSOLVE")) oversolve_env = sn[0] != '0';
+    if (const char *sn = getenv("DNS_OVERSOLVE_FRAC"))
+        oversolve_frac = atof(sn);
+    if (const char *sn = getenv("DNS_OVERSOLVE_RAISE"))
+        oversolve_raise = atof(sn);
+    if (const char *sn = getenv("DNS_OVERSOLVE_LOWER"))
+        oversolve_lower = atof(sn);
     if (const char *sn = getenv("DNS_MG_FUSED")) mg_fused_knob = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_PART_MIN")) mg_part_min = atoi(sn);
     if (const char *sn = getenv("DNS_PAIR")) pair_knob = sn[0] != '0';
@@ -293,7 +300,8 @@ int dns_saddle::ensure_F_device() {
     return DNS_OK;
 }
 
-int dns_saddle::device_values_changed(bool k_current) {
+int dns_saddle::device_values_changed(bool k_current, bool own_rows_only) {
+    fvals_own_rows_only = own_rows_only;
     if (dist_sliced) {
         if (!dd || F.nnz == 0)
             return fail(DNS_ERR_NOT_READY, "sliced handle without its F block");
@@ -1083,9 +1091,20 @@ int dns_saddle::build_jacobi_schur() {
     return DNS_OK;
 }
 
+int dns_saddle::set_stop_frac(double f) {
+    // (k_batch_begin with nothing to copy: the accumulators and the fraction)
+    CopyList none;
+    none.count = 0;
+    hipLaunchKernelGGL(k_batch_begin, 1, kBlock, 0, stream, none, ctl.p, f);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
 int dns_saddle::setup_precond(const dns_precond_opts *o) {
     DNS_HIP(hipSetDevice(device));
     if (o) popts = *o;
+    oversolve = oversolve_env >= 0 ? oversolve_env != 0
+                                   : popts.schur == DNS_SCHUR_MG;
     if (popts.cheb_degree < 1 || popts.cheb_degree > 256)
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
@@ -1104,10 +1123,24 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
                         "multigrid Schur block");
     }
     if (fh_stale && F.nnz > 0) {
+        if (fvals_own_rows_only && comm && comm->nranks > 1) {
+            // a row-partitioned assembly wrote this rank's rows of F only;
+            // the rings of rows the set-up reads beyond them belong to other
+            // ranks (stale here: M + dt/2 A, or the last refresh): every rank
+            // must set up from the SAME, whole matrix -- bounds, the
+            // symmetric-part branch and its error return are decisions all
+            // ranks take alike, and the collectives behind them are entered
+            // by all or by none.  Blocks of non-zeros by velocity-row owner.
+            std::vector<int> zs((size_t)comm->nranks + 1, 0);
+            for (int q = 0; q <= comm->nranks; ++q)
+                zs[q] = Fh.rowptr[st_v[q]];
+            DNS_TRY(comm->allgatherv(F.vals.p, zs, stream));
+        }
         DNS_TRY(F.vals.download(Fh.vals.data(), (size_t)F.nnz, stream));
         DNS_HIP(hipStreamSynchronize(stream));
     }
     fh_stale = false;
+    fvals_own_rows_only = false;
     DNS_TRY(restore_full_device());   // (row-partitioned handle set up again)
     if (dinv_stale && F.nnz > 0) {
         hipLaunchKernelGGL(k_diag_inv, grid_for_elems(nv), kBlock, 0, stream,
@@ -2345,6 +2378,9 @@ static int dns_comm_create_rccl_impl(int device, int32_t nranks, int32_t rank,
         delete c;
         return fail(DNS_ERR_COMM, "ncclCommInitRank: %s", ncclGetErrorString(r));
     }
+    if (const char *form = getenv("DNS_COMM_ALLGATHER"))
+        c->ag_form = strcmp(form, "bcast") == 0 ? 1
+                     : strcmp(form, "staged") == 0 ? 2 : 0;
     *out = c;
     return DNS_OK;
 }
@@ -2391,6 +2427,161 @@ static int dns_comm_stats_impl(dns_comm *c, int64_t *n_allreduce, int64_t *n_all
 
 int dns_comm_stats(dns_comm *c, int64_t *n_allreduce, int64_t *n_allgather) {
     return dns::guarded([&]() -> int { return dns_comm_stats_impl(c, n_allreduce, n_allgather); });
+}
+
+// ---- first-contact self-test of the communicator -------------------------
+// ONE primitive per call, so that the caller can say which one did not come
+// back: 0 all-reduce of `count` doubles, 1 one grouped Send/Recv exchange round
+// the ring (to rank+1, from rank-1: the halo exchange's call pattern), 2
+// all-gather of UNEQUAL blocks (count + q doubles on rank q: staged form), 3
+// all-gather of equal blocks (in-place form).  `graph` = 0: plain launches; 1:
+// the same calls captured in a hipGraph (relaxed mode, as run_cached captures
+// a cycle) and replayed.  One call is checked entry by entry against what the
+// ranks must have produced (*ok), then `reps` calls are timed with an event
+// pair on the launch stream (*us_per_call; the wait for the slowest peer
+// included).  Collective: every rank calls with the same arguments.
+static int dns_comm_selftest_impl(dns_comm *c, int32_t which, int32_t graph,
+                                  int32_t count, int32_t reps, int32_t *ok,
+                                  double *us_per_call) {
+    if (!c || !ok || !us_per_call || which < 0 || which > 3 || count < 1 ||
+        reps < 1)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    *ok = 0;
+    *us_per_call = 0.0;
+    if (graph && !c->nccl)
+        return fail(DNS_ERR_BAD_ARGUMENT, "a host-callback communicator "
+                    "synchronises its stream: nothing to capture");
+    DNS_HIP(hipSetDevice(c->device));
+    const int n = c->nranks, me = c->rank;
+    hipStream_t s = nullptr;
+    DNS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    struct Guard {
+        hipStream_t s;
+        hipEvent_t a = nullptr, b = nullptr;
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        ~Guard() {
+            if (ge) (void)hipGraphExecDestroy(ge);
+            if (g) (void)hipGraphDestroy(g);
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    } guard{s};
+    DNS_HIP(hipEventCreate(&guard.a));
+    DNS_HIP(hipEventCreate(&guard.b));
+    // layouts
+    std::vector<int> starts((size_t)n + 1, 0);
+    for (int q = 0; q < n; ++q)
+        starts[q + 1] = starts[q] + count + (which == 2 ? q : 0);
+    const int total = which >= 2 ? starts[n] : 2 * count;
+    DevBuf<double> buf;
+    DNS_TRY(buf.alloc((size_t)total));
+    if (which >= 2) DNS_TRY(c->reserve_gather((size_t)(count + n), s));
+    std::vector<double> host((size_t)total, 0.0), back((size_t)total, 0.0);
+    const int nxt = (me + 1) % n, prv = (me + n - 1) % n;
+    std::vector<int> sc((size_t)n, 0), sd((size_t)n, 0), rc((size_t)n, 0),
+        rd((size_t)n, 0);
+    if (n > 1) {
+        sc[nxt] = count;
+        rc[prv] = count;
+    }
+    auto fill = [&](bool zero) {
+        for (int i = 0; i < total; ++i) host[i] = 0.0;
+        if (zero) return;
+        if (which == 0)
+            for (int i = 0; i < count; ++i) host[i] = (me + 1.0) * (i + 1.0);
+        else if (which == 1)
+            for (int i = 0; i < count; ++i) host[i] = 1000.0 * me + i;
+        else
+            for (int i = starts[me]; i < starts[me + 1]; ++i)
+                host[i] = 1000.0 * me + (i - starts[me]);
+    };
+    auto one = [&]() -> int {
+        if (which == 0) return c->allreduce(buf.p, count, s);
+        if (which == 1)
+            return c->alltoallv(buf.p, sc, sd, buf.p + count, rc, rd, s);
+        return c->allgatherv(buf.p, starts, s);
+    };
+    auto run = [&](int calls, bool timed) -> int {
+        if (!graph) {
+            if (timed) DNS_HIP(hipEventRecord(guard.a, s));
+            for (int r = 0; r < calls; ++r) DNS_TRY(one());
+            if (timed) DNS_HIP(hipEventRecord(guard.b, s));
+            return DNS_OK;
+        }
+        if (guard.ge) (void)hipGraphExecDestroy(guard.ge);
+        if (guard.g) (void)hipGraphDestroy(guard.g);
+        guard.ge = nullptr;
+        guard.g = nullptr;
+        DNS_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+        int rc2 = DNS_OK;
+        for (int r = 0; r < calls && rc2 == DNS_OK; ++r) rc2 = one();
+        hipError_t e = hipStreamEndCapture(s, &guard.g);
+        DNS_TRY(rc2);
+        if (e != hipSuccess)
+            return fail(DNS_ERR_HIP, "hipStreamEndCapture: %s",
+                        hipGetErrorString(e));
+        DNS_HIP(hipGraphInstantiate(&guard.ge, guard.g, nullptr, nullptr, 0));
+        if (timed) {                 // first replay untimed
+            DNS_HIP(hipGraphLaunch(guard.ge, s));
+            DNS_HIP(hipEventRecord(guard.a, s));
+        }
+        DNS_HIP(hipGraphLaunch(guard.ge, s));
+        if (timed) DNS_HIP(hipEventRecord(guard.b, s));
+        return DNS_OK;
+    };
+    // (1) one call, checked
+    fill(false);
+    DNS_TRY(buf.upload(host.data(), (size_t)total, s));
+    DNS_TRY(run(1, false));
+    DNS_TRY(buf.download(back.data(), (size_t)total, s));
+    DNS_HIP(hipStreamSynchronize(s));
+    bool good = true;
+    if (which == 0) {
+        for (int i = 0; i < count; ++i)
+            good = good && back[i] == 0.5 * n * (n + 1.0) * (i + 1.0);
+    } else if (which == 1) {
+        for (int i = 0; i < count && n > 1; ++i)
+            good = good && back[count + i] == 1000.0 * prv + i;
+    } else {
+        for (int q = 0; q < n; ++q)
+            for (int i = starts[q]; i < starts[q + 1]; ++i)
+                good = good && back[i] == 1000.0 * q + (i - starts[q]);
+    }
+    *ok = good ? 1 : 0;
+    // (2) `reps` calls, timed (on zeros: repeated sums stay finite)
+    fill(true);
+    DNS_TRY(buf.upload(host.data(), (size_t)total, s));
+    DNS_TRY(run(reps, true));
+    DNS_HIP(hipEventSynchronize(guard.b));
+    float ms = 0.f;
+    DNS_HIP(hipEventElapsedTime(&ms, guard.a, guard.b));
+    *us_per_call = 1e3 * (double)ms / reps;
+    return DNS_OK;
+}
+
+int dns_comm_selftest(dns_comm *c, int32_t which, int32_t graph, int32_t count,
+                      int32_t reps, int32_t *ok, double *us_per_call) {
+    return dns::guarded([&]() -> int { return dns_comm_selftest_impl(c, which, graph, count, reps, ok, us_per_call); });
+}
+
+int dns_comm_set_gather_form(dns_comm *c, int32_t form) {
+    if (!c || form < 0 || form > 2)
+        return fail(DNS_ERR_BAD_ARGUMENT, "bad argument");
+    c->ag_form = form;
+    return DNS_OK;
+}
+
+// how the all-gathers of this communicator were issued: out[0..2] = in-place
+// ncclAllGather, staged ncclAllGather, group of ncclBroadcasts
+int dns_comm_gather_forms(dns_comm *c, int64_t *out3) {
+    if (!c || !out3) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
+    out3[0] = c->n_ag_inplace;
+    out3[1] = c->n_ag_staged;
+    out3[2] = c->n_ag_bcast;
+    return DNS_OK;
 }
 
 static int dns_saddle_set_comm_impl(dns_saddle *h, dns_comm *c) {

@@ -70,6 +70,11 @@ k_sum_partials_n(const double *__restrict__ part, int nparts, int nscal,
     if (threadIdx.x < nscal) out[threadIdx.x] = sums[threadIdx.x];
 }
 
+// the residual norm at which a solve raises `done` (oversolve: below `tol`)
+__device__ __forceinline__ double stop_tol(const DnsCtl *ctl) {
+    return ctl->stop_frac > 0.0 ? ctl->tol * ctl->stop_frac : ctl->tol;
+}
+
 // Givens update of column j (thread 0 of workgroup 0 only)
 __device__ inline void givens_close(DnsCtl *ctl, int j, double hn,
                                     int maxiter) {
@@ -103,8 +108,11 @@ __device__ inline void givens_close(DnsCtl *ctl, int j, double hn,
     const bool conv = res <= ctl->tol;
     if (isnan(res) && status == DNS_OK) status = DNS_BREAKDOWN;
     if (status != DNS_OK) ctl->status = status;
+    if (conv && !ctl->conv) ctl->need_it = ctl->total_it;
     if (conv) ctl->conv = 1;
-    if (conv || status != DNS_OK || !(hn > 0.0) || isnan(res) ||
+    // (oversolve: the cycle goes on below the tolerance, see DnsCtl)
+    const bool stop = res <= stop_tol(ctl);
+    if (stop || status != DNS_OK || !(hn > 0.0) || isnan(res) ||
         ctl->total_it >= maxiter)
         ctl->done = 1;
 }
@@ -175,7 +183,8 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
     if (j == 0) {
         bn = sqrt(sc[1]);
         tol = fmax(rtol * bn, atol);
-        stop = !(hn > tol) || isnan(hn) ||
+        const double stol = ctl->stop_frac > 0.0 ? tol * ctl->stop_frac : tol;
+        stop = !(hn > stol) || isnan(hn) ||
                (first != 1 && ctl->total_it >= maxiter) ||
                (first == 0 && ctl->status != DNS_OK);
     }
@@ -227,6 +236,7 @@ k_arn_head(int n, int nv, int np, int j, const double *__restrict__ src,
             ctl->g[0] = hn;
             ctl->hist[0] = hn;
             if (hn <= tol) ctl->conv = 1;
+            ctl->need_it = (hn <= tol) ? 0 : -1;
             if (isnan(hn) || isnan(tol)) ctl->status = DNS_BREAKDOWN;
             ctl->done = stop ? 1 : 0;
         } else {
@@ -469,7 +479,7 @@ k_tau_guard(int np, int nv, const int *__restrict__ rowptr,
                     lo = -ctl->sn[i] * lo + ctl->cs[i] * h[i + 1];
                 const double den = hypot(lo, hn);
                 const double sn = den > 0.0 ? hn / den : 0.0;
-                v = fabs(sn * ctl->g[j - 1]) <= ctl->tol;
+                v = fabs(sn * ctl->g[j - 1]) <= stop_tol(ctl);
             }
             verdict = v;
             if (blockIdx.x == 0) ctl->predone = v;
@@ -639,6 +649,17 @@ k_orth(int n, const double *__restrict__ V, size_t ld, double *__restrict__ w,
     }
 }
 
+// batch accumulators of the oversolve policy: columns the solve needed to meet
+// the tolerance, residual / tolerance in front of its last column
+__device__ __forceinline__ void acc_need_prev(DnsCtl *ctl, int need,
+                                              double prev_res) {
+    if (need > ctl->acc_maxneed) ctl->acc_maxneed = need;
+    if (ctl->tol > 0.0) {
+        const double rel = prev_res / ctl->tol;
+        if (rel > ctl->acc_maxprev) ctl->acc_maxprev = rel;
+    }
+}
+
 // tail of a cycle of `c` steps (ONE workgroup): close the last column unless
 // the cycle already stopped, y = R^-1 g, append the cycle's residual norms to
 // the solve's history
@@ -691,6 +712,8 @@ k_arn_tail(int c, const double *__restrict__ norm_part, int nparts,
         if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
     }
     if (!ctl->conv) ctl->acc_fail += 1;
+    acc_need_prev(ctl, ctl->conv ? ctl->need_it : ctl->total_it + 1,
+                  jcols > 0 ? ctl->hist[jcols - 1] : ctl->resnorm);
 }
 
 // Tail of a cycle AND the correction x += Z y in ONE launch (one GPU): every
@@ -806,6 +829,9 @@ k_arn_tail_acc(int c, int n, const double *__restrict__ norm_part, int nparts,
                 if (rel > ctl->acc_maxrel) ctl->acc_maxrel = rel;
             }
             if (!nowconv) ctl->acc_fail += 1;
+            if (conv && !was_conv) ctl->need_it = tot;
+            acc_need_prev(ctl, nowconv ? ctl->need_it : tot + 1,
+                          jcols > 0 ? ctl->hist[jcols - 1] : res);
         }
     }
     __syncthreads();

@@ -81,9 +81,23 @@ struct dns_imex {
     uint64_t six_conv_gen = 0;     // conv->dbc_gen the cell values belong to
     int prime_six(const dns_imex_coeffs *cf, bool keep_r);
     // coefficients of the polynomial warm start from `nsol_` solutions
+    static constexpr int kExtrapFit35 = 13;
     static int extrap_coeffs(int nsol_, int order, double e[5]) {
         e[0] = 1.0;
         e[1] = e[2] = e[3] = e[4] = 0.0;
+        if (nsol_ >= 5 && order == kExtrapFit35) {
+            // value at the new time of the CUBIC least-squares fit through the
+            // last FIVE solutions.  A warm start multiplies the final
+            // residuals of the solves it is built from by its coefficients:
+            // sqrt(sum c^2) = 4.9 here against 15.8 for the interpolating
+            // quartic (8.3 cubic), for 1.8 x the cubic's truncation error --
+            // once the start residual consists of those residuals rather
+            // than of the truncation error (dt <= 1e-3: scripts/
+            // recycle_probe.py) that is the better trade
+            e[0] = 3.2; e[1] = -2.8; e[2] = -0.8; e[3] = 2.2; e[4] = -0.8;
+            return 3;
+        }
+        if (order == kExtrapFit35) order = 3;      // (history still filling)
         if (nsol_ >= 5 && order >= 4) {
             e[0] = 5.0; e[1] = -10.0; e[2] = 10.0; e[3] = -5.0; e[4] = 1.0;
             return 4;
@@ -162,6 +176,12 @@ struct dns_imex {
     int cpred = -1;                // predicted cycle length of a batch
     bool noslack = false;
     int noslack_hold = 1;
+    // oversolve policy (multigrid Schur block, DnsCtl::stop_frac): `cpred` is
+    // then the cycle length itself; it comes down only when every solve of a
+    // batch stood a decade below the tolerance in FRONT of its last column
+    // and goes up, without a replay, when a batch ended close to it
+    int lower_hold = 0, lower_backoff = 4;
+    bool lowered_last = false;
     int batch_len = 8;             // steps per batch: 8 -> 16 -> 32 while the
                                    // predictions hold
     uint64_t prepared_sig = 0;     // configuration the graphs were captured for

@@ -35,6 +35,15 @@ struct DnsCtl {
     // BiCGStab scalars
     double rho, alpha, omega;
     double acc_maxrel;   // batch maximum of (final residual / tolerance)
+    // "Oversolve" (pipelined batches, multigrid Schur block): the nodes of a
+    // replayed cycle are paid for whether they work or not, so a solve does
+    // not stop at the tolerance but runs the cycle's columns -- `done` is
+    // raised at stop_frac x tol (0 = 1: stop at the tolerance); `conv` still
+    // means "met the tolerance".  What the host's prediction of the cycle
+    // length then goes by: the largest number of columns a solve NEEDED, and
+    // the largest residual / tolerance in front of the last column.
+    double stop_frac, acc_maxprev;
+    int acc_maxneed, need_it;
     double hcol[kMaxRestart + 1];
     double cs[kMaxRestart], sn[kMaxRestart], g[kMaxRestart + 1];
     double y[kMaxRestart];

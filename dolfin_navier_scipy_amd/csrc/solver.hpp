@@ -312,6 +312,8 @@ struct CtlHeaderAcc {   // header + the batch accumulators behind it
     int acc_solves, acc_fail, acc_iters, acc_maxit;
     double rho, alpha, omega;          // (BiCGStab scalars, layout of DnsCtl)
     double acc_maxrel;
+    double stop_frac, acc_maxprev;
+    int acc_maxneed, need_it;
 };
 
 // a captured chunk of work, replayed with hipGraphLaunch
@@ -459,6 +461,10 @@ struct dns_saddle {
     // logical OR of a flag over the ranks of the communicator (one all-reduce
     // of one scalar, synchronises the stream; never inside a capture)
     int all_ranks_any(bool mine, bool *any);
+    // a LOCAL verdict inside a collective routine of the set-up: every rank
+    // enters, the failing rank returns its own status, the others
+    // DNS_ERR_COMM -- nobody is left waiting in the exchange behind it
+    int agree(int rc_local, const char *where);
     bool graph_capable() const {
         return !dist() || (comm->nccl != nullptr && dist_graph_ok);
     }
@@ -508,6 +514,20 @@ struct dns_saddle {
     int schur_mg_apply_dist(const double *in, double *zp, const int *guard);
     int last_iters = -1;              // iteration count of the previous solve
     int pipeline_c = 0;               // > 0: one cycle of this length, no sync
+    // oversolve (DnsCtl::stop_frac): the solves of a pipelined batch run their
+    // cycle's columns instead of stopping at the tolerance.  On by default with
+    // the multigrid Schur block (DNS_OVERSOLVE=0/1 overrides): there a cycle
+    // is 2-3 columns of 13+ launch-bound nodes each, the residual of a solve
+    // that stops AT the tolerance keeps the slack column of the old policy in
+    // every cycle, and it is the final residuals of the last solves,
+    // amplified by the warm start's coefficients, that the next start
+    // residual consists of (scripts/recycle_probe.py)
+    bool oversolve = false;
+    int oversolve_env = -1;           // DNS_OVERSOLVE: -1 unset
+    double oversolve_frac = 1e-3;     // raise `done` at this fraction of tol
+    double oversolve_raise = 0.5;     // batch max of final res / tol: c + 1
+    double oversolve_lower = 0.1;     // ... in front of the last column: c - 1
+    int set_stop_frac(double f);
     bool capturing = false;           // a run_cached capture is open
     // multigrid Schur block (DNS_SCHUR_MG): level 0 = the pressure space
     struct MgLevel {
@@ -579,11 +599,16 @@ struct dns_saddle {
     dns::DevBuf<double> tau;
     bool have_jg = false;
     bool fh_stale = false;            // F.vals changed on the device
+    // ... by a row-partitioned assembly: only this rank's rows are current
+    // (trap_capi.inc, RowRange); a set-up gathers the others from their
+    // owners before it takes the values to the host
+    bool fvals_own_rows_only = false;
     bool dinv_stale = false;          // ... and 1/diag(F) was not refreshed
                                       // (explicit Fh^-1: nobody reads it
                                       // between two set-ups)
     // (k_current: the caller's kernel has written the new values into K too)
-    int device_values_changed(bool k_current = false);
+    int device_values_changed(bool k_current = false,
+                              bool own_rows_only = false);
     int ensure_F_device();            // a sliced handle gets its F block back
     int dist_v0() const;              // this rank's velocity rows [v0, v1)
     int dist_v1() const;

@@ -743,7 +743,7 @@ struct CopyList {
 };
 
 __global__ void __launch_bounds__(kBlock)
-k_batch_begin(CopyList cl, DnsCtl *ctl) {
+k_batch_begin(CopyList cl, DnsCtl *ctl, double stop_frac) {
     for (int q = 0; q < cl.count; ++q) {
         const double *__restrict__ s = cl.src[q];
         double *__restrict__ d = cl.dst[q];
@@ -757,6 +757,9 @@ k_batch_begin(CopyList cl, DnsCtl *ctl) {
         ctl->acc_iters = 0;
         ctl->acc_maxit = 0;
         ctl->acc_maxrel = 0.0;
+        ctl->acc_maxprev = 0.0;
+        ctl->acc_maxneed = 0;
+        ctl->stop_frac = stop_frac;
     }
 }
 

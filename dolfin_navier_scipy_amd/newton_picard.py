@@ -282,7 +282,7 @@ class TrapezoidalStepper(object):
         self.refreshes += 1
 
     def sweep(self, trange, iniv, lin_which, picard, opts=None, extrapolate=4,
-              record=True, pipeline=True, batch=None):
+              record=True, pipeline=True, batch=None, feedback=None):
         """one sweep over `trange` linearised about trajectory `lin_which`
         (slot k <-> trange[k]); the new velocities go to the other trajectory.
         Returns `(vdict, pdict, norm_nwtnupd, stats)` (dicts empty unless
@@ -299,7 +299,13 @@ class TrapezoidalStepper(object):
         about the current operator before the next batch (a first batch above
         the bound gets one rebuild straight away: a set-up made for another
         state) -- the system matrix follows the flow every step, the
-        preconditioner follows it when it pays."""
+        preconditioner follows it when it pays.
+
+        `feedback`: callable `t -> (umat (NV, r), vmat (r, NV))`, the low-rank
+        terms of the closed loop per time instance (snu:1367-1384, 1461-1483;
+        `umat` the same at every instance -- the reference's `b_mat`); such
+        sweeps run step by step (every Woodbury column is a solve of its
+        own)."""
         trange = np.asarray(trange, dtype=np.float64)
         if trange.size > self.nslots:
             raise ValueError('trajectory buffers hold {0} slots'.format(
@@ -318,9 +324,20 @@ class TrapezoidalStepper(object):
         tot = dict(iters=0, device_seconds=0., refreshes=0, replayed_batches=0,
                    batches=[])
 
+        def lowrank(k):
+            if feedback is None:
+                return None
+            umat_c, vmat_c = feedback(trange[k-1])
+            umat_n, vmat_n = feedback(trange[k])
+            if umat_c is not umat_n and not np.array_equal(umat_c, umat_n):
+                raise NotImplementedError('`umat` must not depend on the time '
+                                          '(one input matrix, snu:1476-1478)')
+            return umat_n, vmat_c, vmat_n
+
         def one(k):
             st = self.step(trange[k] - trange[k-1], lin_which, k, k, newton,
-                           opts=opts, extrapolate=extrapolate)
+                           opts=opts, extrapolate=extrapolate,
+                           feedback=lowrank(k))
             if record:
                 vdict[trange[k]], pdict[trange[k]] = self.state()
             return st
@@ -359,7 +376,7 @@ class TrapezoidalStepper(object):
                 self.refresh_precond()
                 tot['refreshes'] += 1
 
-        pipelined = pipeline and uniform
+        pipelined = pipeline and uniform and feedback is None
         # (synchronous until the warm start has its full order -- five
         # solutions for the quartic one: the steps before need more Krylov
         # steps than the run will, and a first batch sized by them fails)
@@ -413,7 +430,7 @@ def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
                   vel_nwtn_stps=2, vel_nwtn_tol=1e-14, opts=None,
                   extrapolate=4, rhs_table=None, nsects=1,
                   loc_nwtn_tol=5e-15, loc_pcrd_stps=True, addfullsweep=False,
-                  tables=None):
+                  tables=None, feedback=None):
     """Picard sweeps first, then Newton sweeps, each linearised about the
     previous sweep's trajectory (snu:1304-1334, 1562-1587).  `linpoints0`:
     `{t: v_inner}` for the first sweep (key `None`: the value for every time
@@ -423,7 +440,8 @@ def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
     `fp` (NP), `mbc` (NV; `condense_velmatsbybcs(M, ..., get_rhs_only=True)`
     of the controlled boundary values, snu:1438-1441) and `dbc` (the
     convection operator's Dirichlet values): controlled Dirichlet values that
-    are functions of the time (snu:1433-1466).
+    are functions of the time (snu:1433-1466).  `feedback`: see
+    `TrapezoidalStepper.sweep`.
 
     `nsects`, `loc_nwtn_tol`, `loc_pcrd_stps`, `addfullsweep` as in the
     reference (snu:1076-1091, 1576-1587): the time range is cut into sections
@@ -477,7 +495,7 @@ def newton_picard(stepper, trange, iniv, linpoints0, vel_pcrd_stps=1,
                 first = False
             vdict, pdict, norm_nwtnupd, _ = stepper.sweep(
                 loctrng, iniv, which, picard, opts=opts,
-                extrapolate=extrapolate)
+                extrapolate=extrapolate, feedback=feedback)
             hist.append(('picard' if picard else 'newton', norm_nwtnupd))
             which = 1 - which       # the new trajectory = next lin. points
             cur.update(vdict)

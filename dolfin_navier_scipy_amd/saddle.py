@@ -122,9 +122,11 @@ class SaddleSystem(object):
     def set_comm(self, comm):
         """attach a `comm.Comm` (row-partitioned solve); call before
         `setup_precond`; `None` detaches"""
-        self._comm = comm
         C.check(self.lib.dns_saddle_set_comm(
             self._h, comm._h if comm is not None else None))
+        # (only once the library has taken it: a handle created from rows
+        # refuses another communicator and keeps the one it has)
+        self._comm = comm
         self.precond_ready = False
 
     def device_matrix_bytes(self):
@@ -458,10 +460,18 @@ def streaming_precond_defaults(n):
     keeps the Krylov-step count and cuts the stream -- measured on the refined
     wake (profiles/r04_gc_pareto/table.txt): n = 173k 3651 -> 4039 steps/s,
     n = 693k 1301 -> 1595, n = 2.78M 308 -> 431.  At the reference sizes (cache
-    resident, ONE Krylov step per time step) degree 6 / 1e-3 stays."""
+    resident, ONE Krylov step per time step) degree 6 / 1e-3 stays.
+
+    `extrapolate`: order of the warm start.  With the multigrid Schur block a
+    solve runs the two columns of its cycle whatever its residual (oversolve,
+    `solver.hpp`); what the next start residual then consists of is the final
+    residuals of the last solves times the warm start's coefficients, and the
+    cubic's (sum |c| = 15) keep a two-column cycle contracting where the
+    quartic's (31) do not: n = 173k 4175 -> 4490 steps/s, n = 693k 1434 ->
+    1870, n = 2.78M 465 -> 604 (profiles/r05_oversolve/)."""
     if n >= 100000:
-        return dict(cheb_degree=8, drop_tol=7e-3)
-    return dict(cheb_degree=6, drop_tol=1e-3)
+        return dict(cheb_degree=8, drop_tol=7e-3, extrapolate=3)
+    return dict(cheb_degree=6, drop_tol=1e-3, extrapolate=4)
 
 
 # ---- standalone kernels ---------------------------------------------------

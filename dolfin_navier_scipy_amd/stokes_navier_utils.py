@@ -352,6 +352,7 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
               return_dictofpstrs=False, cv_mat=None, check_ff=False,
               check_ff_maxv=1e8, verbose=False, start_ssstokes=False,
               closed_loop=False, dynamic_feedback=False, static_feedback=False,
+              b_mat=None, feedbackthroughdict=None,
               vp_output=False, vp_out_fun=None, vp_output_dict=None,
               solver=None, device=0, bcs_time_only=False,
               applybcs_literal=True, **kw):
@@ -359,8 +360,18 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
 
     Keyword names and meaning follow the reference.  `V`: object with the P2
     element data (module docstring).  Differences: result dictionaries hold
-    arrays instead of file names; `closed_loop` feedback (observer helpers,
-    SURVEY section 2: out of scope) raises.  Extra keywords: `solver`
+    arrays instead of file names.  `closed_loop` in the Newton/Picard sweeps
+    (snu:1367-1384, 1461-1483, 1036-1040): `b_mat` (NV x r, inner dofs) and
+    `feedbackthroughdict` -- `{t: dict(mtxtb=(NV, r) array, w=(NV, 1) array)}`,
+    key `None` with `static_feedback`, key `0` for the initial instance
+    otherwise (the name the reference's loop reads; it is bound nowhere in
+    the reference at this commit) -- add `b_mat (b_mat^T w)` to the right-hand
+    sides and the low-rank term `dt/2 b_mat mtxtb^T` to the system
+    (`TrapezoidalStepper.step(feedback=)`, Sherman-Morrison-Woodbury on the
+    device).  In the explicit schemes the reference's static feedback does
+    nothing (snu:1261-1262) and neither does it here; `dynamic_feedback`
+    (observer helpers of `tiu`, SURVEY section 2: out of scope) raises.
+    Extra keywords: `solver`
     (overrides `time_int_utils.SOLVER`), `device`, `bcs_time_only` (the
     control functions `diricontfuncs` ignore `vel`/`p`: the explicit loop may
     then run device resident over whole time slices), `applybcs_literal`
@@ -368,9 +379,14 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
     reference's does with snu:1112 commented out; False: the controlled values
     are written into the auxiliary vector, see `bcs.make_applybcs`).
     """
-    if closed_loop or dynamic_feedback or static_feedback:
-        raise NotImplementedError('feedback loops / observers are outside the '
-                                  'MI355X path (SURVEY.md section 2)')
+    if dynamic_feedback:
+        raise NotImplementedError('observer-based (dynamic) feedback is '
+                                  'outside the MI355X path (SURVEY.md '
+                                  'section 2)')
+    if closed_loop and not treat_nonl_explicit and \
+            (b_mat is None or feedbackthroughdict is None):
+        raise ValueError('`closed_loop` in the Newton/Picard sweeps needs '
+                         '`b_mat` and `feedbackthroughdict`')
     _warn_ignored('solve_nse', kw)
     if trange is None:
         trange = np.linspace(t0, tE, Nts+1)
@@ -615,12 +631,37 @@ def solve_nse(A=None, M=None, J=None, JT=None, fv=None, fp=None, fvtd=None,
                 linpoints[None] = _lp(None)
         except TypeError:
             pass
+        feedback = None
+        if closed_loop:
+            # snu:1367-1384, 1461-1483
+            import scipy.sparse as sps
+            bdense = np.asarray(b_mat.todense()) if sps.issparse(b_mat) \
+                else np.asarray(b_mat, dtype=np.float64)
+
+            def _fbentry(t):
+                if static_feedback:
+                    return feedbackthroughdict[None]
+                return feedbackthroughdict[0 if t == trange[0] else t]
+
+            def feedback(t):
+                return bdense, np.asarray(_fbentry(t)['mtxtb']).T
+            fbcols = np.hstack([
+                b_mat @ (b_mat.T @ np.asarray(
+                    _fbentry(t)['w'], dtype=np.float64).reshape((-1, 1)))
+                for t in trange])
+            if tables is not None:
+                tables['fv'] = tables['fv'] + fbcols
+            else:
+                base = fvtab if fvtab is not None else \
+                    np.tile(np.asarray(cfv).reshape((-1, 1)), (1, trange.size))
+                fvtab = base + fbcols
         vdict, pdict_, hist = dnp.newton_picard(
             ts, trange, iniv, linpoints, vel_pcrd_stps=vel_pcrd_stps,
             vel_nwtn_stps=vel_nwtn_stps, vel_nwtn_tol=vel_nwtn_tol,
             rhs_table=fvtab, nsects=nsects, loc_nwtn_tol=loc_nwtn_tol,
             loc_pcrd_stps=loc_pcrd_stps, addfullsweep=addfullsweep,
-            tables=tables, opts=(solver or {}).get('opts'))
+            tables=tables, opts=(solver or {}).get('opts'),
+            feedback=feedback)
     finally:
         ts.close()
     tlast = trange[-1]

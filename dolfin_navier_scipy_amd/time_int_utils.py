@@ -33,7 +33,7 @@ __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 # at 1e-12 (1e-8) -- tests/test_gpu_config5.py)
 SOLVER = dict(method='gmres', rtol=None, maxiter=400, restart=60,
               cheb_degree=6, drop_tol=1e-3, factorization='full', reorth=2,
-              schur='auto', extrapolate=4, device=0, check_every=2,
+              schur='auto', extrapolate='auto', device=0, check_every=2,
               use_graph=True, carry_residual=True)
 
 
@@ -94,6 +94,11 @@ def _device_system(fmat, J, prm):
         # nested pressure spaces given: multigrid Schur block (refined meshes)
         system.set_schur_mg(prm['prolongations'])
         schur = 'mg'
+    if prm['extrapolate'] == 'auto':
+        # warm start: quartic where one Krylov step per time step does it
+        # (dense Schur block); cubic with the multigrid block, whose solves
+        # run their cycle's two columns (`saddle.streaming_precond_defaults`)
+        prm['extrapolate'] = 3 if schur == 'mg' else 4
     # the full block factorisation needs the explicit polynomial matrix
     fact = prm['factorization']
     if fmat.shape[0] > 1000000 or not 2 <= prm['cheb_degree'] <= 12:

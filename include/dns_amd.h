@@ -256,6 +256,23 @@ int dns_comm_stats2(dns_comm *c, int64_t *out5);
  * between the events includes the wait for the slowest peer. */
 int dns_comm_set_timing(dns_comm *c, int on);
 int dns_comm_timing(dns_comm *c, double *ms3, int64_t *calls3);
+/* First-contact self-test, ONE primitive per call (so that a caller can say
+ * which one did not come back): `which` 0 = all-reduce of `count` doubles, 1 =
+ * one grouped ncclSend/ncclRecv exchange round the ring (the halo exchange's
+ * call pattern), 2 = all-gather of unequal blocks (staged ncclAllGather), 3 =
+ * all-gather of equal blocks (in-place ncclAllGather); `graph` 0 = plain
+ * launches, 1 = captured in a hipGraph and replayed.  One call is checked
+ * entry by entry (*ok), then `reps` calls are timed by an event pair on the
+ * launch stream (*us_per_call).  Collective.  No reference counterpart. */
+int dns_comm_selftest(dns_comm *c, int32_t which, int32_t graph, int32_t count,
+                      int32_t reps, int32_t *ok, double *us_per_call);
+/* out[0..2] = all-gathers issued as in-place ncclAllGather, staged
+ * ncclAllGather (unequal blocks), group of ncclBroadcasts (fallback) */
+int dns_comm_gather_forms(dns_comm *c, int64_t *out3);
+/* 0 = in-place where the blocks are equal, staged otherwise (default); 1 = the
+ * group of broadcasts; 2 = always staged (tests: one rank exercises the pack /
+ * unpack path).  Environment DNS_COMM_ALLGATHER=bcast|staged sets it too. */
+int dns_comm_set_gather_form(dns_comm *c, int32_t form);
 /* The halo plan of a row partition, host only (no GPU needed): for the CSR
  * pattern `a` (n rows, columns < ncols_part partitioned by `col_starts`
  * [nranks+1]; columns >= ncols_part are ignored) and the rows [row0, row1) of
@@ -327,7 +344,11 @@ typedef struct dns_imex_coeffs {
     int32_t extrapolate_x0;      /* warm start: 0: x0 = x_c, 1: 2 x_c - x_p,
                                     2: 3 x_c - 3 x_p + x_pp (quadratic),
                                     3: 4 x_c - 6 x_p + 4 x_pp - x_ppp (cubic),
-                                    4: 5, -10, 10, -5, 1 (quartic)            */
+                                    4: 5, -10, 10, -5, 1 (quartic);
+                                    13: cubic least-squares fit through the
+                                    last five solutions (3.2, -2.8, -0.8, 2.2,
+                                    -0.8: a third of the quartic's
+                                    amplification of the solves' residuals) */
     int32_t carry_residual;      /* 1: the velocity residual b - K x of a step's
                                     (inexact) solve is added to the next
                                     step's right-hand side, so that the

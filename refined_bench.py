@@ -54,7 +54,9 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True,
     stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
     stp.set_convection(cv, scale=-1.0)
     cf = saddle.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
-                                   pscale=-1./dt, extrapolate=4)
+                                   pscale=-1./dt,
+                                   extrapolate=int(os.environ.get(
+                                       'MG_EXTRAP', dflt['extrapolate'])))
     opts = saddle.solve_opts(rtol=1e-10, maxiter=400, use_graph=graph,
                              reorth=int(os.environ.get('MG_REORTH', '2')))
     # untimed steps between the start from rest (inflow switched on at t=0) and

@@ -139,3 +139,70 @@ def test_multi_rank_launch_plumbing_on_cpu(tmp_path):
     assert cfg['weak_scaling']['start_state'] == 'stokes'
     assert cfg['strong_scaling']['start_state'] == 'stokes'
     assert cfg['weak_scaling_bandwidth']['start_state'] == 'rest'
+
+
+def _json_lines(raw):
+    return [ln for ln in raw.decode().splitlines() if ln.startswith('{')]
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver's N=1
+    record shows the script being started): the script starts its two rank
+    processes itself and prints an `n_gpus: 2` line carrying the RCCL
+    first-contact record -- never the one-GPU line"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR',
+                        'MASTER_PORT')}
+    env['GLOO_SOCKET_IFNAME'] = 'lo'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                          '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--dry-run', '--partitioned-timeout', '120'],
+                         env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    assert 'without a launcher' in out.stderr.decode()
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1, out.stdout.decode()
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['scaling'] == 'weak'
+    st = rec['config']['rccl_selftest']
+    assert st['complete'] is True and st['world'] == 2
+    assert sorted(st['primitives']) == sorted(
+        name + suffix for name, _ in bench.SELFTEST_LEGS[::2]
+        for suffix in ('_eager', '_graph'))
+    assert 'FALLBACK' not in rec['config']['parallelism']
+
+
+def test_a_launch_for_another_n_is_refused():
+    """`--gpus 8` inside a launch of 2 ranks (or of 1) prints no line"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'),
+                          '--gpus', '8', '--dry-run'], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=120)
+    assert out.returncode != 0
+    assert not _json_lines(out.stdout)
+    assert 'refusing' in out.stderr.decode()
+
+
+def test_self_launch_refuses_more_ranks_than_gpus(monkeypatch):
+    import argparse
+    monkeypatch.setattr(bench, 'visible_gpu_count', lambda: 1)
+    monkeypatch.delenv('DNS_BENCH_REHEARSE_ONE_GPU', raising=False)
+    args = argparse.Namespace(gpus=4, dry_run=False, time_budget=10.)
+    with pytest.raises(SystemExit) as exc:
+        bench.self_launch(args)
+    assert exc.value.code == 2
+
+
+def test_run_child_keeps_the_last_record_of_a_killed_child():
+    """the self-test prints its record after every primitive: what a hung
+    child had reported says which primitive did not come back"""
+    code = ('import sys, time, json; print(json.dumps(dict(stage="entering '
+            'allreduce_graph"))); sys.stdout.flush(); time.sleep(60)')
+    res = bench.run_child([sys.executable, '-c', code], dict(os.environ), 2.,
+                          True)
+    assert 'killed' in res['error']
+    assert res['partial'] == {'stage': 'entering allreduce_graph'}

@@ -439,6 +439,56 @@ def test_solve_nse_newton_picard_branch(snu, toy_prob):
                            toy_prob['dbcvals'])
 
 
+@pytest.mark.parametrize('static', [True, False])
+def test_solve_nse_closed_loop_feedback_in_the_sweeps(snu, toy_prob, static):
+    """`closed_loop` / `static_feedback` / `feedbackthroughdict` (arrays) of
+    `solve_nse` (snu:1367-1384, 1461-1483): `b_mat (b_mat^T w)` in the
+    right-hand sides, the low-rank term `dt/2 b_mat mtxtb^T` in the system
+    (`_get_mats_rhs_ts`, snu:1036-1040, PLUS quirk kept) -- the device
+    stepper's Sherman-Morrison-Woodbury steps against the oracle's sweeps"""
+    kw, rec, _ = scenarios.build(variant='plain', seed=0, Nts=6, tE=0.03,
+                                 prob=toy_prob)
+    imex_oracle.cnab(**kw)
+    times, vels, _ = rec.arrays()
+    lin0 = {t: vels[k].reshape((-1, 1)) for k, t in enumerate(times)}
+    skw = _static_kwargs(toy_prob, kw)
+    M = skw['M']            # (the scenario's matrices are condensed already)
+    NV = M.shape[0]
+    rng = np.random.default_rng(5)
+    b_mat = 1e-1*(M @ rng.standard_normal((NV, 2)))
+
+    def entry(seed):
+        r = np.random.default_rng(seed)
+        return dict(mtxtb=r.standard_normal((NV, 2))/np.sqrt(NV),
+                    w=1e-1*r.standard_normal((NV, 1)))
+    if static:
+        fbd = {None: entry(0)}
+    else:
+        fbd = {t: entry(k + 1) for k, t in enumerate(kw['trange'])}
+        fbd[0] = fbd[kw['trange'][0]]
+    fkw = dict(closed_loop=True, static_feedback=static, b_mat=b_mat,
+               feedbackthroughdict=fbd, lin_vel_point=lin0, vel_pcrd_stps=1,
+               vel_nwtn_stps=2)
+    vdo, pdo, histo = so.solve_nse(**fkw, **skw)
+    vd0, _, _ = so.solve_nse(lin_vel_point=lin0, vel_pcrd_stps=1,
+                             vel_nwtn_stps=2, **skw)
+    vdg, pdg = snu.solve_nse(treat_nonl_explicit=False,
+                             return_dictofvelstrs=True,
+                             return_dictofpstrs=True, **fkw, **skw)
+    inv = toy_prob['invinds']
+    tE = kw['trange'][-1]
+    # (the loop is closed: the trajectory is not the open-loop one)
+    assert _rel(vdo[tE], vd0[tE]) > 1e-4
+    for t in kw['trange'][1:]:
+        assert _rel(vdg[t][inv], vdo[t]) <= VTOL, t
+        assert _rel(pdg[t], pdo[t]) <= PTOL, t
+    with pytest.raises(ValueError):
+        snu.solve_nse(treat_nonl_explicit=False, closed_loop=True,
+                      lin_vel_point=lin0, **skw)
+    with pytest.raises(NotImplementedError):
+        snu.solve_nse(dynamic_feedback=True, **skw)
+
+
 def test_newton_sweeps_at_once_and_resumed_as_the_reference_driver(snu):
     """`tests/time_dep_nse_linearizations.py:10-61` (cylinder wake N = 1, Re = 40,
     `vel_nwtn_tol = 1e-14`, Stokes start; the driver's dt = 0.01 is beyond the

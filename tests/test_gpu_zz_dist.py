@@ -326,6 +326,38 @@ def test_rccl_world_size_one_equals_plain_solve():
     cm.close()
 
 
+def test_rccl_selftest_and_the_all_gather_forms_on_one_rank():
+    """`dns_comm_selftest` (the first-contact leg of `bench.py --gpus N`):
+    every primitive of the partitioned path, plain and captured in a hipGraph,
+    checked entry by entry -- and the all-gather as ONE ncclAllGather: in
+    place for equal blocks, through the staging buffer + unpack kernel
+    otherwise (forced here: one rank has no unequal blocks), against the
+    group of broadcasts it replaces"""
+    from dolfin_navier_scipy_amd import saddle, comm as dcomm, _capi
+    cm = dcomm.Comm.rccl(0, 1, 0, dcomm.rccl_unique_id())
+    for form in ('auto', 'staged', 'bcast'):
+        cm.set_gather_form(form)
+        for name in cm.SELFTEST_PRIMITIVES:
+            for graph in (False, True):
+                one = cm.selftest(name, graph=graph, count=5, reps=10)
+                assert one['ok'], (form, name, graph)
+                assert 0.0 < one['us_per_call'] < 1e5, one
+    forms = cm.gather_forms()
+    assert min(forms.values()) > 0, forms
+    # the same solve whichever way the blocks travel
+    ref = None
+    for form in ('auto', 'staged', 'bcast'):
+        cm.set_gather_form(form)
+        x, st, v, p = _solve_and_step(saddle, cm, 'full', True)
+        assert st['status'] == 0
+        if ref is None:
+            ref = (x, v)
+        assert np.array_equal(x, ref[0]) and np.array_equal(v, ref[1])
+    with pytest.raises(_capi.DnsError):
+        cm.selftest(7)
+    cm.close()
+
+
 def test_one_step_cycles_carry_the_norms_with_the_dots():
     """pipelined CNAB steps of the bench workload on one RCCL rank: once the
     warm start is good every solve is ONE Krylov step, and with 'dist_lazy1'
@@ -693,6 +725,19 @@ def _trap_sweeps(comm):
         stp.step(dt, 0, k, k, True, opts=osync,
                  feedback=(umat, vmats[k-1], vmats[k]))
     s['fb_state'] = stp.state()
+    # a preconditioner REFRESH about the operator of the step that ran last.
+    # A partitioned assembly leaves only the rank's own rows of F current on
+    # its device; the set-up reads rings of rows beyond them (polynomial,
+    # bounds, skew radius): they are gathered from their owners first, so
+    # that every rank sets up from the same, whole matrix
+    stp.refresh_precond()
+    s['refresh_bounds'] = np.array(stp.system.cheb_bounds(), dtype=float)
+    its = []
+    for k in range(4, min(7, tr.size)):
+        st = stp.step(dt, 0, k, k, True, opts=osync)
+        its.append(st['iters'])
+    s['refresh_iters'] = np.array(its)
+    s['refresh_state'] = stp.state()
     stp.close()
     cv.close()
     tl = tr[-1]
@@ -719,7 +764,8 @@ def _worker_trap(rank, world, port, outdir):
     after = cm.stats()
     np.savez(os.path.join(outdir, 'trap_rank{0}.npz'.format(rank)), v=v, p=p,
              fbv=sw['fb_state'][0], fbp=sw['fb_state'][1],
-             hist=hist, halo=after['halo_exchange'] - before['halo_exchange'],
+             rbounds=sw['refresh_bounds'], rits=sw['refresh_iters'],
+             rv=sw['refresh_state'][0], hist=hist, halo=after['halo_exchange'] - before['halo_exchange'],
              gathers=after['allgatherv'] - before['allgatherv'],
              sweep_gathers=sw['sweep_gathers'], sweep_steps=sw['sweep_steps'],
              nslots=sw['nslots'])
@@ -748,6 +794,16 @@ def test_newton_picard_sweeps_on_a_partitioned_handle(tmp_path):
     fv1, fp1 = s['fb_state']
     assert np.linalg.norm(r0['fbv'] - fv1) <= 1e-9*np.linalg.norm(fv1)
     assert np.linalg.norm(r0['fbp'] - fp1) <= 1e-8*np.linalg.norm(fp1)
+    # the refreshed preconditioner: the same on both ranks and on one GPU
+    # (bounds of the WHOLE current F), hence the same Krylov step counts
+    assert np.array_equal(r0['rbounds'], r1['rbounds'])
+    assert np.allclose(r0['rbounds'], s['refresh_bounds'], rtol=1e-12)
+    assert np.array_equal(r0['rits'], r1['rits'])
+    assert np.array_equal(r0['rits'], s['refresh_iters']), \
+        (r0['rits'], s['refresh_iters'])
+    assert np.array_equal(r0['rv'], r1['rv'])
+    rv1 = s['refresh_state'][0]
+    assert np.linalg.norm(r0['rv'] - rv1) <= 1e-9*np.linalg.norm(rv1)
     tr = s['trange']
     lin_full = {t: s['appnd'](v) for t, v in s['lin0'].items()}
     vo, po, _ = npo.newton_picard(
@@ -785,20 +841,25 @@ def test_newton_picard_sweeps_on_one_rccl_rank():
     assert calls['allgatherv'] > 0 and calls['allreduce'] > 0
 
 
-def _bench_two_ranks_one_gpu(extra_env, timeout=900):
+def _bench_two_ranks_one_gpu(extra_env, timeout=900, self_launch=False):
     """`bench.py --gpus 2` as the driver launches it, both ranks on this
     box's one GPU through the gloo-staged communicator"""
     import json
     import subprocess
     from spawn_util import free_port
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'),
-           '--gpus', '2', '--steps', '20', '--warmup', '5', '--spinup', '24',
-           '--no-bandwidth', '--no-strong', '--no-ensemble',
-           '--partitioned-timeout', '400']
-    env = dict(os.environ, DNS_BENCH_REHEARSE_ONE_GPU='1',
-               GLOO_SOCKET_IFNAME='lo', **extra_env)
+    launcher = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                '--master-port', str(free_port())]
+    if self_launch:       # no launcher: bench.py starts its two ranks itself
+        launcher = [sys.executable]
+    cmd = launcher + [os.path.join(ROOT, 'bench.py'),
+                      '--gpus', '2', '--steps', '20', '--warmup', '5',
+                      '--spinup', '24', '--no-bandwidth', '--no-strong',
+                      '--no-ensemble', '--partitioned-timeout', '400']
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(DNS_BENCH_REHEARSE_ONE_GPU='1', GLOO_SOCKET_IFNAME='lo',
+               **extra_env)
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE,
                          stderr=subprocess.PIPE, timeout=timeout)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
@@ -815,9 +876,15 @@ def test_bench_n2_line_carries_its_parity_and_a_wrong_halo_turns_it_red():
     with ONE wrong entry (`DNS_TEST_CORRUPT_HALO`) fails the leg instead of
     producing a rate (a solver that merely converges would not notice: the
     partitioned code computes its own `true_relres`)"""
-    rec, _ = _bench_two_ranks_one_gpu({})
+    rec, _ = _bench_two_ranks_one_gpu({}, self_launch=True)
+    assert rec['n_gpus'] == 2
     weak = rec['config']['weak_scaling']
     assert 'error' not in weak, weak.get('error')
+    # first contact of the two (gloo-staged) ranks: the plain legs ran
+    st = rec['config']['rccl_selftest']
+    assert st['complete'] and st['ok'], st
+    assert st['primitives']['sendrecv_ring_eager']['ok']
+    assert 'skipped' in st['primitives']['allreduce_graph']
     par = rec['parity']
     assert par == weak['parity'] and par['ok'] is True
     assert par['v_rel_Mnorm'] <= 1e-8 and par['p_rel_l2'] <= 1e-8, par

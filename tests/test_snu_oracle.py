@@ -255,3 +255,68 @@ def test_oracle_solve_nse_converges_with_second_order_in_time(toy_prob, scheme):
         errs.append(float(np.sqrt((difv.T @ (M @ difv)).item())))
     orders = [np.log2(errs[k]/errs[k + 1]) for k in range(dblng - 1)]
     assert orders[0] >= 1.8 and all(o >= 1.6 for o in orders), (errs, orders)
+
+
+def test_oracle_closed_loop_sweeps_satisfy_the_step_equation(toy_prob):
+    """`closed_loop` in the Newton/Picard sweeps of the oracle's `solve_nse`
+    (snu:1367-1384, 1461-1483 with `_get_mats_rhs_ts`, snu:1034-1040) pinned
+    by definition: every step of a sweep solves, with the matrices of ITS
+    linearisation point,
+        (M + dt/2 (A + N_n) - dt/2 B V_n) v_n - dt J^T p_n
+            = M v_c + dt/2 (f_n + f_c - (A + N_c) v_c) + dt/2 B V_c v_c
+    (the PLUS of snu:1040 kept) with `f = fv + rhsbc + rhs_con + B B^T w` (Newton)"""
+    kw, rec, _ = scenarios.build(variant='plain', seed=1, Nts=5, tE=0.025,
+                                 prob=toy_prob)
+    imex_oracle.cnab(**kw)
+    times, vels, _ = rec.arrays()
+    lin0 = {t: vels[k].reshape((-1, 1)) for k, t in enumerate(times)}
+    inv = toy_prob['invinds']
+    A, M, J = (toy_prob['smc'][k] for k in 'AMJ')
+    # (the scenario's matrices are condensed already: inner dofs only)
+    cm, ca, cj = M, A, J
+    NV = cm.shape[0]
+    rng = np.random.default_rng(3)
+    b_mat = sps.csr_matrix(1e-1*(cm @ rng.standard_normal((NV, 2))))
+    fbd = {None: dict(mtxtb=rng.standard_normal((NV, 2))/np.sqrt(NV),
+                      w=1e-1*rng.standard_normal((NV, 1)))}
+    skw = dict(A=A, M=M, J=J, fv=toy_prob['rhsd']['fv'],
+               fp=toy_prob['rhsd']['fp'],
+               iniv=kw['appndbcs'](kw['inivel'], []), inip=kw['inip'],
+               trange=kw['trange'], V=toy_prob['th'], invinds=inv,
+               dbcinds=toy_prob['dbcinds'], dbcvals=toy_prob['dbcvals'])
+    # ONE Newton sweep about `lin0`: the matrices of every step are known
+    vd, pd, hist = so.solve_nse(closed_loop=True, static_feedback=True,
+                                b_mat=b_mat, feedbackthroughdict=fbd,
+                                lin_vel_point=lin0, vel_pcrd_stps=0,
+                                vel_nwtn_stps=1, **skw)
+    assert [h[0] for h in hist] == ['newton']
+    B = np.asarray(b_mat.todense())
+    V = fbd[None]['mtxtb'].T
+    fb = b_mat @ (b_mat.T @ fbd[None]['w'])
+    cfv = skw['fv']
+    tr = kw['trange']
+    dt = tr[1] - tr[0]
+
+    def conv(vin, picard=False):
+        full = kw['appndbcs'](vin, []) if vin.shape[0] == NV else vin
+        return so.get_v_conv_conts(vvec=full, V=toy_prob['th'], invinds=inv,
+                                   dbcinds=[toy_prob['dbcinds'], []],
+                                   dbcvals=[toy_prob['dbcvals'], []],
+                                   Picard=picard)
+    worst = 0.
+    vc = kw['inivel']
+    for k in range(1, tr.size):
+        tn = tr[k]
+        N_c, rcon_c, rbc_c = conv(vc)
+        N_n, rcon_n, rbc_n = conv(lin0[tn])
+        vn, pn = vd[tn], pd[tn]
+        lhs = (cm + .5*dt*(ca + N_n)) @ vn - .5*dt*(B @ (V @ vn)) \
+            - dt*(cj.T @ pn)
+        rhs = cm @ vc + .5*dt*((cfv + rbc_n + rcon_n + fb)
+                               + (cfv + rbc_c + rcon_c + fb)
+                               - (ca + N_c) @ vc) + .5*dt*(B @ (V @ vc))
+        worst = max(worst, np.linalg.norm(lhs - rhs)/np.linalg.norm(cm @ vn))
+        assert np.linalg.norm(cj @ vn - skw['fp']) <= 1e-9*max(
+            1., np.linalg.norm(skw['fp']))
+        vc = vn
+    assert worst <= 1e-10, worst
