@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +60,26 @@ inline int guarded(Body body) noexcept {
         if (s__ != DNS_OK) return s__;                                       \
     } while (0)
 
+// DNS_DEBUG_UPLOADS=1: every copy between HOST memory and the device says
+// its host range [ptr, ptr + bytes) on stderr before it is enqueued, so that
+// the address of a "Memory access fault by GPU ... on address" report can be
+// tied to a buffer and an offset (round 4: a fault at a host heap address
+// whose record held no ranges)
+inline bool debug_uploads() {
+    static const bool on = [] {
+        const char *e = getenv("DNS_DEBUG_UPLOADS");
+        return e && e[0] != '0' && e[0] != 0;
+    }();
+    return on;
+}
+inline void log_host_copy(const char *what, const void *host, const void *dev,
+                          size_t bytes) {
+    if (!debug_uploads()) return;
+    fprintf(stderr, "[dns copy] %-10s host [%p, %p) dev %p bytes %zu\n", what,
+            host, (const void *)((const char *)host + bytes), dev, bytes);
+    fflush(stderr);
+}
+
 // device buffer with explicit lifetime (no exceptions across the C-ABI)
 template <typename T>
 struct DevBuf {
@@ -97,6 +118,7 @@ struct DevBuf {
     int upload_async(const T *host, size_t count, hipStream_t s) {
         if (count > n) return fail(DNS_ERR_BAD_ARGUMENT, "upload overflow");
         if (count == 0) return DNS_OK;
+        log_host_copy("upload", host, p, count * sizeof(T));
         DNS_HIP(hipMemcpyAsync(p, host, count * sizeof(T),
                                hipMemcpyHostToDevice, s));
         return DNS_OK;
@@ -104,6 +126,7 @@ struct DevBuf {
     int download(T *host, size_t count, hipStream_t s) const {
         if (count > n) return fail(DNS_ERR_BAD_ARGUMENT, "download overflow");
         if (count == 0) return DNS_OK;
+        log_host_copy("download", host, p, count * sizeof(T));
         DNS_HIP(hipMemcpyAsync(host, p, count * sizeof(T),
                                hipMemcpyDeviceToHost, s));
         return DNS_OK;
@@ -119,11 +142,37 @@ struct DevBuf {
 template <typename T>
 inline int upload_to(T *dev, const T *host, size_t count, hipStream_t s) {
     if (count == 0) return DNS_OK;
+    log_host_copy("upload_to", host, dev, count * sizeof(T));
     DNS_HIP(hipMemcpyAsync(dev, host, count * sizeof(T), hipMemcpyHostToDevice,
                            s));
     DNS_HIP(hipStreamSynchronize(s));
     return DNS_OK;
 }
+
+// page-locked host staging (hipHostMalloc): copies between it and the device
+// never pin or unpin caller memory
+template <typename T>
+struct PinnedBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { release(); }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int reserve(size_t count) {
+        if (count <= n) return DNS_OK;
+        release();
+        DNS_HIP(hipHostMalloc(reinterpret_cast<void **>(&p),
+                              count * sizeof(T), hipHostMallocDefault));
+        n = count;
+        return DNS_OK;
+    }
+};
 
 // synchronises the stream when the scope is left, whichever way: what makes a
 // group of `upload_async` calls from buffers of that scope safe

@@ -2226,30 +2226,44 @@ static int dns_saddle_solve_multi_impl(dns_saddle *h, int32_t ncols,
                  ld = h->ld, k = (size_t)ncols;
     if (h->mrhs.n < k * ld) DNS_TRY(h->mrhs.alloc(k * ld));
     if (h->msol.n < k * ld) DNS_TRY(h->msol.alloc(k * ld));
-    DNS_TRY(h->mrhs.zero(h->stream));
-    DNS_TRY(h->msol.zero(h->stream));
+    // The caller's blocks (pageable NumPy memory) never meet the DMA engine:
+    // they are packed into a page-locked staging buffer by the CPU and travel
+    // as ONE copy per direction.  Round 4 had a GPU memory fault inside this
+    // function at a page-aligned HOST heap address (profiles/r04_final/
+    // gpu_fault_solve_multi.txt); what this function did that no other upload
+    // of the library does is keep SEVERAL asynchronous copies out of pageable
+    // memory in flight at once -- first one pitched 2-D copy, then 3 k 1-D
+    // copies whose ranges share their boundary pages (a column is NV doubles,
+    // not a multiple of the page size).  The runtime pins pageable ranges in
+    // place page by page and unpins them when a copy retires: a page shared
+    // by a retired and a pending copy is the one mechanism that produces a
+    // fault at exactly such an address.  HYPOTHESIS (the record holds no
+    // ranges to prove it; DNS_DEBUG_UPLOADS=1 prints them from now on) --
+    // the staging removes every concurrent pin of caller memory either way.
+    log_host_copy("multi rhs_v", rhs_v, h->mrhs.p, k * nv * sizeof(double));
+    if (rhs_p)
+        log_host_copy("multi rhs_p", rhs_p, h->mrhs.p, k * np * sizeof(double));
+    if (x0_cols > 0)
+        log_host_copy("multi x0", x0, h->msol.p,
+                      (x0_cols > 1 ? k : 1) * n * sizeof(double));
+    log_host_copy("multi out", out_vp, h->msol.p, k * n * sizeof(double));
+    DNS_TRY(h->mstage.reserve(2 * k * ld));
     {
-        // the caller's blocks are borrowed for the whole call: the copies are
-        // only enqueued, ONE wait for all of them (on every way out).  Plain
-        // 1-D copies, column by column: a pitched hipMemcpy2DAsync out of
-        // pageable host memory faulted the GPU at a host heap address
-        // (intermittently, gpurun_out/r4_t: its blit reads past the rows it
-        // was given); the 1-D path is the one every other upload takes
-        SyncOnExit arrived(h->stream);
+        double *sr = h->mstage.p, *sx = h->mstage.p + k * ld;
+        memset(sr, 0, 2 * k * ld * sizeof(double));
         for (size_t c = 0; c < k; ++c) {
-            DNS_HIP(hipMemcpyAsync(h->mrhs.p + c * ld, rhs_v + c * nv,
-                                   nv * sizeof(double), hipMemcpyHostToDevice,
-                                   h->stream));
+            memcpy(sr + c * ld, rhs_v + c * nv, nv * sizeof(double));
             if (rhs_p && np > 0)
-                DNS_HIP(hipMemcpyAsync(h->mrhs.p + c * ld + nv, rhs_p + c * np,
-                                       np * sizeof(double),
-                                       hipMemcpyHostToDevice, h->stream));
+                memcpy(sr + c * ld + nv, rhs_p + c * np, np * sizeof(double));
             if (x0_cols > 0)
-                DNS_HIP(hipMemcpyAsync(h->msol.p + c * ld,
-                                       x0 + (x0_cols > 1 ? c * n : 0),
-                                       n * sizeof(double),
-                                       hipMemcpyHostToDevice, h->stream));
+                memcpy(sx + c * ld, x0 + (x0_cols > 1 ? c * n : 0),
+                       n * sizeof(double));
         }
+        SyncOnExit arrived(h->stream);
+        DNS_HIP(hipMemcpyAsync(h->mrhs.p, sr, k * ld * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream));
+        DNS_HIP(hipMemcpyAsync(h->msol.p, sx, k * ld * sizeof(double),
+                               hipMemcpyHostToDevice, h->stream));
     }
     h->col_history.assign(k, std::vector<double>());
     int worst = DNS_OK;
@@ -2261,13 +2275,11 @@ static int dns_saddle_solve_multi_impl(dns_saddle *h, int32_t ncols,
         h->col_history[c] = h->history;
         if (st->status != DNS_OK && worst == DNS_OK) worst = st->status;
     }
-    {
-        SyncOnExit arrived(h->stream);
-        for (size_t c = 0; c < k; ++c)
-            DNS_HIP(hipMemcpyAsync(out_vp + c * n, h->msol.p + c * ld,
-                                   n * sizeof(double), hipMemcpyDeviceToHost,
-                                   h->stream));
-    }
+    DNS_HIP(hipMemcpyAsync(h->mstage.p, h->msol.p, k * ld * sizeof(double),
+                           hipMemcpyDeviceToHost, h->stream));
+    DNS_HIP(hipStreamSynchronize(h->stream));
+    for (size_t c = 0; c < k; ++c)
+        memcpy(out_vp + c * n, h->mstage.p + c * ld, n * sizeof(double));
     (void)worst;       // (per-column statuses are in `stats`, like the single solve)
     return DNS_OK;
 }

@@ -383,6 +383,7 @@ struct dns_saddle {
     // blocks of right-hand sides / solutions of dns_saddle_solve_multi
     // (column c at c * ld) and the residual history of every column
     dns::DevBuf<double> mrhs, msol;
+    dns::PinnedBuf<double> mstage;    // host side of solve_multi's blocks
     std::vector<std::vector<double>> col_history;
     dns::DevBuf<double> scal;        // small scalar scratch
     dns::CtlHeader *hdr_host = nullptr;   // pinned

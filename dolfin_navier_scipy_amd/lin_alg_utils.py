@@ -22,7 +22,7 @@ import numpy as np
 import scipy.sparse as sps
 
 from . import _capi as C
-from .saddle import SaddleSystem, solve_opts
+from .saddle import SaddleSystem, solve_opts, choose_schur
 
 __all__ = ['solve_sadpnt_smw', 'app_prj_via_sadpnt', 'apply_massinv',
            'SpslaKrylovCounter', 'clear_cache', 'DEFAULTS']
@@ -134,9 +134,8 @@ def _canonical(mat):
 
 def _precond_kwargs(NP, krplsprms, NV=0):
     prm = dict(krplsprms or {})
+    # ('auto' is resolved when the system is created: `saddle.choose_schur`)
     schur = prm.get('schur', DEFAULTS['schur'])
-    if schur == 'auto':
-        schur = 'dense' if NP <= DEFAULTS['schur_dense_max'] else 'jacobi'
     deg = prm.get('cheb_degree', DEFAULTS['cheb_degree'])
     fact = prm.get('factorization', DEFAULTS['factorization'])
     if NV > 1000000 or not 2 <= deg <= 12:
@@ -153,14 +152,18 @@ def _get_system(amat, jmat, jmatT, krplsprms):
     prols = (krplsprms or {}).get('prolongations')
     key = _pattern_key(amat, jmat, jmatT, prols)
     pkw = _precond_kwargs(jmat.shape[0], krplsprms, NV=jmat.shape[1])
-    if prols is not None:           # nested pressure spaces: multigrid Schur
-        pkw['schur'] = 'mg'
     data = np.array(amat.data, dtype=np.float64, copy=True)
     ent = _cache.get(key)
+    if ent is not None:
+        pkw['schur'] = ent.pkw['schur']      # (chosen when it was created)
     if ent is None:
         system = SaddleSystem(amat, jmat, JT=jmatT, device=DEFAULTS['device'])
-        if prols is not None:
-            system.set_schur_mg(prols)
+        # dense inverse up to `schur_dense_max` pressure dofs, beyond it the
+        # multigrid block: on the caller's nested pressure spaces
+        # (`krplsprms['prolongations']`) or on an algebraic hierarchy
+        pkw['schur'] = choose_schur(system, amat, jmat, schur=pkw['schur'],
+                                    prolongations=prols,
+                                    dense_max=DEFAULTS['schur_dense_max'])
         system.setup_precond(**pkw)
         ent = _Entry(system, data, pkw)
         system._lau_entry = ent

@@ -21,7 +21,7 @@ import numpy as np
 import scipy.sparse as sps
 
 from . import _capi as C
-from .saddle import SaddleSystem, solve_opts
+from .saddle import SaddleSystem, solve_opts, choose_schur
 
 __all__ = ['TrapezoidalStepper', 'newton_picard', 'union_pattern',
            'values_in_pattern']
@@ -114,8 +114,10 @@ class TrapezoidalStepper(object):
         if comm is not None:
             pkw['fhat'] = 'explicit'       # (the partitioned solve needs it)
         pkw.update(precond or {})
-        if pkw['schur'] == 'auto':
-            pkw['schur'] = 'dense' if self.NP <= 6000 else 'jacobi'
+        pkw['schur'] = choose_schur(self.system, F0, self.J,
+                                    schur=pkw['schur'],
+                                    prolongations=pkw.pop('prolongations',
+                                                          None))
         self._pkw = dict(pkw)
         self.system.setup_precond(**pkw)
         conv.bind_pattern(self.pattern)

@@ -6,7 +6,7 @@ import scipy.sparse as sps
 
 from . import _capi as C
 
-__all__ = ['streaming_precond_defaults', 'SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
+__all__ = ['streaming_precond_defaults', 'choose_schur', 'SaddleSystem', 'ImexStepper', 'spmv', 'dot', 'axpy', 'gemv',
            'dense_inverse', 'spmv_bench', 'spmv_pair', 'solve_opts', 'precond_opts']
 
 _METHODS = {'gmres': C.DNS_METHOD_GMRES, 'bicgstab': C.DNS_METHOD_BICGSTAB}
@@ -326,6 +326,8 @@ class ImexStepper(object):
             C.check(self.lib.dns_imex_create(system._h, self._r1.byref(),
                                              ct.byref(self._h)))
         self.last_stats = None
+        # time steps and Krylov steps since the stepper exists
+        self.total_steps, self.total_iters = 0, 0
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -401,6 +403,8 @@ class ImexStepper(object):
         C.check(self.lib.dns_imex_step(self._h, C.dptr(nf), ct.byref(cf),
                                        ct.byref(o), ct.byref(st)))
         self.last_stats = st.asdict()
+        self.total_steps += 1
+        self.total_iters += int(st.iters)
         if raise_on_fail and st.status != C.DNS_OK:
             raise C.NotConverged(st.status, 'time step solve failed: '
                                  '{0}'.format(self.last_stats))
@@ -424,6 +428,8 @@ class ImexStepper(object):
         if status != C.DNS_NOT_CONVERGED:
             C.check(status)
         self.last_stats = st.asdict()
+        self.total_steps += int(nsteps)
+        self.total_iters += int(its.value)
         vals = [ct.c_int32(0) for _ in range(4)]
         C.check(self.lib.dns_imex_run_info(self._h,
                                            *[ct.byref(v) for v in vals]))
@@ -450,6 +456,38 @@ class ImexStepper(object):
         out = ct.c_double(0.)
         C.check(self.lib.dns_imex_vnorm(self._h, ct.byref(out)))
         return out.value
+
+
+def choose_schur(system, F, J, schur='auto', prolongations=None,
+                 dense_max=6000):
+    """the Schur block of a drop-in's system: `'auto'` = the dense inverse up
+    to `dense_max` pressure dofs, beyond it the multigrid block -- on the
+    caller's nested pressure spaces (`prolongations`) or, for a mesh that
+    comes with none, on a hierarchy built from `F` and `J` alone
+    (`amg.algebraic_prolongations`; `'amg'` asks for it by name).  Returns
+    the `schur=` keyword for `setup_precond` (the prolongations are attached
+    here); what was built is left in `system.schur_hierarchy`."""
+    NP = J.shape[0]
+    system.schur_hierarchy = None
+    if prolongations is not None and schur in ('auto', 'mg'):
+        system.set_schur_mg(prolongations)
+        system.schur_hierarchy = dict(kind='geometric',
+                                      levels=[NP] + [P.shape[1]
+                                                     for P in prolongations])
+        return 'mg'
+    if schur == 'auto' and NP <= dense_max:
+        return 'dense'
+    if schur in ('auto', 'amg'):
+        from . import amg
+        info = dict(kind='algebraic')
+        prols = amg.algebraic_prolongations(F, J, info=info,
+                                            coarsest=min(1500, dense_max))
+        if not prols:
+            return 'dense' if NP <= 4*dense_max else 'jacobi'
+        system.set_schur_mg(prols)
+        system.schur_hierarchy = info
+        return 'mg'
+    return schur
 
 
 def streaming_precond_defaults(n):

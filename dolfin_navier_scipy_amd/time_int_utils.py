@@ -22,7 +22,7 @@ import numpy as np
 import scipy.sparse as sps
 
 from . import lin_alg_utils as lau
-from .saddle import SaddleSystem, ImexStepper, solve_opts
+from .saddle import SaddleSystem, ImexStepper, solve_opts, choose_schur
 
 __all__ = ['cnab', 'sbdftwo', 'semi_implicit_euler', 'SOLVER']
 
@@ -35,6 +35,24 @@ SOLVER = dict(method='gmres', rtol=None, maxiter=400, restart=60,
               cheb_degree=6, drop_tol=1e-3, factorization='full', reorth=2,
               schur='auto', extrapolate='auto', device=0, check_every=2,
               use_graph=True, carry_residual=True)
+
+
+# record of the last time loop that ran (diagnostics / tests): which Schur
+# block its system got, the algebraic or geometric hierarchy behind it, time
+# steps and Krylov steps of the loop
+LAST_RUN = {}
+
+
+def _record_run(name, system, stepper):
+    LAST_RUN.clear()
+    try:        # (runs in a `finally`: never in the way of the real error)
+        LAST_RUN.update(
+            integrator=name, time_steps=stepper.total_steps,
+            krylov_steps=stepper.total_iters,
+            schur_hierarchy=getattr(system, 'schur_hierarchy', None),
+            precond=system.precond_info())
+    except Exception:
+        pass
 
 
 def _checkuniformgrid(trange):
@@ -86,14 +104,13 @@ def _solver_settings(solver):
 
 def _device_system(fmat, J, prm):
     NP = J.shape[0]
-    schur = prm['schur']
-    if schur == 'auto':
-        schur = 'dense' if NP <= lau.DEFAULTS['schur_dense_max'] else 'jacobi'
     system = SaddleSystem(fmat, J, device=prm['device'])
-    if prm.get('prolongations') is not None:
-        # nested pressure spaces given: multigrid Schur block (refined meshes)
-        system.set_schur_mg(prm['prolongations'])
-        schur = 'mg'
+    # dense inverse up to `schur_dense_max` pressure dofs; beyond it the
+    # multigrid block, on nested pressure spaces if the caller has them
+    # (`prolongations`: refined meshes), else on an algebraic hierarchy
+    schur = choose_schur(system, fmat, J, schur=prm['schur'],
+                         prolongations=prm.get('prolongations'),
+                         dense_max=lau.DEFAULTS['schur_dense_max'])
     if prm['extrapolate'] == 'auto':
         # warm start: quartic where one Krylov step per time step does it
         # (dense Schur block); cubic with the multigrid block, whose solves
@@ -287,6 +304,7 @@ def cnab(trange=None, inivel=None, inip=None, bcs_ini=[],
                 v_n, p_n = stepper.get_state()
                 savevp(appndbcs(v_n, bcs_n), p_n, time=ctime)
     finally:
+        _record_run('cnab', system, stepper)
         stepper.close()
         system.close()
     return v_n, p_n, ffflag
@@ -416,6 +434,7 @@ def sbdftwo(trange=None, inivel=None, inip=None, bcs_ini=[],
                 v_n, p_n = stepper.get_state()
                 savevp(appndbcs(v_n, bcs_n), p_n, time=ctime)
     finally:
+        _record_run('sbdftwo', system, stepper)
         stepper.close()
         system.close()
     return v_n, p_n, ffflag
@@ -471,6 +490,7 @@ def semi_implicit_euler(iniv=None, jmat=None, mmat=None, amat=None, rhsv=None,
                 out.append(cv)
                 record.pop(0)
     finally:
+        _record_run('semi_implicit_euler', system, stepper)
         stepper.close()
         system.close()
     return out

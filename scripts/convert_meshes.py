@@ -6,7 +6,8 @@ Run once in the build container (the reference tree does not exist on the GPU
 box):  python scripts/convert_meshes.py
 
 Source data: `/root/reference/tests/mesh/cylinder_{0,1,2,3}.xml`,
-`2D-double-rotcyl_lvl{1,2}.xml.gz`, `karman2D-{rotcyl,outlets}_lvl1.xml.gz` and the
+`2D-double-rotcyl_lvl{1,2}.xml.gz`, `karman2D-{rotcyl,outlets}_lvl1.xml.gz`,
+`karman2D-rotcyl_lvl{3,4}.xml.gz` and the
 `*_geo_cntrlbc*.json` geometry descriptions next to them
 (data files the reference's own drivers load, `problem_setups.py:476-478`,
 `tests/time_dep_nse_double_rotcyl_bcrob.py:7,16-18`).  Output: vertex
@@ -42,7 +43,12 @@ if __name__ == '__main__':
         print(out, mesh.nverts, mesh.ncells)
     # the meshes of the reference's known-answer tests (test_units_residuals.py:
     # 17-26, tdp_convcheck.py:85-95)
-    for name in ('karman2D-rotcyl_lvl1', 'karman2D-outlets_lvl1'):
+    # ... and the finer levels of the rotating-cylinder mesh (lvl4: NV = 133 334,
+    # NP = 17 135): pressure spaces beyond the dense Schur block that are NOT
+    # refinements of anything this repository built -- the algebraic
+    # coarsening of the multigrid Schur block is tested on them
+    for name in ('karman2D-rotcyl_lvl1', 'karman2D-outlets_lvl1',
+                 'karman2D-rotcyl_lvl3', 'karman2D-rotcyl_lvl4'):
         mesh = read_dolfin_xml(os.path.join(REFMESH, name + '.xml.gz'))
         out = os.path.join(DATA, 'mesh_{0}.npz'.format(name))
         save_npz_mesh(out, mesh)
