@@ -222,6 +222,9 @@ SIGNATURES = {
     'dns_trap_get_state': (ct.c_int, [ct.c_void_p, c_double_p, c_double_p]),
     'dns_trap_update_norm': (ct.c_int, [ct.c_void_p, c_double_p]),
     'dns_trap_set_pipeline': (ct.c_int, [ct.c_void_p, ct.c_int32]),
+    'dns_trap_set_oversolve': (ct.c_int, [ct.c_void_p, ct.c_double]),
+    'dns_trap_poll_ext': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32),
+                                     ct.POINTER(ct.c_double)]),
     'dns_trap_poll': (ct.c_int, [ct.c_void_p, ct.POINTER(ct.c_int32),
                                  ct.POINTER(ct.c_int32),
                                  ct.POINTER(ct.c_int32),

@@ -738,6 +738,7 @@ int dns_saddle::mg_prepare(int n0) {
     // two sweeps each way: the cycle runs on fused operators (9 launches for
     // three levels instead of 16); DNS_MG_FUSED=0 keeps the plain cycle
     mg_fused = mg_nu == 2 && mg_fused_knob;
+    mg_fused11 = mg_nu == 1 && mg_fused_knob && !comm && mg_cycles < 2;
     mg_rows_parts = 0;
     return DNS_OK;
 }
@@ -808,6 +809,43 @@ int dns_saddle::build_mg_levels(int l0, HostCsr Sl) {
         DNS_TRY(lv.dinv.upload(dv.data(), dv.size(), stream));
         DNS_HIP(hipStreamSynchronize(stream));
         const HostCsr SP = host_spgemm(Sl, P);
+        if (mg_fused11) {
+            // (solver.hpp, mg_fused11) one sweep each way, w = 4 / (3 lmax)
+            lv.omega = lv.omega2 = 4.0 / (3.0 * std::max(
+                                              1e-300, host_jacobi_lmax(Sl)));
+            std::vector<double> wd((size_t)lv.n);
+            for (int i = 0; i < lv.n; ++i) wd[i] = lv.omega * dv[i];
+            const HostCsr I = host_diag(std::vector<double>((size_t)lv.n, 1.0));
+            HostCsr WS = Sl;
+            host_scale_rows(wd, WS);                       // w D^-1 S
+            // (I + T) w D^-1 = (2 I - w D^-1 S) w D^-1
+            HostCsr Ap = host_add(2.0, I, -1.0, WS);
+            for (size_t k = 0; k < Ap.vals.size(); ++k)
+                Ap.vals[k] *= wd[Ap.colidx[k]];
+            // Rd = P^T - (P^T S) w D^-1
+            HostCsr PTSw = host_spgemm(PT, Sl);
+            for (size_t k = 0; k < PTSw.vals.size(); ++k)
+                PTSw.vals[k] *= wd[PTSw.colidx[k]];
+            const HostCsr Rd = host_add(1.0, PT, -1.0, PTSw);
+            HostCsr WSP = SP;
+            host_scale_rows(wd, WSP);
+            HostCsr U = host_hstack(Ap, host_add(1.0, P, -1.0, WSP));
+            if (l == 0)                                    // zp = -x
+                for (double &v : U.vals) v = -v;
+            dns_csr rv = Rd.view(), qv = U.view();
+            DNS_TRY(lv.Rr.upload(&rv, stream));
+            DNS_TRY(lv.Qq.upload(&qv, stream));
+            if (fp32_store)
+                for (CsrDev *op : {&lv.Rr, &lv.Qq})
+                    if (streams(*op))
+                        DNS_TRY(to_f32(op->vals.p, op->vals32,
+                                       (size_t)op->nnz + 2));
+            DNS_HIP(hipStreamSynchronize(stream));
+            lv.nnz_P = lv.P.nnz;
+            lv.nnz_S = lv.S.nnz;
+            lv.P.release_all();
+            lv.PT.release_all();
+        }
         if (mg_fused) {
             // the operators of the fused cycle (solver.hpp, MgLevel)
             // first sweep of a pair with w1 = omega, second with w2 = omega2:
@@ -867,6 +905,8 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
                                const int *guard) {
     const int L = (int)mg.size();
     if (mg_fused && L > 1) return schur_mg_apply_fused(in, zp, xacc, guard);
+    if (mg_fused11 && L > 1 && !dist())
+        return mg_cycle_fused11(in, zp, xacc, guard);
     // sweeps ping-pong between lv.x and lv.x2; returns where the result is
     auto smooth = [&](MgLevel &lv, const double *b, bool from_zero,
                       double *cur) -> double * {
@@ -1045,6 +1085,47 @@ int dns_saddle::mg_cycle_fused(const double *in, double *zp, double *xacc,
                                    lv.omega2, b, lv.x2.p, out, guard, osc,
                                    (l == 0) ? xacc : (double *)nullptr));
         }
+    }
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
+// the V(1,1) cycle on two fused operators per level (solver.hpp, mg_fused11):
+// zp = -V(in), xacc += zp
+int dns_saddle::mg_cycle_fused11(const double *in, double *zp, double *xacc,
+                                 const int *guard) {
+    const int L = (int)mg.size();
+    for (int l = 0; l + 1 < L; ++l) {
+        MgLevel &lv = mg[l];
+        const double *b = (l == 0) ? in : lv.b.p;
+        DNS_TRY(mg_op(lv.Rr, b, lv.n, nullptr, nullptr, nullptr,
+                      mg[l + 1].b.p, guard));
+    }
+    {
+        MgLevel &lc = mg[L - 1];
+        const DnsCtl *gctl = (guard && guard == done_ptr())
+                                 ? (const DnsCtl *)ctl.p
+                                 : (const DnsCtl *)nullptr;
+        const int gg = std::max(1, std::min((lc.n + 3) / 4, 2048));
+        if (fp32_store && mg_cinv32.p)
+            hipLaunchKernelGGL(k_gemv_rows<float>, gg, kBlock, 0, stream, lc.n,
+                               mg_cinv32.p, lc.b.p, lc.x.p, 1.0, gctl);
+        else
+            hipLaunchKernelGGL(k_gemv_rows<double>, gg, kBlock, 0, stream, lc.n,
+                               mg_cinv.p, lc.b.p, lc.x.p, 1.0, gctl);
+    }
+    for (int l = L - 2; l >= 0; --l) {
+        MgLevel &lv = mg[l];
+        const double *b = (l == 0) ? in : lv.b.p;
+        DNS_TRY(mg_op(lv.Qq, b, lv.n, mg[l + 1].x.p, nullptr, nullptr,
+                      (l == 0) ? zp : lv.x.p, guard));
+    }
+    if (xacc) {
+        if (guard)
+            return fail(DNS_ERR_BAD_ARGUMENT,
+                        "fused V(1,1) cycle: no guarded accumulate");
+        hipLaunchKernelGGL(k_axpby, grid_for_elems(np), kBlock, 0, stream,
+                           (int64_t)np, 1.0, zp, 1.0, xacc);
     }
     DNS_HIP(hipGetLastError());
     return DNS_OK;

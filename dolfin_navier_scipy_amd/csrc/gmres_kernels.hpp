@@ -654,6 +654,7 @@ k_orth(int n, const double *__restrict__ V, size_t ld, double *__restrict__ w,
 __device__ __forceinline__ void acc_need_prev(DnsCtl *ctl, int need,
                                               double prev_res) {
     if (need > ctl->acc_maxneed) ctl->acc_maxneed = need;
+    ctl->acc_sumneed += need;
     if (ctl->tol > 0.0) {
         const double rel = prev_res / ctl->tol;
         if (rel > ctl->acc_maxprev) ctl->acc_maxprev = rel;

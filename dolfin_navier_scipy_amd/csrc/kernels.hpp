@@ -44,6 +44,7 @@ struct DnsCtl {
     // the largest residual / tolerance in front of the last column.
     double stop_frac, acc_maxprev;
     int acc_maxneed, need_it;
+    int acc_sumneed, acc_pad;    // sum of the columns the solves needed
     double hcol[kMaxRestart + 1];
     double cs[kMaxRestart], sn[kMaxRestart], g[kMaxRestart + 1];
     double y[kMaxRestart];

@@ -314,6 +314,7 @@ struct CtlHeaderAcc {   // header + the batch accumulators behind it
     double acc_maxrel;
     double stop_frac, acc_maxprev;
     int acc_maxneed, need_it;
+    int acc_sumneed, acc_pad;
 };
 
 // a captured chunk of work, replayed with hipGraphLaunch
@@ -505,6 +506,15 @@ struct dns_saddle {
     int prologue_nparts = 0;          // > 0: partials of ||r||^2, ||b||^2 the
                                       // caller's prologue kernel has written
     bool mg_fused = false;            // the V-cycle runs on the fused operators
+    // V(1,1) on TWO fused operators per level (one GPU): down b_c = Rd b with
+    // Rd = P^T (I - w S D^-1), up x = U [b; e] with U = [(I + T) w D^-1, T P]
+    // -- 2 (L - 1) + 1 launches instead of the 4 (L - 1) + 1 of the fused
+    // V(2,2).  A weaker cycle per launch saved: pays where the cycle is
+    // launch bound and the solves run a fixed number of columns anyway
+    // (oversolve); `smooth_steps = 1` of dns_saddle_set_schur_mg asks for it
+    bool mg_fused11 = false;
+    int mg_cycle_fused11(const double *in, double *zp, double *xacc,
+                         const int *guard);
     bool mg_fused_knob = true;        // DNS_MG_FUSED (read once, at create)
     int mg_part_min = 100000;         // levels with at least this many rows are
                                       // row-partitioned over the ranks

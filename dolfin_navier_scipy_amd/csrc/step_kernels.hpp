@@ -759,6 +759,7 @@ k_batch_begin(CopyList cl, DnsCtl *ctl, double stop_frac) {
         ctl->acc_maxrel = 0.0;
         ctl->acc_maxprev = 0.0;
         ctl->acc_maxneed = 0;
+        ctl->acc_sumneed = 0;
         ctl->stop_frac = stop_frac;
     }
 }

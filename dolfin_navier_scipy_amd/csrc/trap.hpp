@@ -145,6 +145,9 @@ struct dns_trap {
     static constexpr int kUpdSlots = 128;
     int flush_updnorm();
     int pipeline_c = 0;                        // > 0: steps do not synchronise
+    // oversolve (DnsCtl::stop_frac) of the pipelined batches: > 0 = the
+    // solves run their cycle's columns down to this fraction of the tolerance
+    double over_frac = 0.0;
     double last_dt = 0.0;
     // time-dependent data of the sweeps, one row per trajectory slot (= time
     // instance): f_v(t) (forcing + controlled-boundary stiffness terms,

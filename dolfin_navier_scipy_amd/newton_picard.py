@@ -16,6 +16,8 @@ matrix sums and one saddle-point solve per time step:
 Host code only drives the loop (`TrapezoidalStepper.sweep`, `newton_picard`).
 """
 import ctypes as ct
+import os
+import sys
 
 import numpy as np
 import scipy.sparse as sps
@@ -69,7 +71,7 @@ class TrapezoidalStepper(object):
 
     def __init__(self, M, A, J, conv, nslots, dt, device=0, precond=None,
                  JT=None, comm=None, precond_linpoint=None, refresh_iters=3.0,
-                 batch=64):
+                 batch=64, oversolve=1e-3):
         """`comm` (a `comm.Comm`): the saddle solves of the sweeps run
         row-partitioned over its ranks, and so does the
         assembly: a rank evaluates the cells that touch its rows and forms
@@ -84,7 +86,10 @@ class TrapezoidalStepper(object):
         `refresh_iters`: bound on the Krylov steps per time step of a batch of
         `batch` steps beyond which `sweep` rebuilds the preconditioner about
         the current operator (`None` / 0: never, the set-up of the start is
-        kept)"""
+        kept).  `oversolve`: the solves of a pipelined batch run the columns
+        of their cycle down to this fraction of the tolerance instead of
+        stopping at it (`set_oversolve`; 0: stop at the tolerance, with a
+        slack column per cycle as until round 4)"""
         self.lib = C.load_library()
         self.refresh_iters = refresh_iters
         self.batch = int(batch)
@@ -127,6 +132,8 @@ class TrapezoidalStepper(object):
             self.system._h, conv._h, C.dptr(self.mvals), C.dptr(self.avals),
             self.nslots, ct.byref(self._h)))
         self.last_stats = None
+        self._over = False
+        self.set_oversolve(oversolve or 0.0)
 
     def close(self):
         if getattr(self, '_h', None) is not None and self._h:
@@ -257,10 +264,23 @@ class TrapezoidalStepper(object):
         C.check(self.lib.dns_trap_set_pipeline(self._h, int(cycle_len)))
 
     def poll(self):
-        vals = [ct.c_int32(0) for _ in range(4)]
-        C.check(self.lib.dns_trap_poll(self._h, *[ct.byref(v) for v in vals]))
-        return dict(zip(('solves', 'fails', 'iters', 'maxit'),
-                        [v.value for v in vals]))
+        """counters of the pipelined batch since `set_pipeline` / the last
+        poll (`dns_trap_poll_ext`): solves, failures, Krylov steps, the
+        longest solve, the most columns a solve NEEDED to meet the tolerance,
+        the batch maxima of final residual / tolerance and of the residual in
+        front of the last column / tolerance"""
+        iv, dv = (ct.c_int32*6)(), (ct.c_double*2)()
+        C.check(self.lib.dns_trap_poll_ext(self._h, iv, dv))
+        return dict(solves=iv[0], fails=iv[1], iters=iv[2], maxit=iv[3],
+                    maxneed=iv[4], sumneed=iv[5], maxrel=dv[0],
+                    maxprev=dv[1])
+
+    def set_oversolve(self, stop_frac):
+        """`stop_frac > 0`: the solves of a pipelined batch run the columns of
+        their cycle (down to `stop_frac` x tolerance) instead of stopping at
+        the tolerance -- `dns_trap_set_oversolve`; 0 switches it off"""
+        C.check(self.lib.dns_trap_set_oversolve(self._h, float(stop_frac)))
+        self._over = float(stop_frac) > 0.0
 
     def update_norm(self):
         out = ct.c_double(0.)
@@ -383,12 +403,26 @@ class TrapezoidalStepper(object):
         # solutions for the quartic one: the steps before need more Krylov
         # steps than the run will, and a first batch sized by them fails)
         k = min(nt, 7) if pipelined else 1
+        over = pipelined and getattr(self, '_over', False)
+        hints = self.__dict__.setdefault('_cycle_hint', {})
+        learning = False
         if pipelined:
             its, worst = sync_steps(1, k)
             tot['iters'] += its
-            cycle = max(2, worst + 1)
+            cycle = max(1, worst) if over else max(2, worst + 1)
+            if over and newton in hints:
+                # what the last sweep of this kind settled at (sweeps repeat
+                # themselves: Picard, then Newton after Newton over the same
+                # range); the first steps above only bound it from above
+                cycle = min(cycle, hints[newton])
+            learning = over and newton not in hints
+        hold, backoff, lowered = 0, 2, False
         while k < nt:
             kend = min(nt, k + batch)
+            if lowered or learning:
+                # a trial batch -- and the first batches of a stepper that
+                # does not know its cycle length yet -- are short
+                kend = min(nt, k + min(batch, 16))
             if not pipelined:
                 its, _ = sync_steps(k, kend)
             else:
@@ -398,18 +432,60 @@ class TrapezoidalStepper(object):
                     one(kk)
                 acc = self.poll()
                 self.set_pipeline(0)
-                if acc['fails'] == 0:
+                if os.environ.get('DNS_DEBUG'):
+                    print('[sweep] steps {0}..{1} cycle {2}: {3}'.format(
+                        k, kend, cycle, acc), file=sys.stderr)
+                if acc['fails'] == 0 and not over:
                     its, cycle = acc['iters'], max(2, acc['maxit'] + 1)
+                elif acc['fails'] == 0:
+                    # oversolve (as `dns_imex_run`, imex_capi.inc): every solve
+                    # ran the `cycle` columns of the replayed graph.  The
+                    # cycle grows when the batch ended close to the tolerance,
+                    # shrinks to what was run when every solve reached the
+                    # floor earlier, and is TRIED one column shorter (on a
+                    # short batch) when every solve stood a decade below the
+                    # tolerance in front of its last column
+                    its = acc['iters']
+                    was = cycle
+                    if acc['maxrel'] > 0.5:
+                        cycle = was + 1
+                        if lowered:
+                            backoff = min(4096, 4*backoff)
+                        hold = backoff
+                    elif acc['maxit'] < was:
+                        cycle = max(1, acc['maxit'])
+                    elif was > 1 and hold == 0 and (
+                            0. < acc['maxprev'] < 0.1
+                            or (learning and acc['maxneed'] < was
+                                and acc['maxprev'] < 0.5)):
+                        cycle = was - 1
+                    lowered = cycle < was and acc['maxit'] >= was
+                    hold = max(0, hold - 1)
+                    learning = learning and cycle != was
                 else:
                     # a step of this batch was not through after `cycle` Krylov
                     # steps: the batch again, every step run to convergence
                     self.restore(newton)
                     its, worst = sync_steps(k, kend)
-                    cycle = max(2, worst + 1)
+                    if over:
+                        cycle = max(cycle + 1, worst)
+                        if lowered:
+                            backoff = min(4096, 4*backoff)
+                        hold, lowered = max(backoff, 4), False
+                    else:
+                        cycle = max(2, worst + 1)
                     tot['replayed_batches'] += 1
             tot['iters'] += its
-            policy(its/float(kend - k), kend)
+            # (oversolve: what the refresh policy goes by is the columns a
+            # solve NEEDED, not the columns the cycle ran)
+            per = its/float(kend - k)
+            if over and pipelined and acc['fails'] == 0:
+                per = min(per, acc['sumneed']/float(max(1, acc['solves'])))
+            policy(per, kend)
             k = kend
+        if over and nt > 2*batch:
+            hints[newton] = cycle      # (a real sweep, not a warm-up pass)
+        tot['cycle'] = cycle if pipelined else None
         return vdict, pdict, self.update_norm(), tot
 
 

@@ -631,6 +631,18 @@ int dns_trap_step_fb(dns_trap *t, double dt, int32_t lin_which,
 int dns_trap_set_pipeline(dns_trap *t, int32_t cycle_len);
 int dns_trap_poll(dns_trap *t, int32_t *solves, int32_t *fails, int32_t *iters,
                   int32_t *maxit);
+/* Oversolve of the pipelined batches: with stop_frac > 0 a solve does not stop
+ * at the tolerance but runs the columns of its cycle (the nodes of a replayed
+ * cycle are paid for either way) until its residual is below stop_frac x
+ * tolerance; 0 (default) = stop at the tolerance.  dns_trap_poll_ext: the
+ * counters of dns_trap_poll in out6[0..3], out6[4] = the largest number of
+ * columns a solve NEEDED to meet the tolerance, out6[5] = the sum of those
+ * numbers over the batch's solves, out2[0] = batch maximum of
+ * final residual / tolerance, out2[1] = ... of the residual in front of the
+ * last column / tolerance: what the host's choice of the next cycle length
+ * goes by. */
+int dns_trap_set_oversolve(dns_trap *t, double stop_frac);
+int dns_trap_poll_ext(dns_trap *t, int32_t *out6, double *out2);
 /* checkpoint / restore of the stepper's state between pipelined batches: a
  * batch in which a step did not converge within the agreed cycle length is
  * repeated from the checkpoint (call `dns_trap_checkpoint` behind a

@@ -206,3 +206,51 @@ def test_run_child_keeps_the_last_record_of_a_killed_child():
                           True)
     assert 'killed' in res['error']
     assert res['partial'] == {'stage': 'entering allreduce_graph'}
+
+
+def test_the_printed_line_stays_under_the_drivers_record(tmp_path):
+    """the driver keeps an 8 KB tail of the line: the published op lists and
+    the long explanations go to a side file, secondary records keep their
+    figures of merit, what the bench contract names stays"""
+    ops = [dict(op='SpMV {0}'.format(i), count=1.5, bytes=123456789.123)
+           for i in range(40)]
+    big = dict(steps_per_s=1234.56789123, krylov_iters_per_step=2.0,
+               parity=dict(v_rel_Mnorm=1.23456789e-10, ok=True),
+               what='x'*900, roofline_step=dict(frac=0.5, ops=list(ops)),
+               padding={str(i): 0.123456789123*i for i in range(400)})
+    out = dict(metric='timesteps/sec', value=27796.437291, unit='timesteps/s',
+               config=dict(workload='w'*200, parallelism='single',
+                           row_partitioned=dict(big),
+                           weak_scaling_bandwidth_base=dict(big),
+                           newton_picard_sweeps=dict(
+                               picard=dict(steps_per_s=11000.123456)),
+                           refined_mesh=dict(gpu_steps_per_s=4200.987654321)),
+               roofline=dict(bound='hbm', achieved=6480.123456789, peak=8000.,
+                             frac=0.810015432, kernel='k'*150,
+                             step=dict(frac=0.14, ops=list(ops))),
+               cpu_baseline=dict(value=394.123, cores=1, kind='port',
+                                 sample='s'*170))
+    assert len(json.dumps(out)) > 2*bench.LINE_LIMIT
+    side = str(tmp_path / 'ops.json')
+    line, moved = bench.compact_line(out, side=[side])
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT
+    assert line['config']['workload'] == 'w'*200
+    assert line['cpu_baseline']['sample'] == 's'*170
+    assert line['roofline']['kernel'] == 'k'*150
+    assert line['roofline']['frac'] == 0.810015
+    assert line['value'] == 27796.4
+    assert line['roofline']['step']['ops'].startswith('profiles/bench_ops')
+    rp = line['config']['row_partitioned']
+    assert rp['steps_per_s'] == 1234.57 and rp['parity']['ok'] is True
+    assert line['config']['newton_picard_sweeps']['picard']['steps_per_s'] \
+        == 11000.1
+    with open(side) as fh:
+        kept = json.load(fh)
+    assert kept['roofline.step.ops'][3]['op'] == 'SpMV 3'
+    assert any(k.endswith('.what') for k in kept)      # (long strings)
+    # (secondary records beyond the limit keep their figures of merit only)
+    assert 'config.row_partitioned' in kept and 'padding' not in rp
+    # a line that is short already is left alone (but for the rounding)
+    small, moved2 = bench.compact_line(dict(value=1.0, config=dict(a='b')),
+                                       side=[side])
+    assert small == dict(value=1.0, config=dict(a='b')) and not moved2
