@@ -152,7 +152,8 @@ def compact_line(out, limit=LINE_LIMIT, side=None):
             for key, val in node.items():
                 sub = path + '.' + key if path else key
                 if isinstance(val, str) and len(val) > 120 \
-                        and key not in ('metric',):
+                        and key not in ('metric', 'error', 'stage') \
+                        and 'rccl_selftest' not in sub:
                     acc.append((len(val), sub, node, key))
                 else:
                     strings(val, sub, acc)

@@ -536,8 +536,15 @@ struct dns_saddle {
     bool oversolve = false;
     int oversolve_env = -1;           // DNS_OVERSOLVE: -1 unset
     double oversolve_frac = 1e-3;     // raise `done` at this fraction of tol
-    double oversolve_raise = 0.5;     // batch max of final res / tol: c + 1
-    double oversolve_lower = 0.1;     // ... in front of the last column: c - 1
+    // (thresholds from the refined wake: a cycle one column shorter ends
+    // where the longer one stood in front of its last column, and what the
+    // next warm starts make of the larger residuals adds a factor 1.5-2.
+    // The two-column cycle of the bandwidth regime sits at 0.05-0.35 on one
+    // GPU and at 0.3-0.8 through the partitioned code path: with the bound
+    // at 0.7 that path ran three columns, 1322 instead of 1857 steps/s at
+    // n = 693k)
+    double oversolve_raise = 0.9;     // batch max of final res / tol: c + 1
+    double oversolve_lower = 0.25;    // ... in front of the last column: c - 1
     int set_stop_frac(double f);
     bool capturing = false;           // a run_cached capture is open
     // multigrid Schur block (DNS_SCHUR_MG): level 0 = the pressure space

@@ -192,11 +192,31 @@ def default_rtol(amat):
     return DEFAULTS['direct_tol']
 
 
-def _solver_opts(krylov, krpslvprms, amat=None):
+# what the last `solve_sadpnt_smw` ran with (diagnostics / parity tests: the
+# tolerance that stood in for the direct solve, and how it was chosen)
+LAST_SOLVE = {}
+
+
+def _solver_opts(krylov, krpslvprms, amat=None, krplsprms=None):
     prm = krpslvprms if isinstance(krpslvprms, dict) else {}
+    lprm = krplsprms if isinstance(krplsprms, dict) else {}
     if krylov is None:
         method = 'gmres'
-        tol = DEFAULTS['direct_tol'] if amat is None else default_rtol(amat)
+        # the caller knows whether it penalised rows (Robin control: `A +
+        # Arob/alpha`): `krplsprms['penalised']` (True / False) or an explicit
+        # `krplsprms['direct_tol']` decide; the look at the diagonal
+        # (`default_rtol`) is the fallback for callers that say nothing
+        if 'direct_tol' in lprm:
+            tol, how = float(lprm['direct_tol']), 'direct_tol given'
+        elif 'penalised' in lprm:
+            tol = DEFAULTS['direct_tol_penalised'] if lprm['penalised'] \
+                else DEFAULTS['direct_tol']
+            how = 'penalised={0} given'.format(bool(lprm['penalised']))
+        elif amat is None:
+            tol, how = DEFAULTS['direct_tol'], 'default'
+        else:
+            tol, how = default_rtol(amat), 'diagonal heuristic'
+        LAST_SOLVE.update(rtol=tol, rtol_chosen_by=how)
     else:
         kname = str(krylov).lower()
         if kname in ('gmres', 'bicgstab'):
@@ -206,6 +226,7 @@ def _solver_opts(krylov, krpslvprms, amat=None):
         else:
             raise ValueError('unknown Krylov method `{0}`'.format(krylov))
         tol = prm.get('tol', 1e-8)
+        LAST_SOLVE.update(rtol=tol, rtol_chosen_by="krpslvprms['tol']")
     return solve_opts(method=method, rtol=tol,
                       maxiter=prm.get('maxiter', DEFAULTS['maxiter']),
                       restart=prm.get('restart', DEFAULTS['restart']))
@@ -251,7 +272,7 @@ def solve_sadpnt_smw(amat=None, jmat=None, rhsv=None, jmatT=None, rhsp=None,
     rhsp = np.zeros((NP, ncols)) if rhsp is None else \
         np.asarray(rhsp, dtype=np.float64).reshape((NP, -1))
     system = _get_system(amat, jmat, jmatT, krplsprms)
-    opts = _solver_opts(krylov, krpslvprms, amat)
+    opts = _solver_opts(krylov, krpslvprms, amat, krplsprms)
     prm = krpslvprms if isinstance(krpslvprms, dict) else {}
     x0 = prm.get('x0', None)
 

@@ -447,7 +447,7 @@ class TrapezoidalStepper(object):
                     # tolerance in front of its last column
                     its = acc['iters']
                     was = cycle
-                    if acc['maxrel'] > 0.5:
+                    if acc['maxrel'] > 0.9:
                         cycle = was + 1
                         if lowered:
                             backoff = min(4096, 4*backoff)
@@ -455,7 +455,7 @@ class TrapezoidalStepper(object):
                     elif acc['maxit'] < was:
                         cycle = max(1, acc['maxit'])
                     elif was > 1 and hold == 0 and (
-                            0. < acc['maxprev'] < 0.1
+                            0. < acc['maxprev'] < 0.25
                             or (learning and acc['maxneed'] < was
                                 and acc['maxprev'] < 0.5)):
                         cycle = was - 1

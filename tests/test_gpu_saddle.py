@@ -374,6 +374,17 @@ def test_lau_surface(small):
                                          rhsp=rhsp)
     assert vp.shape == (NV+NP, 2)
     assert np.linalg.norm(vp - ref) <= 1e-8*np.linalg.norm(ref)
+    # the tolerance that stood in for the direct solve is on record, and a
+    # caller that knows it penalised rows (Robin control) can say so instead
+    # of leaving it to the look at the diagonal
+    assert lau.LAST_SOLVE == dict(rtol=lau.DEFAULTS['direct_tol'],
+                                  rtol_chosen_by='diagonal heuristic')
+    lau.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv[:, :1],
+                         krplsprms=dict(penalised=True))
+    assert lau.LAST_SOLVE['rtol'] == lau.DEFAULTS['direct_tol_penalised']
+    lau.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv[:, :1],
+                         krplsprms=dict(direct_tol=1e-9))
+    assert lau.LAST_SOLVE == dict(rtol=1e-9, rtol_chosen_by='direct_tol given')
     # krylov kwargs, residual history sink, warm start
     stats = []
     vpk = lau.solve_sadpnt_smw(amat=amat, jmat=J, rhsv=rhsv[:, :1],
