@@ -98,6 +98,8 @@ int dns_saddle::init_device(int dev) {
         sgrid = std::max(64, std::min(atoi(sn), 16384));
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
     if (const char *sn = getenv("DNS_OVERSOLVE")) oversolve_env = sn[0] != '0';
+    if (const char *sn = getenv("DNS_OVERSOLVE_CMIN"))
+        oversolve_cmin_env = std::max(1, atoi(sn));
     if (const char *sn = getenv("DNS_OVERSOLVE_FRAC"))
         oversolve_frac = atof(sn);
     if (const char *sn = getenv("DNS_OVERSOLVE_RAISE"))
@@ -1186,6 +1188,9 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     if (o) popts = *o;
     oversolve = oversolve_env >= 0 ? oversolve_env != 0
                                    : popts.schur == DNS_SCHUR_MG;
+    oversolve_cmin = oversolve_cmin_env > 0
+                         ? oversolve_cmin_env
+                         : (popts.schur == DNS_SCHUR_MG ? 2 : 1);
     if (popts.cheb_degree < 1 || popts.cheb_degree > 256)
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;

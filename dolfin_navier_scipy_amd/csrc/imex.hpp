@@ -180,8 +180,8 @@ struct dns_imex {
     // then the cycle length itself; it comes down only when every solve of a
     // batch stood a decade below the tolerance in FRONT of its last column
     // and goes up, without a replay, when a batch ended close to it
-    int lower_hold = 0, lower_backoff = 4;
-    bool lowered_last = false;
+    int lower_hold = 0, lower_backoff = 2;
+    bool lowered_last = false, spiked = false;
     int batch_len = 8;             // steps per batch: 8 -> 16 -> 32 while the
                                    // predictions hold
     uint64_t prepared_sig = 0;     // configuration the graphs were captured for

@@ -545,6 +545,13 @@ struct dns_saddle {
     // n = 693k)
     double oversolve_raise = 0.9;     // batch max of final res / tol: c + 1
     double oversolve_lower = 0.25;    // ... in front of the last column: c - 1
+    // shortest cycle the policy tries.  With the multigrid block the first
+    // column reduces by ~0.4 and the warm start amplifies by >= 2.5: a
+    // one-column cycle lets the start residuals grow step by step (measured:
+    // 1 -> 1e6 x tol within a batch at n = 693k), every trial of it is a
+    // replayed batch -- so it is not tried (DNS_OVERSOLVE_CMIN overrides)
+    int oversolve_cmin = 1;
+    int oversolve_cmin_env = -1;
     int set_stop_frac(double f);
     bool capturing = false;           // a run_cached capture is open
     // multigrid Schur block (DNS_SCHUR_MG): level 0 = the pressure space
