@@ -1186,8 +1186,15 @@ int dns_saddle::set_stop_frac(double f) {
 int dns_saddle::setup_precond(const dns_precond_opts *o) {
     DNS_HIP(hipSetDevice(device));
     if (o) popts = *o;
+    // (on by default where the cycle is launch bound: there a no-op node
+    // costs what a working node costs.  Beyond ~1.5e6 unknowns the nodes are
+    // bandwidth bound, a skipped one is nearly free, and the two-column
+    // cycle is marginal -- residual levels between 0.2 and 0.9 x tol at
+    // n = 2.8M: 589 steps/s with the slack-column policy against 436-616
+    // depending on where a measuring window falls, profiles/r05_oversolve)
     oversolve = oversolve_env >= 0 ? oversolve_env != 0
-                                   : popts.schur == DNS_SCHUR_MG;
+                                   : (popts.schur == DNS_SCHUR_MG &&
+                                      n < 1500000);
     oversolve_cmin = oversolve_cmin_env > 0
                          ? oversolve_cmin_env
                          : (popts.schur == DNS_SCHUR_MG ? 2 : 1);

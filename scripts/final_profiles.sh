@@ -22,7 +22,7 @@ echo "== bench (driver window)"; timeout -k 10 300 python bench.py --steps 20 --
 echo "== refined legs"
 timeout -k 10 300 python refined_bench.py 2 2048 200 0 > $OUT/refine2_bench.json 2> $OUT/refine2.err || echo "refine2 failed"
 timeout -k 10 300 python refined_bench.py 3 4096 400 0 > $OUT/refine3_bench.json 2> $OUT/refine3.err || echo "refine3 failed"
-timeout -k 10 400 python refined_bench.py 4 8192 100 0 > $OUT/refine4_bench.json 2> $OUT/refine4.err || echo "refine4 failed"
+timeout -k 10 400 python refined_bench.py 4 8192 200 0 > $OUT/refine4_bench.json 2> $OUT/refine4.err || echo "refine4 failed"
 echo "== SBDF2, partitioned path on one RCCL rank"
 timeout -k 10 300 python bench.py --scheme sbdf2 --no-cpu --no-refined --no-picard --roofline-refine 0 > $OUT/bench_sbdf2.json 2> $OUT/bench_sbdf2.err || echo "sbdf2 failed"
 timeout -k 10 300 python bench.py --partitioned-only --gpus 1 --level 2 --steps 400 --warmup 40 --spinup 256 > $OUT/partitioned_one_rank_n10k.json 2> $OUT/partitioned_one_rank_n10k.err || echo "partitioned n10k failed"
