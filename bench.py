@@ -1270,10 +1270,18 @@ def multi_gpu_main(args, world, rank, local_rank):
                            partial=res)
             return res, int(bad.item())
         res, bad = attempt({})
-        if bad and not args.eager:
-            # once more with plain launches instead of replayed graphs (the
-            # captured RCCL calls are the one part of this path no one-GPU box
-            # can exercise with more than one rank)
+        # once more with plain launches instead of replayed graphs (the
+        # captured RCCL calls are the one part of this path no one-GPU box can
+        # exercise with more than one rank) -- unless the self-test has put
+        # the legs on plain launches already, or the budget does not hold a
+        # second run of this leg
+        again = bad and not args.eager and \
+            os.environ.get('DNS_DIST_GRAPH') != '0'
+        if again and remaining() < 0.5*timeout + 60.:
+            again = False
+            if rank == 0 and isinstance(res, dict):
+                res['second_attempt'] = 'skipped: --time-budget'
+        if again:
             first = res
             res, bad = attempt({'DNS_DIST_GRAPH': '0'})
             if rank == 0 and isinstance(res, dict):
@@ -1602,7 +1610,7 @@ def main():
                     'launch over RCCL: dns_comm_* only, a record per primitive')
     ap.add_argument('--selftest-timeout', type=float, default=120.,
                     help='time limit [s] of the RCCL self-test child')
-    ap.add_argument('--time-budget', type=float, default=780.,
+    ap.add_argument('--time-budget', type=float, default=660.,
                     help='N > 1: wall-clock budget [s] of the whole line; the '
                     'self-test and the headline leg always run, a secondary '
                     'leg only while its expected cost still fits')

@@ -2236,6 +2236,8 @@ static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double va
     else if (k == "mg_cycles") h->mg_cycles = std::max(1, std::min(2, (int)value));
     else if (k == "mg_rho") h->mg_rho = std::max(0.01, std::min(0.95, value));
     else if (k == "dist_graph") h->dist_graph_ok = value != 0.0;
+    else if (k == "oversolve") h->oversolve_env = value < 0.0 ? -1 : (value != 0.0);
+    else if (k == "oversolve_cmin") h->oversolve_cmin_env = std::max(1, (int)value);
     else
         return fail(DNS_ERR_BAD_ARGUMENT, "unknown option '%s'", name);
     h->precond_ready = false;        // (set up again with the new setting)

@@ -172,7 +172,8 @@ class SaddleSystem(object):
     def set_option(self, name, value):
         """a tuning knob of this handle (`dns_saddle_set_option`: `stream_nnz`,
         `pair`, `mg_dense_max`, `mg_part_min`, `mg_fused`, `mg_cheb`,
-        `mg_cheb_alpha`, `mg_cycles`, `mg_rho`, `dist_graph`); before
+        `mg_cheb_alpha`, `mg_cycles`, `mg_rho`, `dist_graph`, `oversolve`,
+        `oversolve_cmin`); before
         `setup_precond`"""
         C.check(self.lib.dns_saddle_set_option(self._h, name.encode(),
                                                float(value)))

@@ -526,6 +526,12 @@ int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
  *   "part_setup"    0/1: with a communicator, every rank forms only the rows
  *                   of Fh^-1, J Fh^-1 and of the Schur complement its blocks
  *                   are made of (default 1; 0: every rank forms all rows)
+ *   "oversolve"   : 1 / 0 = the solves of a pipelined batch run the columns
+ *                   of their cycle instead of stopping at the tolerance / stop
+ *                   at it (slack-column policy); -1 = the default (on with the
+ *                   multigrid Schur block below 1.5e6 unknowns)
+ *   "oversolve_cmin": shortest cycle the oversolve policy tries (default 2
+ *                   with the multigrid block, else 1)
  * Unknown names: DNS_ERR_BAD_ARGUMENT.  (No reference counterpart.) */
 int dns_saddle_set_option(dns_saddle *h, const char *name, double value);
 

@@ -1,0 +1,103 @@
+"""The oversolve policy of the pipelined batches (round 5, `DnsCtl::stop_frac`,
+DESIGN section 4): with the multigrid Schur block a solve runs the columns of
+its replayed cycle instead of stopping at the tolerance; the cycle length
+follows the residual levels.  Checked here on the wake refined once (n = 43k,
+two-level hierarchy, launch bound): the cycle settles at two
+columns without replays, the final residuals stand far below the tolerance,
+and the trajectory is the one of the slack-column policy and of a tight
+reference run."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oversolve, rtol, nsteps=384, extrapolate=3):
+    from dolfin_navier_scipy_amd import saddle, convection
+    from dolfin_navier_scipy_amd.fem import (get_sysmats, TaylorHood,
+                                             cylinder_mesh_hierarchy,
+                                             pressure_prolongations)
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, refine=1,
+                                 Re=100.)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    NP, NV = J.shape
+    dt = 1./1024
+    hier = cylinder_mesh_hierarchy(N=2, refine=1)
+    spaces = [TaylorHood(m) for m, _ in hier][::-1]
+    prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
+    system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+    system.set_schur_mg(prols)
+    system.set_option('oversolve', oversolve)
+    system.setup_precond(cheb_degree=8, schur='mg', drop_tol=7e-3,
+                         fhat='explicit', factorization='full')
+    cv = convection.ConvectionP2.from_taylor_hood(
+        femp['V'], femp['invinds'], femp['dbcinds'], femp['dbcvals'])
+    stp = saddle.ImexStepper(system, (M - .5*dt*A).tocsr())
+    v0 = np.zeros((NV, 1))
+    nfc = cv.apply(v0, scale=-1.0)
+    stp.set_state(v0, nfc_c=nfc, nfc_o=nfc)
+    stp.set_rhs(dt*rhsd['fv'], rhsd['fp'])
+    stp.set_convection(cv, scale=-1.0)
+    cf = saddle.ImexStepper.coeffs(a_c=1., cn_c=1.5*dt, cn_o=-.5*dt,
+                                   pscale=-1./dt, extrapolate=extrapolate)
+    opts = saddle.solve_opts(rtol=rtol, maxiter=400, use_graph=True, reorth=2)
+    stp.run(nsteps - 128, cf, opts)
+    _, its, last = stp.run(128, cf, opts)
+    rec = dict(stp.last_run)
+    v, p = stp.get_state()
+    stp.close()
+    cv.close()
+    system.close()
+    return dict(v=v, p=p, per_step=its/128., relres=last['true_relres'],
+                run=rec, M=M)
+
+
+def test_oversolve_runs_whole_cycles_and_keeps_the_trajectory():
+    rtol = 1e-10
+    on = _run(1, rtol)
+    off = _run(0, rtol)
+    ref = _run(0, 1e-13)
+    print('oversolve on: {0:.2f} columns per time step, final relres {1:.1e}, '
+          '{2}; off: {3:.2f} Krylov steps, relres {4:.1e}, {5}'.format(
+              on['per_step'], on['relres'], on['run'], off['per_step'],
+              off['relres'], off['run']))
+    # the last 128 steps: the cycle has settled, nothing is replayed, every
+    # solve ends at least a decade below the tolerance
+    assert on['run']['replayed'] == 0 and on['run']['unconverged'] == 0
+    # (every solve of the window ran the same whole number of columns: the
+    # cycle length, at most one more than the slack-column policy's average
+    # -- two in the developed run, three while the start-up transient lasts)
+    assert abs(on['per_step'] - round(on['per_step'])) <= 1e-9
+    assert 2 <= round(on['per_step']) <= np.ceil(off['per_step']) + 1
+    assert on['relres'] <= 0.1*rtol, on['relres']
+    assert off['relres'] <= rtol
+
+    def rel(a, b, norm):
+        return norm(a - b)/norm(b)
+    M = ref['M']
+    mn = lambda x: float(np.sqrt((x.T @ (M @ x)).item()))
+    ev_on, ev_off = rel(on['v'], ref['v'], mn), rel(off['v'], ref['v'], mn)
+    ep_on = rel(on['p'], ref['p'], np.linalg.norm)
+    ep_off = rel(off['p'], ref['p'], np.linalg.norm)
+    print('distance to the rtol 1e-13 run after 384 steps: oversolve v '
+          '{0:.1e} p {1:.1e}; slack-column policy v {2:.1e} p {3:.1e}'.format(
+              ev_on, ep_on, ev_off, ep_off))
+    assert ev_on <= 1e-8 and ep_on <= 1e-8
+    assert ev_off <= 1e-8 and ep_off <= 1e-8
+    # (solves that end far below the tolerance stay closer to the reference)
+    assert ev_on <= ev_off
+
+
+def test_oversolve_option_and_defaults():
+    from dolfin_navier_scipy_amd import _capi
+    import scipy.sparse as sps
+    # (unknown values are refused like unknown names)
+    from dolfin_navier_scipy_amd import saddle
+    F = sps.identity(8, format='csr')*2.0
+    J = sps.csr_matrix(np.ones((1, 8)))
+    system = saddle.SaddleSystem(F, J)
+    system.set_option('oversolve', 1).set_option('oversolve_cmin', 2)
+    system.set_option('oversolve', -1)
+    with pytest.raises(_capi.DnsError):
+        system.set_option('oversolve_typo', 1)
+    system.close()
