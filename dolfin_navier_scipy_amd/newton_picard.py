@@ -414,7 +414,11 @@ class TrapezoidalStepper(object):
                 # what the last sweep of this kind settled at (sweeps repeat
                 # themselves: Picard, then Newton after Newton over the same
                 # range); the first steps above only bound it from above
-                cycle = min(cycle, hints[newton])
+                # (+ 1: a sweep STARTS in a transient -- from the initial state,
+                # with an empty warm-start history -- that the end of the last
+                # sweep did not see; a first batch that fails is repeated
+                # step by step)
+                cycle = min(cycle, hints[newton] + 1)
             learning = over and newton not in hints
         hold, backoff, lowered = 0, 2, False
         while k < nt:
