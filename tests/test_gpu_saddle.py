@@ -1,5 +1,8 @@
 """Parity of the GPU saddle-point solve with the CPU oracle (direct solve) and
 with the NumPy model of the device algorithm (iteration counts)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import scipy.sparse as sps
@@ -8,6 +11,9 @@ import krylov_model as km
 from oracle import saddle_oracle
 
 pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
 @pytest.fixture(scope='module')
@@ -670,3 +676,53 @@ def test_streaming_kernels_forced_on_small_systems(sad, monkeypatch):
         v, pt = vp[:NV], vp[NV:]
     assert np.linalg.norm(vs - v) <= 1e-8*np.linalg.norm(v)
     assert np.linalg.norm(ps + pt/dt) <= 1e-6*np.linalg.norm(pt/dt)
+
+
+def test_debug_uploads_prints_the_host_ranges_of_every_copy():
+    """`DNS_DEBUG_UPLOADS=1` (round 5, after a GPU memory fault at a host
+    address whose record held no ranges): every copy between host memory and
+    the device says `[ptr, ptr + bytes)` on stderr before it is enqueued, the
+    blocks of `dns_saddle_solve_multi` included -- a fault address can then be
+    tied to a buffer and an offset"""
+    import subprocess
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import scenarios
+from dolfin_navier_scipy_amd import saddle
+prob = scenarios.toy_problem(nx=9, ny=4)
+M, A, J = (prob['smc'][k] for k in 'MAJ')
+NP, NV = J.shape
+system = saddle.SaddleSystem((M + 1e-2*A).tocsr(), J)
+system.setup_precond(cheb_degree=4, schur='dense')
+rhs = np.random.default_rng(0).standard_normal((NV, 3))
+out = system.solve_multi(rhs, rtol=1e-10)
+print('RHS', hex(rhs.ctypes.data), rhs.nbytes)
+system.close()
+''' % (ROOT, HERE)
+    env = dict(os.environ, DNS_DEBUG_UPLOADS='1')
+    res = subprocess.run([sys.executable, '-c', code], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    err = res.stderr.decode()
+    lines = [ln for ln in err.splitlines() if ln.startswith('[dns copy]')]
+    assert len(lines) > 10
+    kinds = set(ln.split()[2] for ln in lines)
+    assert {'upload', 'download'} <= kinds
+    assert any('multi rhs_v' in ln for ln in lines)
+    assert any('multi out' in ln for ln in lines)
+    # every line carries a well-formed half-open host range
+    import re
+    for ln in lines:
+        m = re.search(r'host \[(0x[0-9a-f]+), (0x[0-9a-f]+)\) dev '
+                      r'(0x[0-9a-f]+|\(nil\)) bytes (\d+)', ln)
+        assert m, ln
+        assert int(m.group(2), 16) - int(m.group(1), 16) == int(m.group(4))
+    # without the switch nothing is printed
+    res2 = subprocess.run([sys.executable, '-c', code],
+                          env={k: v for k, v in os.environ.items()
+                               if k != 'DNS_DEBUG_UPLOADS'},
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=300)
+    assert res2.returncode == 0 and '[dns copy]' not in res2.stderr.decode()
