@@ -697,6 +697,7 @@ system = saddle.SaddleSystem((M + 1e-2*A).tocsr(), J)
 system.setup_precond(cheb_degree=4, schur='dense')
 rhs = np.random.default_rng(0).standard_normal((NV, 3))
 out = system.solve_multi(rhs, rtol=1e-10)
+one = system.solve(rhs[:, 0].copy(), rtol=1e-10)
 print('RHS', hex(rhs.ctypes.data), rhs.nbytes)
 system.close()
 ''' % (ROOT, HERE)
