@@ -288,6 +288,24 @@ struct TrapRhs {
     // current velocity (k_conv_step_cells), formed here instead of being read
     const int *cgptr, *cgidx;
     const double *cells_c, *fv_c;
+    // x0 != nullptr (round 5): the start residual of the step's solve is
+    // formed HERE -- r = [b_v - F x0_v - JT x0_p; fp - J x0_v] with the
+    // partials of ||r||^2 and ||b||^2, one pair per workgroup of this family
+    // -- instead of by a launch of its own in front of the Krylov cycle.  The
+    // new values of F are being written by the OTHER workgroups of this
+    // launch, so the row does not read them: F x0 = (M + tdt A) x0 from the
+    // values it walks anyway + tdt x the gather of the cell vectors
+    // L_cell x0_cell the element kernel has left (`cx0`, the lists of the
+    // convection vector).  (Re-forming N's entries per non-zero in the row --
+    // three dependent loads each -- made the launch longer than the residual
+    // kernel it saves: measured, 11.3k -> 10.8k steps/s.)
+    const double *x0;
+    const double *cx0;       // cell values of N(v_lin) x0_v (k_conv_step_cells)
+    const int *jt_rp, *jt_ci;
+    const double *jt_v;
+    const int *j_rp, *j_ci;
+    const double *j_v;
+    double *r, *partR, *partB;
 };
 
 }  // namespace dns
@@ -313,10 +331,13 @@ struct dns_conv {
     }
     int lane_min = dns::kConvLaneMin;      // DNS_CONV_LANE_MIN (read at create)
     dns::DevBuf<double> cellvals_c;        // cell values of a second velocity
+    dns::DevBuf<double> cellvals_x0;       // ... of N(v_lin) x0 (trapezoidal
+                                           // stepper: residual in the gather)
                                            // (trapezoidal step: the current one)
     int enqueue_step_cells(const double *v_lin, int newton, const double *x_c,
                            int row_shift_c, hipStream_t s, const int *sel,
-                           int nsel);
+                           int nsel,
+                           const double *x0 = nullptr);
     std::vector<int> cmap_host;            // [12][ncells], as on the device
     std::vector<int> gptr_host, gidx_host; // the inverted index, as on the device
     struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
@@ -415,7 +436,12 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
                      const double *__restrict__ area,
                      const double *__restrict__ v_inner, TabRef dbctab,
                      int newton, double *__restrict__ L,    // [144][ncells]
-                     const int *__restrict__ sel, int nsel) {
+                     const int *__restrict__ sel, int nsel,
+                     const double *__restrict__ x0 = nullptr,
+                     double *__restrict__ cx0 = nullptr) {   // [12][ncells]
+    // x0 / cx0: the rows (a, i) of L_cell x0_cell ride along (x0 an inner
+    // vector: Dirichlet dofs contribute nothing) -- the cell values of
+    // N(v_lin) x0 for the residual formed in the gather launch (TrapRhs)
     // sel: only the cells sel[0..nsel) (row-partitioned trapezoidal stepper:
     // the cells that touch this rank's rows)
     const double *__restrict__ dbcvals = tab_row(dbctab);
@@ -424,13 +450,14 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
     const int a = t & 7;
     if (slot >= (sel ? nsel : ncells) || a >= 6) return;
     const int c = sel ? sel[slot] : slot;
-    double ul[6][2];
+    double ul[6][2], xl[6][2];
 #pragma unroll
     for (int b = 0; b < 6; ++b)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = cellmap[(size_t)(2 * b + i) * ncells + c];
             ul[b][i] = (m >= 0) ? v_inner[m] : dbcvals[-m - 1];
+            xl[b][i] = (x0 && m >= 0) ? x0[m] : 0.0;
         }
     double gl[3][2];
 #pragma unroll
@@ -490,6 +517,21 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
                     ((i == k) ? n1[b] : 0.0) + (newton ? n2[b][i][k] : 0.0);
                 L[(size_t)slot * ncells + c] = v;
             }
+    if (cx0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double y = 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                y = fma(n1[b], xl[b][i], y);
+                if (newton) {
+                    y = fma(n2[b][i][0], xl[b][0], y);
+                    y = fma(n2[b][i][1], xl[b][1], y);
+                }
+            }
+            cx0[(size_t)(2 * a + i) * ncells + c] = y;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(kBlock)
@@ -518,11 +560,13 @@ k_conv_step_cells(int ga, int gb, int ncells, const int *__restrict__ cellmap,
                   double *__restrict__ L, const double *__restrict__ x_c,
                   TabRef dbc_c, double *__restrict__ cells_c,
                   double *__restrict__ cells_lin,
-                  const int *__restrict__ sel, int nsel) {
+                  const int *__restrict__ sel, int nsel,
+                  const double *__restrict__ x0 = nullptr,
+                  double *__restrict__ cx0 = nullptr) {
     const int bid = blockIdx.x;
     if (bid < ga) {
         conv_mat_cells_block(bid, ncells, cellmap, glam, area, v_lin, dbc_lin,
-                             newton, L, sel, nsel);
+                             newton, L, sel, nsel, x0, cx0);
     } else if (bid < ga + gb) {
         conv_cells_block(bid - ga, ncells, cellmap, glam, area,
                          ConvFromVec{x_c}, dbc_c, cells_c, sel, nsel);
@@ -613,16 +657,30 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
         constexpr int LR = 16;
         const int sub = (rb * kBlock + threadIdx.x) / LR, sl = threadIdx.x % LR;
         const int nsub = nrb * (kBlock / LR);
+        const bool withr = rhs.x0 != nullptr;
+        __shared__ double red[4];
+        double sr = 0.0, sb = 0.0;       // this thread's share of the norms
         for (int r = r0 + sub; r < nrows; r += nsub) {
-            double s = 0.0, rc = 0.0, acc = 0.0;
+            double s = 0.0, rc = 0.0, acc = 0.0, kx = 0.0;
             for (int k = bptr[r] + sl; k < bptr[r + 1]; k += LR)
                 s = fma(L[bidx[k]], dbcvals[bbc[k]], s);
             if (gptr)
                 for (int k = gptr[r] + sl; k < gptr[r + 1]; k += LR)
                     rc += cellvals[gidx[k]];
-            for (int k = rhs.rowptr[r] + sl; k < rhs.rowptr[r + 1]; k += LR)
-                acc = fma(mvals[k] - tdt * avals[k], rhs.v_c[rhs.colidx[k]],
-                          acc);
+            for (int k = rhs.rowptr[r] + sl; k < rhs.rowptr[r + 1]; k += LR) {
+                const int c = rhs.colidx[k];
+                const double mk = mvals[k], ak = avals[k];
+                acc = fma(mk - tdt * ak, rhs.v_c[c], acc);
+                if (withr) kx = fma(fma(tdt, ak, mk), rhs.x0[c], kx);
+            }
+            if (withr) {
+                double nx = 0.0;
+                for (int k = rhs.cgptr[r] + sl; k < rhs.cgptr[r + 1]; k += LR)
+                    nx += rhs.cx0[rhs.cgidx[k]];
+                kx = fma(tdt, nx, kx);
+                for (int k = rhs.jt_rp[r] + sl; k < rhs.jt_rp[r + 1]; k += LR)
+                    kx = fma(rhs.jt_v[k], rhs.x0[rhs.nv + rhs.jt_ci[k]], kx);
+            }
             double cc = 0.0;
             if (rhs.cells_c)
                 for (int k = rhs.cgptr[r] + sl; k < rhs.cgptr[r + 1]; k += LR)
@@ -631,6 +689,7 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
             rc = subwave_sum<LR>(rc);
             acc = subwave_sum<LR>(acc);
             cc = subwave_sum<LR>(cc);
+            if (withr) kx = subwave_sum<LR>(kx);
             if (sl == 0) {
                 if (!gptr && rhscon) rc = rhscon[r];
                 rhsbc[r] = -s;
@@ -638,11 +697,43 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
                 if (fvn) fvn[r] = fn;
                 const double fc = rhs.cells_c ? rhs.fv_c[r] - cc
                                              : rhs.fvn_c[r];
-                rhs.b[r] = acc + tdt * (fn + fc);
+                const double bv = acc + tdt * (fn + fc);
+                rhs.b[r] = bv;
+                if (withr) {
+                    const double rv = bv - kx;
+                    rhs.r[r] = rv;
+                    sr = fma(rv, rv, sr);
+                    sb = fma(bv, bv, sb);
+                }
             }
         }
-        for (int i = rb * kBlock + threadIdx.x; i < rhs.np; i += nrb * kBlock)
-            rhs.b[rhs.nv + i] = rhs.fp[i];
+        if (!withr) {
+            for (int i = rb * kBlock + threadIdx.x; i < rhs.np;
+                 i += nrb * kBlock)
+                rhs.b[rhs.nv + i] = rhs.fp[i];
+            return;
+        }
+        // pressure rows: b_p = fp, r_p = fp - J x0_v (sixteen lanes per row)
+        for (int i = sub; i < rhs.np; i += nsub) {
+            double jx = 0.0;
+            for (int k = rhs.j_rp[i] + sl; k < rhs.j_rp[i + 1]; k += LR)
+                jx = fma(rhs.j_v[k], rhs.x0[rhs.j_ci[k]], jx);
+            jx = subwave_sum<LR>(jx);
+            if (sl == 0) {
+                const double bp = rhs.fp[i], rp = bp - jx;
+                rhs.b[rhs.nv + i] = bp;
+                rhs.r[rhs.nv + i] = rp;
+                sr = fma(rp, rp, sr);
+                sb = fma(bp, bp, sb);
+            }
+        }
+        sr = block_sum(sr, red);
+        __syncthreads();
+        sb = block_sum(sb, red);
+        if (threadIdx.x == 0) {
+            rhs.partR[rb] = sr;
+            rhs.partB[rb] = sb;
+        }
         return;
     }
     for (int r = r0 + rb * kBlock + threadIdx.x; r < nrows; r += nrb * kBlock) {
@@ -689,17 +780,19 @@ inline int dns_conv::enqueue_mat_cells(const double *v_dev, int newton,
 inline int dns_conv::enqueue_step_cells(const double *v_lin, int newton,
                                         const double *x_c, int row_shift_c,
                                         hipStream_t s, const int *sel,
-                                        int nsel) {
+                                        int nsel, const double *x0) {
     const int live = sel ? nsel : ncells;
     if (live <= 0) return DNS_OK;
     if (cellvals_c.n < (size_t)12 * ncells)
         DNS_TRY(cellvals_c.alloc((size_t)12 * ncells));
+    if (x0 && cellvals_x0.n < (size_t)12 * ncells)
+        DNS_TRY(cellvals_x0.alloc((size_t)12 * ncells));
     const int g = (8 * live + dns::kBlock - 1) / dns::kBlock;
     hipLaunchKernelGGL(dns::k_conv_step_cells, g * (newton ? 3 : 2),
                        dns::kBlock, 0, s, g, g, ncells, cellmap.p, glam.p,
                        area.p, v_lin, dbc_ref(), newton, mat->L.p, x_c,
                        dbc_ref(row_shift_c), cellvals_c.p, cellvals.p, sel,
-                       nsel);
+                       nsel, x0, x0 ? cellvals_x0.p : (double *)nullptr);
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

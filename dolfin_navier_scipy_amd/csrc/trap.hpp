@@ -148,6 +148,7 @@ struct dns_trap {
     // oversolve (DnsCtl::stop_frac) of the pipelined batches: > 0 = the
     // solves run their cycle's columns down to this fraction of the tolerance
     double over_frac = 0.0;
+    bool env_fuse_r = true;                    // DNS_TRAP_FUSE_R=0: residual kernel
     double last_dt = 0.0;
     // time-dependent data of the sweeps, one row per trajectory slot (= time
     // instance): f_v(t) (forcing + controlled-boundary stiffness terms,
