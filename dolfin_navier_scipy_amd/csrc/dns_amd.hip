@@ -94,6 +94,7 @@ int dns_saddle::init_device(int dev) {
         DNS_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     }
     if (const char *sn = getenv("DNS_STREAM_NNZ")) stream_nnz = atoll(sn);
+    if (const char *sn = getenv("DNS_MG_STREAM_NNZ")) mg_stream_nnz = atoll(sn);
     if (const char *sn = getenv("DNS_STREAM_GRID"))
         sgrid = std::max(64, std::min(atoi(sn), 16384));
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
@@ -839,7 +840,7 @@ int dns_saddle::build_mg_levels(int l0, HostCsr Sl) {
             DNS_TRY(lv.Qq.upload(&qv, stream));
             if (fp32_store)
                 for (CsrDev *op : {&lv.Rr, &lv.Qq})
-                    if (streams(*op))
+                    if (streams_mg(*op))
                         DNS_TRY(to_f32(op->vals.p, op->vals32,
                                        (size_t)op->nnz + 2));
             DNS_HIP(hipStreamSynchronize(stream));
@@ -878,7 +879,7 @@ int dns_saddle::build_mg_levels(int l0, HostCsr Sl) {
                 // a level that is row-partitioned later uploads its row blocks,
                 // which drops the copy: those levels stream fp64)
                 for (CsrDev *op : {&lv.Apre, &lv.Rr, &lv.Qq, &lv.S})
-                    if (streams(*op))
+                    if (streams_mg(*op))
                         DNS_TRY(to_f32(op->vals.p, op->vals32,
                                        (size_t)op->nnz + 2));
             }
@@ -915,7 +916,7 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
         for (int sweep = 0; sweep < mg_nu; ++sweep) {
             double *nxt = (cur == lv.x.p) ? lv.x2.p : lv.x.p;
             const double *xin = (from_zero && sweep == 0) ? nullptr : cur;
-            if (xin && !dist() && streams(lv.S)) {
+            if (xin && !dist() && streams_mg(lv.S)) {
                 // bandwidth regime: the sweep as an epilogue of the streaming
                 // kernel
                 StreamEpi ep = stream_epi_plain(1.0, 0.0, b);
@@ -945,7 +946,7 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
         const double *b = (l == 0) ? in : lv.b.p;
         xat[l] = smooth(lv, b, true, lv.x2.p);
         if (!xat[l]) return DNS_ERR_HIP;
-        const bool bigS = !dist() && streams(lv.S);
+        const bool bigS = !dist() && streams_mg(lv.S);
         DNS_TRY(launch_spmv(lv.S, xat[l], lv.r.p, -1.0, 1.0, b,
                             bigS ? DNS_SPMV_STREAM16 : DNS_SPMV_VECTOR, stream,
                             guard));
@@ -1001,7 +1002,7 @@ int dns_saddle::mg_op(const CsrDev &A, const double *xa, int nsplit,
                       const double *xb, const MgLevel *add, const double *b,
                       double *out, const int *guard) {
     // (called with whole operators only: the levels every rank runs in full)
-    if (streams(A)) {
+    if (streams_mg(A)) {
         StreamEpi ep = stream_epi_plain(1.0, 0.0, nullptr);
         ep.x2 = xb;
         ep.nsplit = nsplit;
@@ -1064,7 +1065,7 @@ int dns_saddle::mg_cycle_fused(const double *in, double *zp, double *xacc,
         double *out = (l == 0) ? zp : lv.x.p;
         const double osc = (l == 0) ? -scale : 1.0;
         // (whole operators: one GPU, or the levels every rank runs in full)
-        if (streams(lv.S)) {
+        if (streams_mg(lv.S)) {
             StreamEpi ep = stream_epi_plain(osc, 0.0, b);
             ep.dinv = lv.dinv.p;
             ep.xin = lv.x2.p;
@@ -2222,6 +2223,7 @@ static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double va
     if (!h || !name) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     const std::string k(name);
     if (k == "stream_nnz") h->stream_nnz = (int64_t)value;
+    else if (k == "mg_stream_nnz") h->mg_stream_nnz = (int64_t)value;
     else if (k == "pair") h->pair_knob = value != 0.0;
     else if (k == "part_setup") h->part_setup = value != 0.0;
     else if (k == "mg_rows") h->mg_rows_knob = value != 0.0;

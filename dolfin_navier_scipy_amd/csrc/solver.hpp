@@ -375,6 +375,18 @@ struct dns_saddle {
     bool streams(const dns::CsrDev &A) const {
         return A.nnz >= stream_nnz && A.c16.p != nullptr;
     }
+    // ... and the operators of the multigrid cycle from this many on.  The
+    // threshold above is where `Gc` of the N = 2 system (1.1M non-zeros, one
+    // launch per Krylov step, latency bound) still takes the sub-wave kernel;
+    // the level operators of a refined mesh are four launches per cycle of
+    // 0.3-3M non-zeros each, and as fp32 streams with 16-bit columns they
+    // move half the bytes of the sub-wave kernel's fp64 / int32 rows
+    // (measured at n = 173k, profiles/r05_mg_stream/)
+    int64_t mg_stream_nnz = 600000;
+    bool streams_mg(const dns::CsrDev &A) const {
+        return A.nnz >= std::min(stream_nnz, mg_stream_nnz) &&
+               A.c16.p != nullptr;
+    }
     dns::DevBuf<double> V, Z, w, z, u, r, xdev, bdev;   // Z_j = P^-1 V_j
     dns::DevBuf<double> xcat;        // [r_v; z_p] packed for the streaming Gc
     dns::DevBuf<double> partA, partN, partR, partB, partC, partE;

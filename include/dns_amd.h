@@ -526,6 +526,10 @@ int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
  *   "part_setup"    0/1: with a communicator, every rank forms only the rows
  *                   of Fh^-1, J Fh^-1 and of the Schur complement its blocks
  *                   are made of (default 1; 0: every rank forms all rows)
+ *   "mg_stream_nnz": operators of the multigrid cycle with at least this
+ *                   many non-zeros run as fp32 streams through the
+ *                   LDS-streaming kernels (default 600000; "stream_nnz",
+ *                   1300000, is the threshold of K, Fh^-1 and J Fh^-1)
  *   "oversolve"   : 1 / 0 = the solves of a pipelined batch run the columns
  *                   of their cycle instead of stopping at the tolerance / stop
  *                   at it (slack-column policy); -1 = the default (on with the
