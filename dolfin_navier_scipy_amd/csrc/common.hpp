@@ -4,6 +4,7 @@
 #include <new>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -80,6 +81,78 @@ inline void log_host_copy(const char *what, const void *host, const void *dev,
     fflush(stderr);
 }
 
+// ---------------------------------------------------------------------------
+// Host <-> device copies never hand PAGEABLE memory to the DMA engine.
+// Twice now (rounds 4 and 5) a run of the GPU suite died with "Memory access
+// fault by GPU ... on address <page-aligned HOST heap address>" inside a call
+// whose only touch of host memory was a hipMemcpyAsync out of pageable memory
+// (a caller's NumPy block, a std::vector of the set-up) -- intermittently, at
+// different places, every kernel argument accounted for.  For pageable
+// memory the runtime pins the pages in place and lets a blit kernel read
+// them; what exactly goes wrong there is not ours to find (DNS_DEBUG_UPLOADS
+// prints the ranges for whoever looks).  So every copy goes through a
+// page-locked bounce buffer of this thread: the CPU copies between the
+// caller's memory and the bounce buffer, the DMA engine only ever sees
+// hipHostMalloc memory.  4 MiB chunks, each synchronised (a copy IS complete
+// when the call returns, as DevBuf::upload promises anyway): PCIe rate minus
+// a few per cent.
+// ---------------------------------------------------------------------------
+struct BounceBuffer {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~BounceBuffer() {
+        if (p) (void)hipHostFree(p);
+    }
+    int reserve(size_t want) {
+        if (want <= bytes) return DNS_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        bytes = 0;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(DNS_ERR_HIP, "hipHostMalloc(%zu) failed: %s", want,
+                        hipGetErrorString(e));
+        }
+        bytes = want;
+        return DNS_OK;
+    }
+};
+inline thread_local BounceBuffer g_bounce;
+constexpr size_t kBounceChunk = (size_t)4 << 20;
+
+inline int staged_h2d(void *dev, const void *host, size_t bytes,
+                      hipStream_t s) {
+    if (bytes == 0) return DNS_OK;
+    DNS_TRY(g_bounce.reserve(std::min(bytes, kBounceChunk)));
+    const char *src = static_cast<const char *>(host);
+    char *dst = static_cast<char *>(dev);
+    for (size_t off = 0; off < bytes; off += kBounceChunk) {
+        const size_t len = std::min(kBounceChunk, bytes - off);
+        memcpy(g_bounce.p, src + off, len);
+        DNS_HIP(hipMemcpyAsync(dst + off, g_bounce.p, len,
+                               hipMemcpyHostToDevice, s));
+        DNS_HIP(hipStreamSynchronize(s));
+    }
+    return DNS_OK;
+}
+
+inline int staged_d2h(void *host, const void *dev, size_t bytes,
+                      hipStream_t s) {
+    if (bytes == 0) return DNS_OK;
+    DNS_TRY(g_bounce.reserve(std::min(bytes, kBounceChunk)));
+    char *dst = static_cast<char *>(host);
+    const char *src = static_cast<const char *>(dev);
+    for (size_t off = 0; off < bytes; off += kBounceChunk) {
+        const size_t len = std::min(kBounceChunk, bytes - off);
+        DNS_HIP(hipMemcpyAsync(g_bounce.p, src + off, len,
+                               hipMemcpyDeviceToHost, s));
+        DNS_HIP(hipStreamSynchronize(s));
+        memcpy(dst + off, g_bounce.p, len);
+    }
+    return DNS_OK;
+}
+
 // device buffer with explicit lifetime (no exceptions across the C-ABI)
 template <typename T>
 struct DevBuf {
@@ -108,9 +181,7 @@ struct DevBuf {
     // DMA engine gets to it is a GPU memory fault (round 3: intermittent
     // aborts of the test session).  Ordered on `s` like any other work.
     int upload(const T *host, size_t count, hipStream_t s) {
-        DNS_TRY(upload_async(host, count, s));
-        if (count > 0) DNS_HIP(hipStreamSynchronize(s));
-        return DNS_OK;
+        return upload_async(host, count, s);
     }
     // ... and the variant that only enqueues: the CALLER guarantees that
     // `host` stays valid and unmodified until it has synchronised `s` on
@@ -119,17 +190,15 @@ struct DevBuf {
         if (count > n) return fail(DNS_ERR_BAD_ARGUMENT, "upload overflow");
         if (count == 0) return DNS_OK;
         log_host_copy("upload", host, p, count * sizeof(T));
-        DNS_HIP(hipMemcpyAsync(p, host, count * sizeof(T),
-                               hipMemcpyHostToDevice, s));
-        return DNS_OK;
+        // (through the page-locked bounce buffer: complete on return)
+        return staged_h2d(p, host, count * sizeof(T), s);
     }
     int download(T *host, size_t count, hipStream_t s) const {
         if (count > n) return fail(DNS_ERR_BAD_ARGUMENT, "download overflow");
         if (count == 0) return DNS_OK;
         log_host_copy("download", host, p, count * sizeof(T));
-        DNS_HIP(hipMemcpyAsync(host, p, count * sizeof(T),
-                               hipMemcpyDeviceToHost, s));
-        return DNS_OK;
+        // (through the page-locked bounce buffer: complete on return)
+        return staged_d2h(host, p, count * sizeof(T), s);
     }
     int zero(hipStream_t s) {
         DNS_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
@@ -143,10 +212,7 @@ template <typename T>
 inline int upload_to(T *dev, const T *host, size_t count, hipStream_t s) {
     if (count == 0) return DNS_OK;
     log_host_copy("upload_to", host, dev, count * sizeof(T));
-    DNS_HIP(hipMemcpyAsync(dev, host, count * sizeof(T), hipMemcpyHostToDevice,
-                           s));
-    DNS_HIP(hipStreamSynchronize(s));
-    return DNS_OK;
+    return staged_h2d(dev, host, count * sizeof(T), s);
 }
 
 // page-locked host staging (hipHostMalloc): copies between it and the device

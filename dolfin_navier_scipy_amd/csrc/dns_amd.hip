@@ -1925,10 +1925,8 @@ int dns_saddle::gmres(const double *b, double *x, const dns_solve_opts *o,
     last_iters = total;
     history.assign((size_t)std::max(1, hdr_host->hist_len), hdr_host->resnorm);
     if (hdr_host->hist_len > 0 && want_history) {
-        DNS_HIP(hipMemcpyAsync(history.data(), histdev.p,
-                               history.size() * sizeof(double),
-                               hipMemcpyDeviceToHost, stream));
-        DNS_HIP(hipStreamSynchronize(stream));
+        DNS_TRY(dns::staged_d2h(history.data(), histdev.p,
+                                history.size() * sizeof(double), stream));
     }
     st->iters = total;
     st->restarts = restarts;
@@ -2016,10 +2014,8 @@ int dns_saddle::bicgstab(const double *b, double *x, const dns_solve_opts *o,
     }
     const int total = hdr_host->total_it;
     history.assign((size_t)total + 1, 0.0);
-    DNS_HIP(hipMemcpyAsync(history.data(), histdev.p,
-                           history.size() * sizeof(double),
-                           hipMemcpyDeviceToHost, stream));
-    DNS_HIP(hipStreamSynchronize(stream));
+    DNS_TRY(dns::staged_d2h(history.data(), histdev.p,
+                            history.size() * sizeof(double), stream));
     st->iters = total;
     st->restarts = 0;
     st->bnorm = hdr_host->bnorm;
@@ -2734,7 +2730,9 @@ int dns_partition_range(int32_t n, int32_t nranks, int32_t rank,
 static int dns_device_read_impl(int device, const void *dev, void *host, size_t bytes) {
     if (!dev || !host) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     DNS_HIP(hipSetDevice(device));
-    DNS_HIP(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    DNS_HIP(hipDeviceSynchronize());
+    dns::log_host_copy("device_read", host, dev, bytes);
+    DNS_TRY(dns::staged_d2h(host, dev, bytes, nullptr));
     return DNS_OK;
 }
 
@@ -2745,7 +2743,9 @@ int dns_device_read(int device, const void *dev, void *host, size_t bytes) {
 static int dns_device_write_impl(int device, void *dev, const void *host, size_t bytes) {
     if (!dev || !host) return fail(DNS_ERR_BAD_ARGUMENT, "null argument");
     DNS_HIP(hipSetDevice(device));
-    DNS_HIP(hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice));
+    DNS_HIP(hipDeviceSynchronize());
+    dns::log_host_copy("device_write", host, dev, bytes);
+    DNS_TRY(dns::staged_h2d(dev, host, bytes, nullptr));
     return DNS_OK;
 }
 
