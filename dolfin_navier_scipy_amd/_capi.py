@@ -219,6 +219,9 @@ SIGNATURES = {
                                  ct.c_int32, ct.c_int32, ct.c_int32,
                                  ct.c_int32, ct.POINTER(dns_solve_opts),
                                  ct.POINTER(dns_solve_stats)]),
+    'dns_trap_run': (ct.c_int, [ct.c_void_p, ct.c_double, ct.c_int32,
+                                ct.c_int32, ct.c_int32, ct.c_int32,
+                                ct.c_int32, ct.POINTER(dns_solve_opts)]),
     'dns_trap_get_state': (ct.c_int, [ct.c_void_p, c_double_p, c_double_p]),
     'dns_trap_update_norm': (ct.c_int, [ct.c_void_p, c_double_p]),
     'dns_trap_set_pipeline': (ct.c_int, [ct.c_void_p, ct.c_int32]),

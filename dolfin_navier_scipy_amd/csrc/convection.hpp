@@ -308,6 +308,44 @@ struct TrapRhs {
     double *r, *partR, *partB;
 };
 
+// The update norm of a trapezoidal step (trap.hpp, k_trap_updnorm:
+// dt ||v_n - v_lin||_M^2 and the new velocity into its trajectory slot) as a
+// JOB the element launch of the NEXT step carries in extra workgroups: what it
+// reads (the new velocity, its linearisation point, M) is complete and stays
+// untouched until that step's solve ends -- one launch per step less.
+struct UpdJob {
+    const int *rowptr, *colidx;
+    const double *mvals, *x, *y;
+    double *part, *copy_out;
+    int nv, nblk, lpr;
+    double scale;
+};
+
+template <int LPR>
+__device__ __forceinline__ void updnorm_block(int bid, const UpdJob &u,
+                                              double *red) {
+    const int sub = (bid * kBlock + threadIdx.x) / LPR;
+    const int sublane = threadIdx.x % LPR;
+    const int nsub = u.nblk * (kBlock / LPR);
+    double acc = 0.0;
+    for (int row = sub; row < u.nv; row += nsub) {
+        double s = 0.0;
+        const int k1 = u.rowptr[row + 1];
+        for (int k = u.rowptr[row] + sublane; k < k1; k += LPR) {
+            const int c = u.colidx[k];
+            s = fma(u.mvals[k], u.x[c] - u.y[c], s);
+        }
+        s = subwave_sum<LPR>(s);
+        if (sublane == 0) {
+            const double xr = u.x[row];
+            acc = fma(xr - u.y[row], s, acc);
+            if (u.copy_out) u.copy_out[row] = xr;
+        }
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) u.part[bid] = u.scale * acc;
+}
+
 }  // namespace dns
 
 struct dns_conv {
@@ -337,7 +375,8 @@ struct dns_conv {
     int enqueue_step_cells(const double *v_lin, int newton, const double *x_c,
                            int row_shift_c, hipStream_t s, const int *sel,
                            int nsel,
-                           const double *x0 = nullptr);
+                           const double *x0 = nullptr,
+                           const dns::UpdJob *upd = nullptr);
     std::vector<int> cmap_host;            // [12][ncells], as on the device
     std::vector<int> gptr_host, gidx_host; // the inverted index, as on the device
     struct dns_conv_mat *mat = nullptr;    // bound matrix pattern (optional)
@@ -561,8 +600,8 @@ k_conv_step_cells(int ga, int gb, int ncells, const int *__restrict__ cellmap,
                   TabRef dbc_c, double *__restrict__ cells_c,
                   double *__restrict__ cells_lin,
                   const int *__restrict__ sel, int nsel,
-                  const double *__restrict__ x0 = nullptr,
-                  double *__restrict__ cx0 = nullptr) {
+                  const double *__restrict__ x0, double *__restrict__ cx0,
+                  int gc, UpdJob upd) {
     const int bid = blockIdx.x;
     if (bid < ga) {
         conv_mat_cells_block(bid, ncells, cellmap, glam, area, v_lin, dbc_lin,
@@ -570,9 +609,21 @@ k_conv_step_cells(int ga, int gb, int ncells, const int *__restrict__ cellmap,
     } else if (bid < ga + gb) {
         conv_cells_block(bid - ga, ncells, cellmap, glam, area,
                          ConvFromVec{x_c}, dbc_c, cells_c, sel, nsel);
-    } else {
+    } else if (bid < ga + gb + gc) {
         conv_cells_block(bid - ga - gb, ncells, cellmap, glam, area,
                          ConvFromVec{v_lin}, dbc_lin, cells_lin, sel, nsel);
+    } else {
+        // (the update norm of the step before, UpdJob)
+        __shared__ double red[4];
+        const int ub = bid - ga - gb - gc;
+        if (upd.lpr <= 8)
+            updnorm_block<8>(ub, upd, red);
+        else if (upd.lpr <= 16)
+            updnorm_block<16>(ub, upd, red);
+        else if (upd.lpr <= 32)
+            updnorm_block<32>(ub, upd, red);
+        else
+            updnorm_block<64>(ub, upd, red);
     }
 }
 
@@ -780,19 +831,26 @@ inline int dns_conv::enqueue_mat_cells(const double *v_dev, int newton,
 inline int dns_conv::enqueue_step_cells(const double *v_lin, int newton,
                                         const double *x_c, int row_shift_c,
                                         hipStream_t s, const int *sel,
-                                        int nsel, const double *x0) {
+                                        int nsel, const double *x0,
+                                        const dns::UpdJob *upd) {
     const int live = sel ? nsel : ncells;
-    if (live <= 0) return DNS_OK;
+    if (live <= 0)
+        return upd ? dns::fail(DNS_ERR_BAD_ARGUMENT,
+                               "update-norm job without cells to ride on")
+                   : DNS_OK;
     if (cellvals_c.n < (size_t)12 * ncells)
         DNS_TRY(cellvals_c.alloc((size_t)12 * ncells));
     if (x0 && cellvals_x0.n < (size_t)12 * ncells)
         DNS_TRY(cellvals_x0.alloc((size_t)12 * ncells));
     const int g = (8 * live + dns::kBlock - 1) / dns::kBlock;
-    hipLaunchKernelGGL(dns::k_conv_step_cells, g * (newton ? 3 : 2),
+    const int gc = newton ? g : 0;
+    hipLaunchKernelGGL(dns::k_conv_step_cells,
+                       2 * g + gc + (upd ? upd->nblk : 0),
                        dns::kBlock, 0, s, g, g, ncells, cellmap.p, glam.p,
                        area.p, v_lin, dbc_ref(), newton, mat->L.p, x_c,
                        dbc_ref(row_shift_c), cellvals_c.p, cellvals.p, sel,
-                       nsel, x0, x0 ? cellvals_x0.p : (double *)nullptr);
+                       nsel, x0, x0 ? cellvals_x0.p : (double *)nullptr, gc,
+                       upd ? *upd : dns::UpdJob{});
     DNS_HIP(hipGetLastError());
     return DNS_OK;
 }

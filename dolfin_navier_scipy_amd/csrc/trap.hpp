@@ -144,11 +144,27 @@ struct dns_trap {
     int upd_slot = 0, upd_stride = 0;
     static constexpr int kUpdSlots = 128;
     int flush_updnorm();
+    // the update norm of the last pipelined step, not launched yet: the
+    // element launch of the next step carries it (dns::UpdJob); whoever
+    // reads its results first (the partials, the trajectory slot) launches
+    // it on its own -- flush_pending_upd()
+    struct {
+        bool on = false;
+        dns::UpdJob job = {};
+        int out_which = -1;                    // trajectory it writes a slot of
+    } pend;
+    bool env_upd_ride = true;                  // DNS_TRAP_UPD_RIDE=0: own launch
+    int flush_pending_upd();
     int pipeline_c = 0;                        // > 0: steps do not synchronise
     // oversolve (DnsCtl::stop_frac) of the pipelined batches: > 0 = the
     // solves run their cycle's columns down to this fraction of the tolerance
     double over_frac = 0.0;
     bool env_fuse_r = true;                    // DNS_TRAP_FUSE_R=0: residual kernel
+    // pipelined sweep on one GPU: the Krylov cycle as plain launches, not as a
+    // graph replay between the plain launches of the assembly and the update
+    // norm -- every switch between the two costs the queue 6-9 us (measured,
+    // profiles/r05_sweeps: 11.07k -> 11.78k steps/s); DNS_TRAP_GRAPH=1: replay
+    bool env_graph = false;
     double last_dt = 0.0;
     // time-dependent data of the sweeps, one row per trajectory slot (= time
     // instance): f_v(t) (forcing + controlled-boundary stiffness terms,

@@ -253,6 +253,16 @@ class TrapezoidalStepper(object):
                                  '{0}'.format(self.last_stats))
         return self.last_stats
 
+    def run(self, dt, lin_which, slot0, count, newton, opts=None,
+            extrapolate=4):
+        """`count` pipelined steps in a row (`dns_trap_run`): step `k` is
+        linearised about slot `slot0 + k` and stores its velocity there --
+        the time loop of a sweep without a trip through Python per step"""
+        o = solve_opts() if opts is None else opts
+        C.check(self.lib.dns_trap_run(
+            self._h, float(dt), int(lin_which), int(slot0), int(count),
+            int(bool(newton)), int(extrapolate), ct.byref(o)))
+
     def state(self):
         v, p = np.empty(self.NV), np.empty(self.NP)
         C.check(self.lib.dns_trap_get_state(self._h, C.dptr(v), C.dptr(p)))
@@ -432,8 +442,14 @@ class TrapezoidalStepper(object):
             else:
                 self.checkpoint()
                 self.set_pipeline(cycle)
-                for kk in range(k, kend):
-                    one(kk)
+                if record:
+                    for kk in range(k, kend):
+                        one(kk)
+                else:
+                    # (uniform grid, no low-rank terms: the loop is the
+                    # library's)
+                    self.run(trange[k] - trange[k-1], lin_which, k, kend - k,
+                             newton, opts=opts, extrapolate=extrapolate)
                 acc = self.poll()
                 self.set_pipeline(0)
                 if os.environ.get('DNS_DEBUG'):

@@ -639,6 +639,14 @@ int dns_trap_step_fb(dns_trap *t, double dt, int32_t lin_which,
  * them) and folds the device part of the update norm in.  A sweep with
  * `fails > 0` has to be repeated with cycle_len = 0. */
 int dns_trap_set_pipeline(dns_trap *t, int32_t cycle_len);
+/* `count` pipelined steps of step size dt in a row: step k has its
+ * linearisation point in slot slot0 + k of traj[lin_which] and stores its
+ * velocity in the same slot of the other buffer (the time loop of a sweep,
+ * snu:1402-1566, without a trip through the caller per step).  Needs
+ * dns_trap_set_pipeline(cycle_len > 0) */
+int dns_trap_run(dns_trap *t, double dt, int32_t lin_which, int32_t slot0,
+                 int32_t count, int32_t newton, int32_t extrapolate_x0,
+                 const dns_solve_opts *opts);
 int dns_trap_poll(dns_trap *t, int32_t *solves, int32_t *fails, int32_t *iters,
                   int32_t *maxit);
 /* Oversolve of the pipelined batches: with stop_frac > 0 a solve does not stop

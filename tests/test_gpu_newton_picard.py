@@ -137,6 +137,56 @@ def test_device_sweep_matches_oracle(setup, cvop, picard):
     stp.close()
 
 
+@pytest.mark.parametrize('picard', [True, False])
+def test_library_time_loop_equals_the_per_step_calls(toy_prob, picard):
+    """`dns_trap_run` (the sweep's time loop inside the library; the update
+    norm of a step rides in the element launch of the next one, dns::UpdJob)
+    against one `dns_trap_step` call per step: same update norm, same
+    trajectory -- read slot by slot, the LAST slot first (its update-norm job
+    is still pending when the batch ends)"""
+    from dolfin_navier_scipy_amd import convection, newton_picard as dnp, saddle
+    s = _setup(toy_prob, Nts=40, tE=0.1)
+    tr = s['trange']
+    cv = convection.ConvectionP2.from_taylor_hood(s['th'], s['inv'],
+                                                  s['dbcinds'], s['dbcvals'])
+    stp = dnp.TrapezoidalStepper(s['M'], s['A'], s['J'], cv, nslots=tr.size,
+                                 dt=tr[1] - tr[0], precond=dict(cheb_degree=4))
+    stp.set_rhs(s['fv'], s['fp'])
+    for k, t in enumerate(tr):
+        stp.write_linpoint(0, k, s['lin0'][t])
+    opts = saddle.solve_opts(rtol=1e-12, maxiter=400, use_graph=True)
+    rec_v, _, upd_rec, st_rec = stp.sweep(tr, s['iniv'], 0, picard, opts=opts,
+                                          record=True)
+    assert st_rec['cycle'] is not None          # (pipelined batches)
+    traj_rec = [stp.read_traj(1, k) for k in range(1, tr.size)]
+    for k, t in enumerate(tr[1:], start=1):
+        assert np.array_equal(traj_rec[k - 1], rec_v[t])
+    # poison the output buffer, then the library's loop
+    for k in range(tr.size):
+        stp.write_linpoint(1, k, 0*s['iniv'] + 7.0)
+    _, _, upd_run, st_run = stp.sweep(tr, s['iniv'], 0, picard, opts=opts,
+                                      record=False)
+    last = stp.read_traj(1, tr.size - 1)
+    scale = np.abs(traj_rec[-1]).max()
+    assert np.abs(last - traj_rec[-1]).max() <= 1e-9*scale
+    for k in range(1, tr.size):
+        assert np.abs(stp.read_traj(1, k) - traj_rec[k - 1]).max() <= \
+            1e-9*scale, k
+    assert abs(upd_run - upd_rec) <= 1e-8*abs(upd_rec) + 1e-20
+    assert st_run['iters'] > 0
+    # a slot read while its step's update-norm job is still pending (no poll
+    # in between): the read launches the job first
+    stp.write_linpoint(1, 7, 0*s['iniv'] + 7.0)
+    stp.set_pipeline(3)
+    stp.run(tr[1] - tr[0], 0, 5, 3, not picard, opts=opts)
+    got = stp.read_traj(1, 7)
+    stp.poll()
+    stp.set_pipeline(0)
+    assert np.array_equal(got, stp.state()[0])
+    stp.close()
+    cv.close()
+
+
 def test_async_trajectory_writer(setup, cvop, tmp_path):
     """the trajectory of a sweep travels to the host (and to
     `.npy` files, what `dou.save_npa` writes per step in the reference,
