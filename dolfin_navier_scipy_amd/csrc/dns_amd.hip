@@ -98,6 +98,8 @@ int dns_saddle::init_device(int dev) {
     if (const char *sn = getenv("DNS_STREAM_GRID"))
         sgrid = std::max(64, std::min(atoi(sn), 16384));
     if (const char *sn = getenv("DNS_MG_DENSE_MAX")) mg_dense_max = atoi(sn);
+    if (const char *sn = getenv("DNS_MG_DENSE_HALF_MAX"))
+        mg_dense_half_max = atoi(sn);
     if (const char *sn = getenv("DNS_OVERSOLVE")) oversolve_env = sn[0] != '0';
     if (const char *sn = getenv("DNS_OVERSOLVE_CMIN"))
         oversolve_cmin_env = std::max(1, atoi(sn));
@@ -724,7 +726,8 @@ int dns_saddle::mg_prepare(int n0) {
     // instead of two more sparse levels does not pay -- refine 2: 2145 vs
     // 2172 steps/s, refine 3: 568 vs 702 with 2.6 instead of 2.45 Krylov steps
     // per time step -- hence the small default, DNS_MG_DENSE_MAX.)
-    const int dense_max = mg_dense_max;
+    const int dense_max = std::max(mg_dense_max,
+                                   std::min(mg_dense_half_max, 16384));
     int L = (int)mg_prol_h.size() + 1;
     {
         int nl = n0;
@@ -774,8 +777,31 @@ int dns_saddle::build_mg_levels(int l0, HostCsr Sl) {
             DNS_TRY(mg_cinv.upload(sd.data(), sd.size(), stream));
             DNS_HIP(hipStreamSynchronize(stream));
             DNS_TRY(invert_dense(mg_cinv.p, lv.n));
-            if (fp32_store)
+            mg_cinv16.release();
+            mg_cld16 = 0;
+            if (mg_dense_half_max > 0 && lv.n > mg_dense_max &&
+                lv.n <= mg_dense_half_max) {
+                // (a level this size is dense only in half precision)
+                const int ldh = (lv.n + 7) / 8 * 8;
+                const int ga = 1024;
+                DevBuf<double> amax;
+                DNS_TRY(amax.alloc((size_t)ga));
+                DNS_TRY(mg_cscale.alloc(1));
+                DNS_TRY(mg_cinv16.alloc((size_t)lv.n * ldh));
+                hipLaunchKernelGGL(k_absmax, ga, kBlock, 0, stream,
+                                   (int64_t)lv.n * lv.n, mg_cinv.p, amax.p);
+                hipLaunchKernelGGL(k_to_half_rows,
+                                   grid_for_elems((int64_t)lv.n * ldh), kBlock,
+                                   0, stream, lv.n, ldh, mg_cinv.p, amax.p, ga,
+                                   1024.0, mg_cinv16.p, mg_cscale.p);
+                DNS_HIP(hipGetLastError());
+                DNS_HIP(hipStreamSynchronize(stream));
+                mg_cld16 = ldh;
+                mg_cinv.release();
+                mg_cinv32.release();
+            } else if (fp32_store) {
                 DNS_TRY(to_f32(mg_cinv.p, mg_cinv32, sd.size()));
+            }
             break;
         }
         const HostCsr &P = mg_prol_h[l];
@@ -962,13 +988,7 @@ int dns_saddle::schur_mg_apply(const double *in, double *zp, double *xacc,
         const DnsCtl *gctl = (guard && guard == done_ptr())
                                  ? (const DnsCtl *)ctl.p
                                  : (const DnsCtl *)nullptr;
-        const int gg = std::max(1, std::min((lc.n + 3) / 4, 2048));
-        if (fp32_store && mg_cinv32.p)
-            hipLaunchKernelGGL(k_gemv_rows<float>, gg, kBlock, 0, stream, lc.n,
-                               mg_cinv32.p, b, lc.x.p, 1.0, gctl);
-        else
-            hipLaunchKernelGGL(k_gemv_rows<double>, gg, kBlock, 0, stream, lc.n,
-                               mg_cinv.p, b, lc.x.p, 1.0, gctl);
+        DNS_TRY(mg_coarse_apply(b, lc.x.p, gctl));
         xat[L - 1] = lc.x.p;
     }
     for (int l = L - 2; l >= 0; --l) {
@@ -1031,6 +1051,24 @@ int dns_saddle::mg_op(const CsrDev &A, const double *xa, int nsplit,
 // the V(2,2) cycle on the fused operators: per level two launches down
 // (x_pre = Apre b; b_c = Rr [b; x_pre]) and two up (x' = Qq [x_pre; e] + c(b);
 // one more sweep -- the finest level's writes zp = -x'' itself)
+int dns_saddle::mg_coarse_apply(const double *b, double *x,
+                                const DnsCtl *gctl) {
+    const int nc = mg.back().n;
+    const int gg = std::max(1, std::min((nc + 3) / 4, 2048));
+    if (mg_cinv16.p)
+        hipLaunchKernelGGL(k_gemv_half, gg, kBlock,
+                           (size_t)mg_cld16 * sizeof(float), stream, nc,
+                           mg_cld16, mg_cinv16.p, mg_cscale.p, b, x, 1.0, gctl);
+    else if (fp32_store && mg_cinv32.p)
+        hipLaunchKernelGGL(k_gemv_rows<float>, gg, kBlock, 0, stream, nc,
+                           mg_cinv32.p, b, x, 1.0, gctl);
+    else
+        hipLaunchKernelGGL(k_gemv_rows<double>, gg, kBlock, 0, stream, nc,
+                           mg_cinv.p, b, x, 1.0, gctl);
+    DNS_HIP(hipGetLastError());
+    return DNS_OK;
+}
+
 int dns_saddle::mg_cycle_fused(const double *in, double *zp, double *xacc,
                                 const int *guard, double scale) {
     // zp = -scale * V(in)  (and xacc += zp)
@@ -1048,13 +1086,7 @@ int dns_saddle::mg_cycle_fused(const double *in, double *zp, double *xacc,
         const DnsCtl *gctl = (guard && guard == done_ptr())
                                  ? (const DnsCtl *)ctl.p
                                  : (const DnsCtl *)nullptr;
-        const int gg = std::max(1, std::min((lc.n + 3) / 4, 2048));
-        if (fp32_store && mg_cinv32.p)
-            hipLaunchKernelGGL(k_gemv_rows<float>, gg, kBlock, 0, stream, lc.n,
-                               mg_cinv32.p, lc.b.p, lc.x.p, 1.0, gctl);
-        else
-            hipLaunchKernelGGL(k_gemv_rows<double>, gg, kBlock, 0, stream, lc.n,
-                               mg_cinv.p, lc.b.p, lc.x.p, 1.0, gctl);
+        DNS_TRY(mg_coarse_apply(lc.b.p, lc.x.p, gctl));
     }
     for (int l = L - 2; l >= 0; --l) {
         MgLevel &lv = mg[l];
@@ -1109,13 +1141,7 @@ int dns_saddle::mg_cycle_fused11(const double *in, double *zp, double *xacc,
         const DnsCtl *gctl = (guard && guard == done_ptr())
                                  ? (const DnsCtl *)ctl.p
                                  : (const DnsCtl *)nullptr;
-        const int gg = std::max(1, std::min((lc.n + 3) / 4, 2048));
-        if (fp32_store && mg_cinv32.p)
-            hipLaunchKernelGGL(k_gemv_rows<float>, gg, kBlock, 0, stream, lc.n,
-                               mg_cinv32.p, lc.b.p, lc.x.p, 1.0, gctl);
-        else
-            hipLaunchKernelGGL(k_gemv_rows<double>, gg, kBlock, 0, stream, lc.n,
-                               mg_cinv.p, lc.b.p, lc.x.p, 1.0, gctl);
+        DNS_TRY(mg_coarse_apply(lc.b.p, lc.x.p, gctl));
     }
     for (int l = L - 2; l >= 0; --l) {
         MgLevel &lv = mg[l];
@@ -2227,6 +2253,7 @@ static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double va
     else if (k == "dist_lazy1") h->dist_lazy1 = value != 0.0;
     else if (k == "cycle_first") h->cycle_first = (int)value;
     else if (k == "mg_dense_max") h->mg_dense_max = (int)value;
+    else if (k == "mg_dense_half_max") h->mg_dense_half_max = (int)value;
     else if (k == "mg_part_min") h->mg_part_min = (int)value;
     else if (k == "mg_fused") h->mg_fused_knob = value != 0.0;
     else if (k == "mg_cheb") h->mg_cheb = value != 0.0;
@@ -2939,6 +2966,11 @@ static int dns_saddle_precond_info_impl(dns_saddle *h, int32_t cap, int64_t *out
     }
     // (last: device bytes of the pair format of K, 0 = the CSR kernels apply K)
     v.push_back(h->Kp.ready ? h->Kp.bytes() : 0);
+    // (bytes per entry of the coarsest level's dense inverse as applied)
+    v.push_back(L == 0 ? 0
+                       : (h->mg_cinv16.p ? 2
+                                         : (h->fp32_store && h->mg_cinv32.p ? 4
+                                                                            : 8)));
     *count = (int32_t)v.size();
     if (out)
         for (int32_t i = 0; i < std::min<int32_t>(cap, *count); ++i)

@@ -10,6 +10,7 @@
 
 #include "bicgstab_kernels.hpp"
 #include "comm.hpp"
+#include "dense_half.hpp"
 #include "gmres_kernels.hpp"
 #include "halo.hpp"
 #include "hostcsr.hpp"
@@ -601,6 +602,15 @@ struct dns_saddle {
     dns::DevBuf<double> mg_cinv;          // dense inverse on the coarsest level
     dns::DevBuf<float> mg_cinv32;         // ... its fp32 copy (fp32_store)
     int mg_dense_max = 2000;              // first level <= this: dense inverse
+    // ... and up to this size when the inverse is stored in HALF precision
+    // (dense_half.hpp: one bandwidth-bound launch instead of the five
+    // latency-bound ones of a sparse level; 0 = never); DNS_MG_DENSE_HALF_MAX
+    int mg_dense_half_max = 0;
+    dns::DevBuf<__half> mg_cinv16;        // the inverse / mg_cscale[0]
+    dns::DevBuf<double> mg_cscale;
+    int mg_cld16 = 0;                     // its leading dimension (8 | ld)
+    // x = (coarsest level)^-1 b in whichever store the set-up chose
+    int mg_coarse_apply(const double *b, double *x, const dns::DnsCtl *gctl);
     int mg_nu = 2;
     bool mg_cheb = true;                  // DNS_MG_CHEB (read once, at create)
     double mg_cheb_alpha = 3.0;           // DNS_MG_CHEB_ALPHA (measured: 3

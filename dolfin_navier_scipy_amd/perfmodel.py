@@ -46,8 +46,12 @@ def _schur_ops(info, moved):
         ops.append(('MG level {0}: prolongation x += P e'.format(l), 1,
                     spmv_bytes(lev['nnz_P'], n, nc) + 8*n))
     ncoarse = lv[-1]['n']
+    # (a half-precision inverse, dense_half.hpp, is counted as stored in both
+    # columns: it is dense at that size only because it is half)
+    cb = info.get('mg_coarse_val_bytes', 8)
+    vb = 2 if cb == 2 else (4 if (fp32 and cb == 4) else 8)
     ops.append(('MG coarsest: dense inverse GEMV', 1,
-                8*ncoarse*ncoarse + 16*ncoarse))
+                vb*ncoarse*ncoarse + 16*ncoarse))
     return ops
 
 

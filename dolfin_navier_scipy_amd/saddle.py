@@ -171,8 +171,8 @@ class SaddleSystem(object):
 
     def set_option(self, name, value):
         """a tuning knob of this handle (`dns_saddle_set_option`: `stream_nnz`,
-        `pair`, `mg_dense_max`, `mg_part_min`, `mg_fused`, `mg_cheb`,
-        `mg_cheb_alpha`, `mg_cycles`, `mg_rho`, `dist_graph`, `oversolve`,
+        `pair`, `mg_dense_max`, `mg_dense_half_max`, `mg_part_min`,
+        `mg_fused`, `mg_cheb`, `mg_cheb_alpha`, `mg_cycles`, `mg_rho`, `dist_graph`, `oversolve`,
         `oversolve_cmin`); before
         `setup_precond`"""
         C.check(self.lib.dns_saddle_set_option(self._h, name.encode(),
@@ -196,6 +196,7 @@ class SaddleSystem(object):
             out['mg_levels'].append(dict(n=n, nnz_S=nnzs, nnz_P=nnzp))
         tail = 9 + 3*v[7]
         out['pair_format_bytes'] = v[tail] if len(v) > tail else 0
+        out['mg_coarse_val_bytes'] = v[tail + 1] if len(v) > tail + 1 else 8
         return out
 
     def solve(self, rhsv, rhsp=None, x0=None, raise_on_fail=True, **kw):

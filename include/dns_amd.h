@@ -511,6 +511,9 @@ int dns_saddle_set_schur_mg(dns_saddle *h, int32_t nprol, const dns_csr *prol,
  *                   LDS-streaming kernels (bandwidth regime)
  *   "pair"          0/1: pair format of K in the bandwidth regime
  *   "mg_dense_max"  first multigrid level <= this gets the dense inverse
+ *   "mg_dense_half_max"  ... and a level up to this size gets it in half
+ *                   precision (one bandwidth-bound launch instead of the five
+ *                   latency-bound launches of a sparse level); 0 = never
  *   "mg_part_min"   levels with at least this many rows are row-partitioned
  *   "mg_fused"      0/1: fused V(2,2) operators
  *   "mg_cheb"       0/1: Chebyshev pair of smoothing weights; "mg_cheb_alpha"
