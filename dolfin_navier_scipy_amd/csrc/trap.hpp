@@ -131,7 +131,15 @@ struct dns_trap {
         hipStream_t cstream = nullptr;
         hipEvent_t ready = nullptr, done[2] = {nullptr, nullptr};
         bool pending[2] = {false, false};
-        std::vector<void *> pinned;
+        // a queued export: the copy engine writes into a page-locked buffer
+        // of the library's own; the caller's array is filled by the CPU when
+        // the export is waited for (no DMA into caller memory, common.hpp)
+        struct Job {
+            double *host;
+            void *stage;
+            size_t bytes;
+        };
+        std::vector<Job> jobs;
         std::mutex mu;
     } exp_;
     int export_fence(int which);   // solver stream waits for a pending export

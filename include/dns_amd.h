@@ -597,13 +597,15 @@ int dns_trap_traj_write(dns_trap *t, int32_t which, int32_t slot,
 int dns_trap_traj_read(dns_trap *t, int32_t which, int32_t slot, double *v);
 /* Asynchronous writer of the trajectory store (replaces the
  * blocking per-step `dou.save_npa`, reference snu:1012-1014, 1424-1431): the
- * copy of the slots [slot0, slot0+count) of traj[which] into `host` (count*NV
- * doubles, page-locked by the call) is queued on a copy stream of its own
+ * copy of the slots [slot0, slot0+count) of traj[which] (count*NV doubles,
+ * into a page-locked buffer of the library's) is queued on a copy stream of
+ * its own
  * behind the work the solver's stream has been given so far; the call returns
  * at once and the next sweep runs while the data travels.  The solver's stream
  * waits for a pending export only before it overwrites traj[which].
- * dns_trap_traj_export_wait blocks until all exports have arrived and releases
- * the page locks; any host thread may call it. */
+ * dns_trap_traj_export_wait blocks until all exports have arrived and fills
+ * the `host` arrays (which have to be alive until then); any host thread may
+ * call it. */
 int dns_trap_traj_export_async(dns_trap *t, int32_t which, int32_t slot0,
                                int32_t count, double *host);
 int dns_trap_traj_export_wait(dns_trap *t);
