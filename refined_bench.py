@@ -30,6 +30,17 @@ def run(refine=2, nts=2048, nsteps=200, with_cpu=True, Re=100., graph=True,
     hier = cylinder_mesh_hierarchy(N=2, refine=refine)
     spaces = [TaylorHood(m) for m, _ in hier][::-1]
     prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
+    if os.environ.get('MG_COLLAPSE'):
+        # experiment: every `MG_COLLAPSE` consecutive prolongations as one
+        # (aggressive coarsening: fewer levels = fewer dependent launches)
+        k = int(os.environ['MG_COLLAPSE'])
+        merged = []
+        for i in range(0, len(prols), k):
+            P = prols[i]
+            for Q in prols[i + 1:i + k]:
+                P = (P @ Q).tocsr()
+            merged.append(P)
+        prols = merged
     F = (M + .5*dt*A).tocsr()
     R1 = (M - .5*dt*A).tocsr()
     t0 = time.perf_counter()
