@@ -306,6 +306,9 @@ struct TrapRhs {
     const int *j_rp, *j_ci;
     const double *j_v;
     double *r, *partR, *partB;
+    // (with x0) workgroups at the END of the row family that take the
+    // pressure rows -- beside the velocity rows, not behind them
+    int pblocks;
 };
 
 // The update norm of a trapezoidal step (trap.hpp, k_trap_updnorm:
@@ -469,6 +472,17 @@ struct dns_conv {
 // ---------------------------------------------------------------------------
 namespace dns {
 
+// waves per SIMD the element-matrix kernels are compiled for: left alone the
+// compiler takes 256 VGPRs + 74 AGPRs (ONE wave per SIMD: 256 workgroups on
+// the whole chip, the 342 of a Newton step run in two rounds)
+#ifndef DNS_CELLS_WAVES
+#define DNS_CELLS_WAVES 1
+#endif
+#ifndef DNS_CELLS_QUNROLL
+#define DNS_CELLS_QUNROLL 1
+#endif
+constexpr int kCellsWaves = DNS_CELLS_WAVES;
+
 __device__ __forceinline__ void
 conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
                      const double *__restrict__ glam,
@@ -512,7 +526,10 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
         n1[b] = 0.0;
         n2[b][0][0] = n2[b][0][1] = n2[b][1][0] = n2[b][1][1] = 0.0;
     }
-#pragma unroll
+    // (the quadrature loop is NOT unrolled: unrolled, the seven points' basis
+    // tables and temporaries take the kernel to 256 VGPRs + 74 AGPRs -- one
+    // wave per SIMD, 256 workgroups on the whole chip)
+#pragma unroll DNS_CELLS_QUNROLL
     for (int q = 0; q < 7; ++q) {
         double uq[2] = {0.0, 0.0};
         double g[2][2] = {{0.0, 0.0}, {0.0, 0.0}};   // g[i][k] = d_k u_i
@@ -573,7 +590,7 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
     }
 }
 
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, kCellsWaves)
 k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
                  const double *__restrict__ glam,
                  const double *__restrict__ area,
@@ -591,7 +608,7 @@ k_conv_mat_cells(int ncells, const int *__restrict__ cellmap,
 // values and output array), the rest -- Newton -- the cell values of
 // N(v_lin) v_lin.  (Three launches before, two of them at the end of the
 // step before.)
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, kCellsWaves)
 k_conv_step_cells(int ga, int gb, int ncells, const int *__restrict__ cellmap,
                   const double *__restrict__ glam,
                   const double *__restrict__ area,
@@ -660,6 +677,163 @@ k_conv_bc_gather(int nrows, const int *__restrict__ bptr,
     }
 }
 
+// The row part of k_conv_mat_bc_gather for the trapezoidal stepper
+// (`rhs.b != nullptr`): Dirichlet-column right-hand side, momentum right-hand
+// side, and -- WITHR -- the start residual with its norms.  What is present
+// (HASG: cell values of N(u)u gathered here, Newton; WITHR: x0; CELLS: the
+// current velocity's cell values) is a template parameter: with run-time
+// tests every optional load sat in a basic block of its own that ended with
+// a wait.
+template <bool HASG, bool WITHR, bool CELLS>
+__device__ __forceinline__ void
+trap_rows(int rb, int nrb, int r0, int nrows, const int *__restrict__ bptr,
+          const int *__restrict__ bidx, const int *__restrict__ bbc,
+          const double *__restrict__ dbcvals, const double *__restrict__ L,
+          const double *__restrict__ mvals, const double *__restrict__ avals,
+          double tdt, double *__restrict__ rhsbc, const double *__restrict__ fv,
+          const double *__restrict__ rhscon, double *__restrict__ fvn,
+          const int *__restrict__ gptr, const int *__restrict__ gidx,
+          const double *__restrict__ cellvals, const TrapRhs &rhs) {
+    constexpr int LR = 16;
+    constexpr bool withr = WITHR;
+    // (the last `pblocks` workgroups: pressure rows only)
+    const int pbl = withr ? min(rhs.pblocks, nrb - 1) : 0;
+    const int nrv = nrb - pbl;
+    const bool prows = rb >= nrv;
+    const int sub = ((prows ? rb - nrv : rb) * kBlock + threadIdx.x) / LR,
+              sl = threadIdx.x % LR;
+    const int nsub = (prows ? pbl : nrv) * (kBlock / LR);
+    __shared__ double red[4];
+    double sr = 0.0, sb = 0.0;       // this thread's share of the norms
+    for (int r = r0 + sub; r < (prows ? 0 : nrows); r += nsub) {
+        double s = 0.0, rc = 0.0, acc = 0.0, kx = 0.0, nx = 0.0, cc = 0.0;
+        // The lists of a row -- boundary pairs, cell values of N(u)u,
+        // the row of M / A, cell vectors of x0 and of the current
+        // velocity, the row of J^T -- are walked in THREE memory round
+        // trips for the common case (a lane's first entry of each list,
+        // two of the matrix row): all list bounds, then all indices and
+        // matrix values, then all gathers.  One list after the other it
+        // was two round trips per list.  Longer lists finish in the
+        // loops behind; every sum keeps the order it had.
+        constexpr bool wcx = WITHR || CELLS;
+        const int pb = bptr[r] + sl, pb1 = bptr[r + 1];
+        const int pg = HASG ? gptr[r] + sl : 0, pg1 = HASG ? gptr[r + 1] : 0;
+        const int pf = rhs.rowptr[r] + sl, pf1 = rhs.rowptr[r + 1];
+        const int pc = wcx ? rhs.cgptr[r] + sl : 0,
+                  pc1 = wcx ? rhs.cgptr[r + 1] : 0;
+        const int pj = withr ? rhs.jt_rp[r] + sl : 0,
+                  pj1 = withr ? rhs.jt_rp[r + 1] : 0;
+        const bool vb = pb < pb1, vg = pg < pg1, vf = pf < pf1,
+                   vf2 = pf + LR < pf1, vc = pc < pc1, vj = pj < pj1;
+        // (a list that is empty for this lane reads entry 0 of its
+        // arrays -- they are never empty -- and drops the value)
+        const int ib = bidx[vb ? pb : 0], ibc = bbc[vb ? pb : 0];
+        const int ig = HASG ? gidx[vg ? pg : 0] : 0;
+        const int qf = vf ? pf : 0, qf2 = vf2 ? pf + LR : 0;
+        const int icf = rhs.colidx[qf], icf2 = rhs.colidx[qf2];
+        const double mk = mvals[qf], ak = avals[qf];
+        const double mk2 = mvals[qf2], ak2 = avals[qf2];
+        const int ic = wcx ? rhs.cgidx[vc ? pc : 0] : 0;
+        const int qj = vj ? pj : 0;
+        const int ij = withr ? rhs.jt_ci[qj] : 0;
+        const double jv = withr ? rhs.jt_v[qj] : 0.0;
+        // (an index read for an empty list is not used as one: a table
+        // without entries holds one uninitialised element)
+        const double lb = L[vb ? ib : 0], db = dbcvals[vb ? ibc : 0];
+        const double gcv = HASG ? cellvals[vg ? ig : 0] : 0.0;
+        const int jf = vf ? icf : 0, jf2 = vf2 ? icf2 : 0;
+        const double vc1 = rhs.v_c[jf], vc2 = rhs.v_c[jf2];
+        const double x01 = withr ? rhs.x0[jf] : 0.0,
+                     x02 = withr ? rhs.x0[jf2] : 0.0;
+        const int jc = vc ? ic : 0;
+        const double cxv = withr ? rhs.cx0[jc] : 0.0;
+        const double ccv = CELLS ? rhs.cells_c[jc] : 0.0;
+        const double xj = withr ? rhs.x0[vj ? rhs.nv + ij : 0] : 0.0;
+        if (vb) s = fma(lb, db, s);
+        for (int k = pb + LR; k < pb1; k += LR)
+            s = fma(L[bidx[k]], dbcvals[bbc[k]], s);
+        if (vg) rc += gcv;
+        for (int k = pg + LR; k < pg1; k += LR) rc += cellvals[gidx[k]];
+        if (vf) {
+            acc = fma(mk - tdt * ak, vc1, acc);
+            if (withr) kx = fma(fma(tdt, ak, mk), x01, kx);
+        }
+        if (vf2) {
+            acc = fma(mk2 - tdt * ak2, vc2, acc);
+            if (withr) kx = fma(fma(tdt, ak2, mk2), x02, kx);
+        }
+        for (int k = pf + 2 * LR; k < pf1; k += LR) {
+            const int c = rhs.colidx[k];
+            const double mkk = mvals[k], akk = avals[k];
+            acc = fma(mkk - tdt * akk, rhs.v_c[c], acc);
+            if (withr) kx = fma(fma(tdt, akk, mkk), rhs.x0[c], kx);
+        }
+        if (withr) {
+            if (vc) nx += cxv;
+            for (int k = pc + LR; k < pc1; k += LR)
+                nx += rhs.cx0[rhs.cgidx[k]];
+            kx = fma(tdt, nx, kx);
+            if (vj) kx = fma(jv, xj, kx);
+            for (int k = pj + LR; k < pj1; k += LR)
+                kx = fma(rhs.jt_v[k], rhs.x0[rhs.nv + rhs.jt_ci[k]], kx);
+        }
+        if (rhs.cells_c) {
+            if (vc) cc += ccv;
+            for (int k = pc + LR; k < pc1; k += LR)
+                cc += rhs.cells_c[rhs.cgidx[k]];
+        }
+        s = subwave_sum<LR>(s);
+        rc = subwave_sum<LR>(rc);
+        acc = subwave_sum<LR>(acc);
+        cc = subwave_sum<LR>(cc);
+        if (withr) kx = subwave_sum<LR>(kx);
+        if (sl == 0) {
+            if (!HASG && rhscon) rc = rhscon[r];
+            rhsbc[r] = -s;
+            const double fn = fv[r] - s + rc;
+            if (fvn) fvn[r] = fn;
+            const double fc = CELLS ? rhs.fv_c[r] - cc
+                                         : rhs.fvn_c[r];
+            const double bv = acc + tdt * (fn + fc);
+            rhs.b[r] = bv;
+            if (withr) {
+                const double rv = bv - kx;
+                rhs.r[r] = rv;
+                sr = fma(rv, rv, sr);
+                sb = fma(bv, bv, sb);
+            }
+        }
+    }
+    if (!withr) {
+        for (int i = rb * kBlock + threadIdx.x; i < rhs.np;
+             i += nrb * kBlock)
+            rhs.b[rhs.nv + i] = rhs.fp[i];
+        return;
+    }
+    // pressure rows: b_p = fp, r_p = fp - J x0_v (sixteen lanes per row)
+    for (int i = sub; i < ((prows || pbl == 0) ? rhs.np : 0); i += nsub) {
+        double jx = 0.0;
+        for (int k = rhs.j_rp[i] + sl; k < rhs.j_rp[i + 1]; k += LR)
+            jx = fma(rhs.j_v[k], rhs.x0[rhs.j_ci[k]], jx);
+        jx = subwave_sum<LR>(jx);
+        if (sl == 0) {
+            const double bp = rhs.fp[i], rp = bp - jx;
+            rhs.b[rhs.nv + i] = bp;
+            rhs.r[rhs.nv + i] = rp;
+            sr = fma(rp, rp, sr);
+            sb = fma(bp, bp, sb);
+        }
+    }
+    sr = block_sum(sr, red);
+    __syncthreads();
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0) {
+        rhs.partR[rb] = sr;
+        rhs.partB[rb] = sb;
+    }
+    return;
+}
+
 // both gathers of an assembly in ONE launch (they read the same local
 // matrices and do not need each other): workgroups [0, gm) the matrix values,
 // the rest the Dirichlet-column right-hand side and -- fvn != nullptr -- the
@@ -692,7 +866,16 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
         for (int z = z0 + blockIdx.x * kBlock + threadIdx.x; z < nnz;
              z += gm * kBlock) {
             double s = 0.0;
-            for (int k = mptr[z]; k < mptr[z + 1]; ++k) s += L[midx[k]];
+            // two contributions per pass (a non-zero has 1.5 on average,
+            // six to eight on the diagonal): their indices first, then the
+            // gathers -- the sum runs in the order of the list as before
+            const int k1 = mptr[z + 1];
+            for (int k = mptr[z]; k < k1; k += 2) {
+                const int i0 = midx[k], i1 = midx[min(k + 1, k1 - 1)];
+                const double l0 = L[i0], l1 = L[i1];
+                s += l0;
+                s += (k + 1 < k1) ? l1 : 0.0;
+            }
             nvals[z] = s;
             if (fvals) {
                 const double f = mvals[z] + tdt * (avals[z] + s);
@@ -705,86 +888,20 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
     const double *__restrict__ dbcvals = tab_row(dbctab);
     const int rb = blockIdx.x - gm, nrb = gridDim.x - gm;
     if (rhs.b) {
-        constexpr int LR = 16;
-        const int sub = (rb * kBlock + threadIdx.x) / LR, sl = threadIdx.x % LR;
-        const int nsub = nrb * (kBlock / LR);
-        const bool withr = rhs.x0 != nullptr;
-        __shared__ double red[4];
-        double sr = 0.0, sb = 0.0;       // this thread's share of the norms
-        for (int r = r0 + sub; r < nrows; r += nsub) {
-            double s = 0.0, rc = 0.0, acc = 0.0, kx = 0.0;
-            for (int k = bptr[r] + sl; k < bptr[r + 1]; k += LR)
-                s = fma(L[bidx[k]], dbcvals[bbc[k]], s);
-            if (gptr)
-                for (int k = gptr[r] + sl; k < gptr[r + 1]; k += LR)
-                    rc += cellvals[gidx[k]];
-            for (int k = rhs.rowptr[r] + sl; k < rhs.rowptr[r + 1]; k += LR) {
-                const int c = rhs.colidx[k];
-                const double mk = mvals[k], ak = avals[k];
-                acc = fma(mk - tdt * ak, rhs.v_c[c], acc);
-                if (withr) kx = fma(fma(tdt, ak, mk), rhs.x0[c], kx);
-            }
-            if (withr) {
-                double nx = 0.0;
-                for (int k = rhs.cgptr[r] + sl; k < rhs.cgptr[r + 1]; k += LR)
-                    nx += rhs.cx0[rhs.cgidx[k]];
-                kx = fma(tdt, nx, kx);
-                for (int k = rhs.jt_rp[r] + sl; k < rhs.jt_rp[r + 1]; k += LR)
-                    kx = fma(rhs.jt_v[k], rhs.x0[rhs.nv + rhs.jt_ci[k]], kx);
-            }
-            double cc = 0.0;
-            if (rhs.cells_c)
-                for (int k = rhs.cgptr[r] + sl; k < rhs.cgptr[r + 1]; k += LR)
-                    cc += rhs.cells_c[rhs.cgidx[k]];
-            s = subwave_sum<LR>(s);
-            rc = subwave_sum<LR>(rc);
-            acc = subwave_sum<LR>(acc);
-            cc = subwave_sum<LR>(cc);
-            if (withr) kx = subwave_sum<LR>(kx);
-            if (sl == 0) {
-                if (!gptr && rhscon) rc = rhscon[r];
-                rhsbc[r] = -s;
-                const double fn = fv[r] - s + rc;
-                if (fvn) fvn[r] = fn;
-                const double fc = rhs.cells_c ? rhs.fv_c[r] - cc
-                                             : rhs.fvn_c[r];
-                const double bv = acc + tdt * (fn + fc);
-                rhs.b[r] = bv;
-                if (withr) {
-                    const double rv = bv - kx;
-                    rhs.r[r] = rv;
-                    sr = fma(rv, rv, sr);
-                    sb = fma(bv, bv, sb);
-                }
-            }
+        const bool hg = gptr != nullptr, wr = rhs.x0 != nullptr,
+                   cl = rhs.cells_c != nullptr;
+#define DNS_TRAP_ROWS(G, R, C)                                               \
+    trap_rows<G, R, C>(rb, nrb, r0, nrows, bptr, bidx, bbc, dbcvals, L,      \
+                       mvals, avals, tdt, rhsbc, fv, rhscon, fvn, gptr, gidx, \
+                       cellvals, rhs)
+        if (hg) {
+            if (wr) { if (cl) DNS_TRAP_ROWS(true, true, true); else DNS_TRAP_ROWS(true, true, false); }
+            else { if (cl) DNS_TRAP_ROWS(true, false, true); else DNS_TRAP_ROWS(true, false, false); }
+        } else {
+            if (wr) { if (cl) DNS_TRAP_ROWS(false, true, true); else DNS_TRAP_ROWS(false, true, false); }
+            else { if (cl) DNS_TRAP_ROWS(false, false, true); else DNS_TRAP_ROWS(false, false, false); }
         }
-        if (!withr) {
-            for (int i = rb * kBlock + threadIdx.x; i < rhs.np;
-                 i += nrb * kBlock)
-                rhs.b[rhs.nv + i] = rhs.fp[i];
-            return;
-        }
-        // pressure rows: b_p = fp, r_p = fp - J x0_v (sixteen lanes per row)
-        for (int i = sub; i < rhs.np; i += nsub) {
-            double jx = 0.0;
-            for (int k = rhs.j_rp[i] + sl; k < rhs.j_rp[i + 1]; k += LR)
-                jx = fma(rhs.j_v[k], rhs.x0[rhs.j_ci[k]], jx);
-            jx = subwave_sum<LR>(jx);
-            if (sl == 0) {
-                const double bp = rhs.fp[i], rp = bp - jx;
-                rhs.b[rhs.nv + i] = bp;
-                rhs.r[rhs.nv + i] = rp;
-                sr = fma(rp, rp, sr);
-                sb = fma(bp, bp, sb);
-            }
-        }
-        sr = block_sum(sr, red);
-        __syncthreads();
-        sb = block_sum(sb, red);
-        if (threadIdx.x == 0) {
-            rhs.partR[rb] = sr;
-            rhs.partB[rb] = sb;
-        }
+#undef DNS_TRAP_ROWS
         return;
     }
     for (int r = r0 + rb * kBlock + threadIdx.x; r < nrows; r += nrb * kBlock) {
@@ -884,7 +1001,8 @@ inline int dns_conv::enqueue_mat_bc_gather(double *nvals, const double *mvals,
                                             dns::kBlock, 4096));
     // (with the right-hand side: sixteen lanes per row)
     const int gb = std::max(1, std::min(((rhs ? 16 : 1) * (r1 - r0) +
-                                         dns::kBlock - 1) / dns::kBlock, 2048));
+                                         dns::kBlock - 1) / dns::kBlock, 2048)) +
+                   ((rhs && rhs->x0) ? rhs->pblocks : 0);
     hipLaunchKernelGGL(dns::k_conv_mat_bc_gather, gm + gb, dns::kBlock, 0, s,
                        gm, z1, mat->mptr.p, mat->midx.p, mat->L.p, nvals,
                        mvals, avals, tdt, fvals, r1, mat->bptr.p,
