@@ -602,7 +602,11 @@ k_arn_tail6(int c, int n, int nrow_blocks,
     }
     if (open_col) reduce_partials(norm_part, nparts, nparts, c + 1, sc);
     if (threadIdx.x == 0) {
-        double gl[2] = {0.0, 0.0}, rcol[kMaxRestart + 1];
+        // (the column being closed lives in LDS: as a local array indexed
+        // at run time it went to scratch memory, 528 bytes per lane of every
+        // wave of the launch for one thread's use)
+        __shared__ double rcol[kMaxRestart + 1];
+        double gl[2] = {0.0, 0.0};
         int jcols = ctl->jdone, status = DNS_OK, conv = 0, tot = ctl->total_it;
         double res = ctl->resnorm;
         bool closed = false;
