@@ -491,7 +491,11 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
                      int newton, double *__restrict__ L,    // [144][ncells]
                      const int *__restrict__ sel, int nsel,
                      const double *__restrict__ x0 = nullptr,
-                     double *__restrict__ cx0 = nullptr) {   // [12][ncells]
+                     double *__restrict__ cx0 = nullptr,     // [12][ncells]
+                     double *__restrict__ clin = nullptr) {  // [12][ncells]
+    // clin: the cell values of N(v_lin) v_lin = N1_cell u_cell ride along as
+    // well (Newton's right-hand side, snu:126-133: a family of workgroups of
+    // its own before, 114 of the 598 of a launch that has 512 places)
     // x0 / cx0: the rows (a, i) of L_cell x0_cell ride along (x0 an inner
     // vector: Dirichlet dofs contribute nothing) -- the cell values of
     // N(v_lin) x0 for the residual formed in the gather launch (TrapRhs)
@@ -573,6 +577,15 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
                     ((i == k) ? n1[b] : 0.0) + (newton ? n2[b][i][k] : 0.0);
                 L[(size_t)slot * ncells + c] = v;
             }
+    if (clin) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            double y = 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) y = fma(n1[b], ul[b][i], y);
+            clin[(size_t)(2 * a + i) * ncells + c] = y;
+        }
+    }
     if (cx0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -621,8 +634,11 @@ k_conv_step_cells(int ga, int gb, int ncells, const int *__restrict__ cellmap,
                   int gc, UpdJob upd) {
     const int bid = blockIdx.x;
     if (bid < ga) {
+        // (gc == 0 with Newton: N(v_lin) v_lin comes out of this family)
         conv_mat_cells_block(bid, ncells, cellmap, glam, area, v_lin, dbc_lin,
-                             newton, L, sel, nsel, x0, cx0);
+                             newton, L, sel, nsel, x0, cx0,
+                             (newton && gc == 0) ? cells_lin
+                                                 : (double *)nullptr);
     } else if (bid < ga + gb) {
         conv_cells_block(bid - ga, ncells, cellmap, glam, area,
                          ConvFromVec{x_c}, dbc_c, cells_c, sel, nsel);
@@ -960,7 +976,8 @@ inline int dns_conv::enqueue_step_cells(const double *v_lin, int newton,
     if (x0 && cellvals_x0.n < (size_t)12 * ncells)
         DNS_TRY(cellvals_x0.alloc((size_t)12 * ncells));
     const int g = (8 * live + dns::kBlock - 1) / dns::kBlock;
-    const int gc = newton ? g : 0;
+    // (Newton's N(v_lin) v_lin: by the matrix family itself, no third one)
+    const int gc = 0;
     hipLaunchKernelGGL(dns::k_conv_step_cells,
                        2 * g + gc + (upd ? upd->nblk : 0),
                        dns::kBlock, 0, s, g, g, ncells, cellmap.p, glam.p,
