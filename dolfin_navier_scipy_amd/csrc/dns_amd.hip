@@ -117,7 +117,7 @@ int dns_saddle::init_device(int dev) {
     if (const char *sn = getenv("DNS_DIST_GRAPH")) dist_graph_ok = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_CHEB")) mg_cheb = sn[0] != '0';
     if (const char *sn = getenv("DNS_MG_CYCLES"))
-        mg_cycles = std::max(1, std::min(2, atoi(sn)));
+        mg_cycles_knob = std::max(0, std::min(2, atoi(sn)));
     if (const char *sn = getenv("DNS_MG_RHO"))
         mg_rho = std::max(0.01, std::min(0.95, atof(sn)));
     if (const char *sn = getenv("DNS_MG_CHEB_ALPHA"))
@@ -1222,9 +1222,17 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     oversolve = oversolve_env >= 0 ? oversolve_env != 0
                                    : (popts.schur == DNS_SCHUR_MG &&
                                       n < 1500000);
+    // (two cycles per application of the multigrid block where whole Krylov
+    // cycles are run: solver.hpp, mg_cycles; one column then suffices)
+    mg_cycles = mg_cycles_knob > 0
+                    ? mg_cycles_knob
+                    : ((oversolve && popts.schur == DNS_SCHUR_MG && !comm) ? 2
+                                                                           : 1);
     oversolve_cmin = oversolve_cmin_env > 0
                          ? oversolve_cmin_env
-                         : (popts.schur == DNS_SCHUR_MG ? 2 : 1);
+                         : (popts.schur == DNS_SCHUR_MG
+                                ? ((mg_cycles >= 2 && !comm) ? 1 : 2)
+                                : 1);
     if (popts.cheb_degree < 1 || popts.cheb_degree > 256)
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
@@ -2258,7 +2266,8 @@ static int dns_saddle_set_option_impl(dns_saddle *h, const char *name, double va
     else if (k == "mg_fused") h->mg_fused_knob = value != 0.0;
     else if (k == "mg_cheb") h->mg_cheb = value != 0.0;
     else if (k == "mg_cheb_alpha") h->mg_cheb_alpha = std::max(1.5, value);
-    else if (k == "mg_cycles") h->mg_cycles = std::max(1, std::min(2, (int)value));
+    else if (k == "mg_cycles")
+        h->mg_cycles_knob = std::max(0, std::min(2, (int)value));
     else if (k == "mg_rho") h->mg_rho = std::max(0.01, std::min(0.95, value));
     else if (k == "dist_graph") h->dist_graph_ok = value != 0.0;
     else if (k == "oversolve") h->oversolve_env = value < 0.0 ? -1 : (value != 0.0);
@@ -2971,6 +2980,8 @@ static int dns_saddle_precond_info_impl(dns_saddle *h, int32_t cap, int64_t *out
                        : (h->mg_cinv16.p ? 2
                                          : (h->fp32_store && h->mg_cinv32.p ? 4
                                                                             : 8)));
+    // (cycles per application of the multigrid block as it runs)
+    v.push_back(L == 0 ? 0 : ((h->mg_cycles >= 2 && !h->dist()) ? 2 : 1));
     *count = (int32_t)v.size();
     if (out)
         for (int32_t i = 0; i < std::min<int32_t>(cap, *count); ++i)

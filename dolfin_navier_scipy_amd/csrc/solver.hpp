@@ -636,7 +636,16 @@ struct dns_saddle {
     // as two Richardson steps at the Chebyshev roots of [1 - rho, 1]
     // (DNS_MG_RHO: bound of the cycle's contraction number) -- a LINEAR map
     // of its input like one cycle (the fused Gram-Schmidt relies on that)
+    // Default (mg_cycles_knob == 0): TWO cycles where the pipelined batches
+    // run whole Krylov cycles (`oversolve`: multigrid Schur block, fewer than
+    // 1.5e6 unknowns, one GPU) -- the second cycle costs nine small launches,
+    // a second Krylov column costs those nine AND the K apply, the head, the
+    // J Fh^-1 and the Fh^-1 products; with the stronger block one column per
+    // time step holds (the warm start stays below the tolerance, the column
+    // keeps it there): refine 2 4835 -> 5636 steps/s, refine 3 1905 -> 2483
+    // (profiles/r05_mg_cycles/); ONE cycle otherwise
     int mg_cycles = 1;
+    int mg_cycles_knob = 0;           // 0 = auto, 1 / 2 = as said
     double mg_rho = 0.3;
     dns::DevBuf<double> mg_r2, mg_z2;
     int schur_mg_apply(const double *in, double *zp, double *xacc,

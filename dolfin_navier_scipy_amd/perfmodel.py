@@ -52,6 +52,15 @@ def _schur_ops(info, moved):
     vb = 2 if cb == 2 else (4 if (fp32 and cb == 4) else 8)
     ops.append(('MG coarsest: dense inverse GEMV', 1,
                 vb*ncoarse*ncoarse + 16*ncoarse))
+    ncyc = info.get('mg_cycles', 1)
+    if ncyc > 1:
+        # two cycles as two Richardson steps: everything above once more,
+        # the residual in - S_0 x_1 between them and the combination
+        ops = [(name, cnt*ncyc, b) for name, cnt, b in ops]
+        n0 = lv[0]['n']
+        ops.append(('MG: residual between the cycles, SpMV(S_0)', ncyc - 1,
+                    spmv_bytes(lv[0]['nnz_S'], n0, n0) + 8*n0))
+        ops.append(('MG: x_1 + a_2 V(r)', ncyc - 1, 24*n0))
     return ops
 
 

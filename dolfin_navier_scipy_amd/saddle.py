@@ -197,6 +197,7 @@ class SaddleSystem(object):
         tail = 9 + 3*v[7]
         out['pair_format_bytes'] = v[tail] if len(v) > tail else 0
         out['mg_coarse_val_bytes'] = v[tail + 1] if len(v) > tail + 1 else 8
+        out['mg_cycles'] = max(1, v[tail + 2]) if len(v) > tail + 2 else 1
         return out
 
     def solve(self, rhsv, rhsp=None, x0=None, raise_on_fail=True, **kw):
