@@ -1164,7 +1164,7 @@ int dns_saddle::mg_cycle_fused11(const double *in, double *zp, double *xacc,
 //   x1 = a1 V(in);  x2 = x1 + a2 V(in - S x1);  zp = -x2
 int dns_saddle::schur_mg_apply_fused(const double *in, double *zp, double *xacc,
                                      const int *guard) {
-    if (mg_cycles < 2 || dist())
+    if (mg_cycles_eff() < 2)
         return mg_cycle_fused(in, zp, xacc, guard, 1.0);
     const double mid = 1.0 - 0.5 * mg_rho, rad = 0.5 * mg_rho;
     const double c = 0.70710678118654752;
@@ -1226,13 +1226,10 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     // cycles are run: solver.hpp, mg_cycles; one column then suffices)
     mg_cycles = mg_cycles_knob > 0
                     ? mg_cycles_knob
-                    : ((oversolve && popts.schur == DNS_SCHUR_MG && !comm) ? 2
-                                                                           : 1);
-    oversolve_cmin = oversolve_cmin_env > 0
-                         ? oversolve_cmin_env
-                         : (popts.schur == DNS_SCHUR_MG
-                                ? ((mg_cycles >= 2 && !comm) ? 1 : 2)
-                                : 1);
+                    : ((oversolve && popts.schur == DNS_SCHUR_MG) ? 2 : 1);
+    // (the shortest cycle of the batches: oversolve_cmin_eff(), once the
+    // partition of the hierarchy is known)
+    oversolve_cmin = oversolve_cmin_eff();
     if (popts.cheb_degree < 1 || popts.cheb_degree > 256)
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
@@ -2981,7 +2978,7 @@ static int dns_saddle_precond_info_impl(dns_saddle *h, int32_t cap, int64_t *out
                                          : (h->fp32_store && h->mg_cinv32.p ? 4
                                                                             : 8)));
     // (cycles per application of the multigrid block as it runs)
-    v.push_back(L == 0 ? 0 : ((h->mg_cycles >= 2 && !h->dist()) ? 2 : 1));
+    v.push_back(L == 0 ? 0 : h->mg_cycles_eff());
     *count = (int32_t)v.size();
     if (out)
         for (int32_t i = 0; i < std::min<int32_t>(cap, *count); ++i)

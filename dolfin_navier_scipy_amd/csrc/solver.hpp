@@ -646,6 +646,17 @@ struct dns_saddle {
     // (profiles/r05_mg_cycles/); ONE cycle otherwise
     int mg_cycles = 1;
     int mg_cycles_knob = 0;           // 0 = auto, 1 / 2 = as said
+    // (what runs: a row-partitioned solve keeps ONE cycle -- the two-cycle
+    // path has no partitioned residual product, and with a hierarchy every
+    // rank holds whole the second cycle did not buy the one-column regime on
+    // the partitioned path: n = 173k on one rank 3916 -> 3152 steps/s at two
+    // columns, n = 693k 1856 -> 2006 at 1.3, profiles/r05_mg_cycles/)
+    int mg_cycles_eff() const { return (mg_cycles >= 2 && !dist()) ? 2 : 1; }
+    int oversolve_cmin_eff() const {
+        if (oversolve_cmin_env > 0) return oversolve_cmin_env;
+        if (popts.schur != DNS_SCHUR_MG) return 1;
+        return mg_cycles_eff() >= 2 ? 1 : 2;
+    }
     double mg_rho = 0.3;
     dns::DevBuf<double> mg_r2, mg_z2;
     int schur_mg_apply(const double *in, double *zp, double *xacc,

@@ -132,6 +132,11 @@ def _solve_and_step(sad, comm, fhat, reorth, fact='triangular', info=None):
         # partitioned (the default with a communicator)
         knobs['DNS_PART_SETUP'] = '0'
         fhat = fhat[:-4]
+    if fhat in ('mg', 'mgpart', 'mg3', 'mg3part', 'mg3parts'):
+        # ONE V-cycle per application: what a row-partitioned solve runs
+        # (`mg_cycles_eff`); the single-rank runs it is compared with run the
+        # same block, not their default of two cycles
+        knobs['DNS_MG_CYCLES'] = '1'
     if fhat in ('mgpart', 'mg3part', 'mg3parts'):
         knobs['DNS_MG_PART_MIN'] = '0'
     if fhat in ('mg3', 'mg3part', 'mg3parts'):
