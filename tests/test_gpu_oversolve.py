@@ -101,3 +101,45 @@ def test_oversolve_option_and_defaults():
     with pytest.raises(_capi.DnsError):
         system.set_option('oversolve_typo', 1)
     system.close()
+
+
+def test_two_cycles_where_whole_krylov_cycles_are_run():
+    """the multigrid block applies TWO V-cycles exactly where the batches run
+    whole Krylov cycles (oversolve on: launch-bound sizes, one GPU) -- one
+    column per time step then holds, `profiles/r05_mg_cycles/` -- and one
+    cycle when oversolve is off or the option says so; the byte model of the
+    bench counts what runs"""
+    from dolfin_navier_scipy_amd import saddle, perfmodel
+    from dolfin_navier_scipy_amd.fem import (get_sysmats, TaylorHood,
+                                             cylinder_mesh_hierarchy,
+                                             pressure_prolongations)
+    femp, sm, rhsd = get_sysmats(problem='cylinderwake', N=2, refine=1,
+                                 Re=100.)
+    M, A, J = sm['M'], sm['A'], sm['J']
+    dt = 1./1024
+    hier = cylinder_mesh_hierarchy(N=2, refine=1)
+    spaces = [TaylorHood(m) for m, _ in hier][::-1]
+    prols = pressure_prolongations(spaces, [p for _, p in hier][::-1])
+    got = {}
+    for name, opts in (('default', {}), ('oversolve off', {'oversolve': 0}),
+                       ('one cycle', {'mg_cycles': 1})):
+        system = saddle.SaddleSystem((M + .5*dt*A).tocsr(), J)
+        system.set_schur_mg(prols)
+        for k, v in opts.items():
+            system.set_option(k, v)
+        system.setup_precond(cheb_degree=8, schur='mg', drop_tol=7e-3,
+                             fhat='explicit', factorization='full')
+        info = system.precond_info()
+        got[name] = (info['mg_cycles'],
+                     sum(c*b for _, c, b in perfmodel._schur_ops(info, False)))
+        rng = np.random.default_rng(0)
+        x = system.solve(M @ rng.standard_normal(M.shape[0]), rtol=1e-10,
+                         maxiter=200)
+        assert system.last_stats['status'] == 0
+        got[name] += (system.last_stats['iters'],)
+        system.close()
+    assert got['default'][0] == 2
+    assert got['oversolve off'][0] == 1 and got['one cycle'][0] == 1
+    # two cycles move about twice the bytes of the block and save Krylov steps
+    assert 1.9*got['one cycle'][1] <= got['default'][1] <= 2.3*got['one cycle'][1]
+    assert got['default'][2] < got['one cycle'][2]
