@@ -1164,7 +1164,7 @@ int dns_saddle::mg_cycle_fused11(const double *in, double *zp, double *xacc,
 //   x1 = a1 V(in);  x2 = x1 + a2 V(in - S x1);  zp = -x2
 int dns_saddle::schur_mg_apply_fused(const double *in, double *zp, double *xacc,
                                      const int *guard) {
-    if (mg_cycles_eff() < 2)
+    if (!mg_two_now)
         return mg_cycle_fused(in, zp, xacc, guard, 1.0);
     const double mid = 1.0 - 0.5 * mg_rho, rad = 0.5 * mg_rho;
     const double c = 0.70710678118654752;
@@ -1230,6 +1230,7 @@ int dns_saddle::setup_precond(const dns_precond_opts *o) {
     // (the shortest cycle of the batches: oversolve_cmin_eff(), once the
     // partition of the hierarchy is known)
     oversolve_cmin = oversolve_cmin_eff();
+    mg_two_now = mg_two_for(1000);    // (outside a Krylov cycle: as the option says)
     if (popts.cheb_degree < 1 || popts.cheb_degree > 256)
         return fail(DNS_ERR_BAD_ARGUMENT, "cheb_degree out of range");
     precond_ready = false;
@@ -1578,6 +1579,9 @@ static inline uint64_t bits_of(double v) {
 int dns_saddle::enqueue_cycle(const double *b, double *x, int c,
                               const dns_solve_opts *o, int first,
                               bool have_resid) {
+    // (cycles per application of the multigrid block in THIS Krylov cycle:
+    // part of what a captured graph of length c holds)
+    mg_two_now = mg_two_for(c);
     // `first`: 1 = the head kernel of this cycle resets the solve's counters,
     // 2 = only its status (going on after a Gram-Schmidt fallback)
     // (one GPU; the row-partitioned solve has its own: enqueue_cycle_dist)
@@ -2979,6 +2983,9 @@ static int dns_saddle_precond_info_impl(dns_saddle *h, int32_t cap, int64_t *out
                                                                             : 8)));
     // (cycles per application of the multigrid block as it runs)
     v.push_back(L == 0 ? 0 : h->mg_cycles_eff());
+    // (... in Krylov cycles of at most this many columns: 1 by default, any
+    // when the option says two)
+    v.push_back(L == 0 ? 0 : (h->mg_cycles_knob == 2 ? 1000 : 1));
     *count = (int32_t)v.size();
     if (out)
         for (int32_t i = 0; i < std::min<int32_t>(cap, *count); ++i)

@@ -642,8 +642,9 @@ struct dns_saddle {
     // a second Krylov column costs those nine AND the K apply, the head, the
     // J Fh^-1 and the Fh^-1 products; with the stronger block one column per
     // time step holds (the warm start stays below the tolerance, the column
-    // keeps it there): refine 2 4835 -> 5636 steps/s, refine 3 1905 -> 2483
-    // (profiles/r05_mg_cycles/); ONE cycle otherwise
+    // keeps it there): refine 2 4835 -> 5650-5750 steps/s, refine 3 1905 ->
+    // 2480 (profiles/r05_mg_cycles/); ONE cycle otherwise, and -- chosen by
+    // default -- in cycles of more than one column (mg_two_for)
     int mg_cycles = 1;
     int mg_cycles_knob = 0;           // 0 = auto, 1 / 2 = as said
     // (what runs: a row-partitioned solve keeps ONE cycle -- the two-cycle
@@ -652,6 +653,16 @@ struct dns_saddle {
     // the partitioned path: n = 173k on one rank 3916 -> 3152 steps/s at two
     // columns, n = 693k 1856 -> 2006 at 1.3, profiles/r05_mg_cycles/)
     int mg_cycles_eff() const { return (mg_cycles >= 2 && !dist()) ? 2 : 1; }
+    // Chosen by default (knob 0), the second cycle runs in ONE-column Krylov
+    // cycles only: a longer cycle is what a transient needs, and there a
+    // second column (one cycle each) is the cheaper way to the same
+    // reduction -- with two cycles in every column a 200-step window that
+    // starts in a two-column phase ran at 3360 steps/s instead of 4810 (refine
+    // 2).  enqueue_cycle sets `mg_two_now` for the kernels it enqueues.
+    bool mg_two_now = false;
+    bool mg_two_for(int c) const {
+        return mg_cycles_eff() >= 2 && (mg_cycles_knob == 2 || c <= 1);
+    }
     int oversolve_cmin_eff() const {
         if (oversolve_cmin_env > 0) return oversolve_cmin_env;
         if (popts.schur != DNS_SCHUR_MG) return 1;

@@ -132,6 +132,10 @@ def cnab_step_ops(info, nnz_R1, ncells, iters, moved=False):
 def step_roofline(info, nnz_R1, ncells, iters, ms_per_step, peak_GBs=8000.,
                   regime=None):
     """the `roofline.step` block of the bench line"""
+    if info.get('mg_cycles', 1) > 1 and \
+            iters > info.get('mg_two_cycle_maxc', 1000) + 0.5:
+        # (the second V-cycle runs in cycles of at most that many columns)
+        info = dict(info, mg_cycles=1)
     ops = cnab_step_ops(info, nnz_R1, ncells, iters, moved=False)
     total = sum(c*b for _, c, b in ops)
     moved = sum(c*b for _, c, b in

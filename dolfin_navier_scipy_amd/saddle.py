@@ -198,6 +198,7 @@ class SaddleSystem(object):
         out['pair_format_bytes'] = v[tail] if len(v) > tail else 0
         out['mg_coarse_val_bytes'] = v[tail + 1] if len(v) > tail + 1 else 8
         out['mg_cycles'] = max(1, v[tail + 2]) if len(v) > tail + 2 else 1
+        out['mg_two_cycle_maxc'] = v[tail + 3] if len(v) > tail + 3 else 0
         return out
 
     def solve(self, rhsv, rhsp=None, x0=None, raise_on_fail=True, **kw):
