@@ -488,7 +488,7 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
                      const double *__restrict__ glam,
                      const double *__restrict__ area,
                      const double *__restrict__ v_inner, TabRef dbctab,
-                     int newton, double *__restrict__ L,    // [144][ncells]
+                     int newton, double *__restrict__ L,    // [ncells][144]
                      const int *__restrict__ sel, int nsel,
                      const double *__restrict__ x0 = nullptr,
                      double *__restrict__ cx0 = nullptr,     // [12][ncells]
@@ -575,7 +575,7 @@ conv_mat_cells_block(int bid, int ncells, const int *__restrict__ cellmap,
                 const int slot = (2 * a + i) * 12 + (2 * b + k);
                 const double v =
                     ((i == k) ? n1[b] : 0.0) + (newton ? n2[b][i][k] : 0.0);
-                L[(size_t)slot * ncells + c] = v;
+                L[(size_t)c * 144 + slot] = v;
             }
     if (clin) {
 #pragma unroll
@@ -943,7 +943,7 @@ k_conv_mat_bc_gather(int gm, int nnz, const int *__restrict__ mptr,
 struct dns_conv_mat {
     int nnz = 0;
     dns::DevBuf<int> mptr, midx, bptr, bidx, bbc;
-    dns::DevBuf<double> L;            // [144][ncells] local matrices
+    dns::DevBuf<double> L;            // [ncells][144] local matrices
 };
 
 inline dns_conv::~dns_conv() { delete mat; }
